@@ -1,0 +1,339 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by importing the REFERENCE's own lib/models on PyTorch-CPU.
+
+Runs only in the build container (needs /root/reference).  Nothing from the reference
+is written into this repo except numeric inputs/outputs.  Harness-side patches, applied
+in this process only:
+  1. Tensor.cuda / Module.cuda become identity (models.py:119-120, connect.py:219 call
+     .cuda() at construct time);
+  2. the PrRoIPool JIT loader is replaced by a raising stub (its hipify step would write
+     into /root/reference);
+  3. forward passes run under no_grad and eval().
+
+Usage:  python tests/golden/make_golden.py [calib] [model] [host] [e2e]
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True    # never leave __pycache__ inside /root/reference
+
+import numpy as np
+
+REF = '/root/reference'
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+GOLD = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, REF)           # `lib` must resolve to the reference here
+sys.path.insert(1, REPO)
+sys.path.insert(2, GOLD)
+
+import torch  # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+
+import lib.models.prroi_pool.functional as _prf  # noqa: E402
+
+
+def _no_jit():
+    raise RuntimeError('PrRoIPool JIT build is disabled in the golden harness')
+
+
+_prf._import_prroi_pooling = _no_jit
+
+import lib.models.models as ref_models  # noqa: E402
+from usot_amd import synth  # noqa: E402
+from sampling import summarize  # noqa: E402
+
+assert ref_models.__file__.startswith(REF), ref_models.__file__
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def build(calibrated):
+    net = ref_models.USOT()
+    sd = synth.torch_state_dict(net, seed=0, calibrated=calibrated)
+    missing = net.load_state_dict(sd, strict=True)
+    return net, sd
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def do_calib():
+    """One train-mode pass with momentum 1 so running stats == batch stats of this input."""
+    net, _ = build(calibrated=False)
+    keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with open(os.path.join(GOLD, 'state_dict_keys.json'), 'w') as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    net.pr_pool = False
+    with torch.no_grad():
+        net.template(t(synth.crop(100, 8, 127)))
+        mem = t(synth.memory_kernels(102, 56))
+        net.track(t(synth.crop(101, 8, 255)), template_mem=mem, score_mem=torch.ones(8, 7))
+    out = {k: v.numpy() for k, v in net.state_dict().items()
+           if k.endswith('running_mean') or k.endswith('running_var')}
+    os.makedirs(synth.DATA_DIR, exist_ok=True)
+    np.savez_compressed(synth.CALIB_FILE, **out)
+    print('calibration: %d tensors -> %s' % (len(out), synth.CALIB_FILE))
+
+
+def do_model():
+    net, sd = build(calibrated=True)
+    net.eval()
+    net.pr_pool = False
+    g = {}
+    with torch.no_grad():
+        # a1-a3 backbone at the three crop sizes (+ batch 2 at 255)
+        for size, b, seed in ((127, 1, 0), (255, 1, 1), (271, 1, 3), (255, 2, 4)):
+            stages, p3 = net.feature_extractor(t(synth.crop(seed, b, size)))
+            tag = 'backbone_%d_b%d' % (size, b)
+            for nm, ten in zip(('stem', 'p1', 'p2'), stages):
+                g.update(summarize('%s/%s' % (tag, nm), ten.numpy()))
+            g.update(summarize(tag + '/p3', p3.numpy()))
+            g.update(summarize(tag + '/neck', net.neck(p3).numpy()))
+        # a10 template with the centre-crop neck (PrPool has no CPU reference)
+        net.template(t(synth.crop(0, 1, 127)))
+        zf = net.zf.clone()
+        g.update(summarize('template_crop/zf', zf.numpy()))
+        # a11 track: offline only, and with N_q = 7 memory, batch 1; 271 crop
+        x = t(synth.crop(1, 1, 255))
+        mem = t(synth.memory_kernels(7, 7))
+        cls, bbox, none1, none2 = net.track(x)
+        assert none1 is None and none2 is None
+        g.update(summarize('track_offline/cls', cls.numpy()))
+        g.update(summarize('track_offline/bbox', bbox.numpy()))
+        cls, bbox, cls_mem, xf = net.track(x, template_mem=mem, score_mem=torch.full((1, 7), 0.9))
+        for nm, ten in (('cls', cls), ('bbox', bbox), ('cls_mem', cls_mem), ('xf', xf)):
+            g.update(summarize('track_mem/' + nm, ten.numpy()))
+        x271 = t(synth.crop(3, 1, 271))
+        cls, bbox, cls_mem, xf = net.track(x271, template_mem=mem, score_mem=torch.full((1, 7), 0.9))
+        for nm, ten in (('cls', cls), ('bbox', bbox), ('cls_mem', cls_mem)):
+            g.update(summarize('track_mem_271/' + nm, ten.numpy()))
+        # batch 2 (two templates, 14 memory kernels)
+        net.template(t(synth.crop(5, 2, 127)))
+        mem2 = t(synth.memory_kernels(8, 14))
+        cls, bbox, cls_mem, xf = net.track(t(synth.crop(4, 2, 255)), template_mem=mem2,
+                                           score_mem=torch.full((2, 7), 0.9))
+        for nm, ten in (('cls', cls), ('bbox', bbox), ('cls_mem', cls_mem)):
+            g.update(summarize('track_mem_b2/' + nm, ten.numpy()))
+        # a5-a9 head pieces on seeded feature maps
+        cm = net.connect_model
+        xf = t(synth.memory_kernels(20, 1, 256, 31))
+        zk = t(synth.memory_kernels(21, 1))
+        mk = t(synth.memory_kernels(22, 7))
+        cz, cx = cm.cls_encode(zk, xf)
+        for i, nm in enumerate(('11', '12', '21')):
+            g.update(summarize('enc/cls_s' + nm, cx[i].numpy()))
+            g.update(summarize('enc/cls_k' + nm, cz[i].numpy()))
+        rz, rx = cm.reg_encode(zk, xf)
+        for i, nm in enumerate(('11', '12', '21')):
+            g.update(summarize('enc/reg_s' + nm, rx[i].numpy()))
+        g.update(summarize('groupdw/cls', cm.cls_dw(cz, cx).numpy()))
+        g.update(summarize('groupdw/reg', cm.reg_dw(rz, rx).numpy()))
+        mz, _ = cm.cls_encode(mk, None)
+        rep = [c.repeat(7, 1, 1, 1) for c in cx]
+        dwm = cm.cls_dw(mz, rep)
+        g.update(summarize('groupdw/mem', dwm.numpy()))
+        g.update(summarize('conf_fusion/out', cm.conf_fusion(dwm.view(1, 7, 256, 25, 25)).numpy()))
+        g.update(summarize('tower/bbox', cm.bbox_tower(dwm[:1]).numpy()))
+        # a6 xcorr_depthwise alone, the geometries on the path (+ the 271 one)
+        from lib.models.connect import xcorr_depthwise
+        for i, (hx, wx, hk, wk) in enumerate(((29, 29, 5, 5), (27, 29, 3, 5), (29, 27, 5, 3),
+                                              (31, 31, 5, 5), (12, 9, 4, 2))):
+            gx = np.random.default_rng(900 + i)
+            xa = gx.standard_normal((2, 24, hx, wx)).astype(np.float32)
+            ka = gx.standard_normal((2, 24, hk, wk)).astype(np.float32)
+            g['xcorr%d/x' % i], g['xcorr%d/k' % i] = xa, ka
+            g['xcorr%d/out' % i] = xcorr_depthwise(t(xa), t(ka)).numpy()
+    np.savez_compressed(os.path.join(GOLD, 'golden_model.npz'), **g)
+    print('model goldens: %d arrays, %.1f KB' % (
+        len(g), os.path.getsize(os.path.join(GOLD, 'golden_model.npz')) / 1024))
+
+
+def _import_ref_tracker(resize=None):
+    """Import lib.tracker.usot_tracker with import-only shims for cv2 / imgaug."""
+    cv2 = types.ModuleType('cv2')
+
+    def _resize(img, size, *a, **k):
+        if resize is None:
+            raise RuntimeError('cv2.resize reached in a golden that must not need it')
+        return resize(img, size)
+    cv2.resize = _resize
+    sys.modules['cv2'] = cv2
+
+    ia = types.ModuleType('imgaug')
+    iaa = types.ModuleType('imgaug.augmenters')
+    bbs = types.ModuleType('imgaug.augmentables.bbs')
+    aug = types.ModuleType('imgaug.augmentables')
+
+    class BoundingBox:
+        def __init__(self, x1, y1, x2, y2):
+            self.x1, self.y1, self.x2, self.y2 = x1, y1, x2, y2
+
+    class BoundingBoxesOnImage:
+        def __init__(self, boxes, shape):
+            self.bounding_boxes, self.shape = boxes, shape
+
+        def __getitem__(self, i):
+            return self.bounding_boxes[i]
+
+    class Fliplr:
+        def __init__(self, p):
+            assert p == 1
+
+    class Sequential:
+        def __init__(self, children):
+            assert len(children) == 1 and isinstance(children[0], Fliplr)
+
+        def __call__(self, image, bounding_boxes):
+            w = image.shape[1]
+            out = [BoundingBox(w - b.x2, b.y1, w - b.x1, b.y2) for b in bounding_boxes.bounding_boxes]
+            return image[:, ::-1], BoundingBoxesOnImage(out, image.shape)
+    iaa.Fliplr, iaa.Sequential = Fliplr, Sequential
+    bbs.BoundingBox, bbs.BoundingBoxesOnImage = BoundingBox, BoundingBoxesOnImage
+    ia.augmenters, ia.augmentables = iaa, aug
+    aug.bbs = bbs
+    for n, m in (('imgaug', ia), ('imgaug.augmenters', iaa), ('imgaug.augmentables', aug),
+                 ('imgaug.augmentables.bbs', bbs)):
+        sys.modules[n] = m
+    import lib.tracker.usot_tracker as rt
+    return rt
+
+
+class _Info:
+    arch = 'USOT'
+    dataset = 'SYNTH'
+    epoch_test = False
+    version = 'v1'
+
+
+def do_host():
+    """a14-a16: grids, box->feature-coordinate maps, decode, memory selection."""
+    rt = _import_ref_tracker()
+    g = {}
+    trk = rt.USOTTracker(_Info())
+    idx_cases = {}
+    for inst in (255, 271):
+        p = rt.USOTConfig()
+        p.instance_size = inst
+        p.renew()
+        p.sf_size = p.score_size
+        trk.grids(p)
+        tag = 'i%d' % inst
+        g[tag + '/grid_x'], g[tag + '/grid_y'] = trk.grid_to_search_x, trk.grid_to_search_y
+        g[tag + '/search_axis'] = trk.search_area_x_axis
+        boxes = np.array([[30.2, 41.7, 96.1, 88.8], [-5, -9, 300, 280], [0, 0, 126, 126],
+                          [100.5, 90.25, 160.75, 170.0]], np.float32)
+        g[tag + '/boxes'] = boxes
+        g[tag + '/pool_template'] = np.stack([trk.pool_label_template(p, b) for b in boxes])
+        g[tag + '/pool_search'] = np.stack([trk.pool_label_search(p, b) for b in boxes])
+        # decode with canned network outputs
+        S = p.score_size
+        window = np.outer(np.hanning(S), np.hanning(S))
+        for case in range(4):
+            r = np.random.default_rng(4000 + 10 * inst + case)
+            cls = (2.5 * r.standard_normal((1, 1, S, S))).astype(np.float32)
+            cmem = (2.5 * r.standard_normal((1, 1, S, S))).astype(np.float32)
+            bbox = np.exp(r.uniform(2.0, 4.5, (1, 4, S, S))).astype(np.float32)
+            xf = r.standard_normal((1, 4, 31, 31)).astype(np.float32)
+            tpos = np.array([200.0 + 3 * case, 150.0 - 2 * case])
+            tsz = np.array([60.0 + 7 * case, 45.0 + 3 * case])
+            scale_z = 127.0 / np.sqrt((tsz[0] + 0.5 * tsz.sum()) * (tsz[1] + 0.5 * tsz.sum()))
+            seen = {}
+
+            class StubNet:
+                def track(self, x, template_mem=None, score_mem=None):
+                    return t(cls), t(bbox), t(cmem), t(xf)
+
+                def extract_memory_feature(self, xf=None, search_bbox=None, ori_x=None):
+                    seen['box'] = search_bbox.numpy().copy()
+                    return torch.zeros(1, 4, 7, 7)
+            pos, sz, score, _ = trk.update(StubNet(), None, tpos.copy(), tsz * scale_z, window,
+                                           scale_z, p)
+            c = '%s/decode%d' % (tag, case)
+            g[c + '/cls'], g[c + '/cls_mem'], g[c + '/bbox'] = cls, cmem, bbox
+            g[c + '/tpos'], g[c + '/tsz'], g[c + '/scale_z'] = tpos, tsz, np.array(scale_z)
+            g[c + '/out_pos'], g[c + '/out_sz'] = np.asarray(pos), np.asarray(sz)
+            g[c + '/out_score'], g[c + '/out_poolbox'] = np.array(score), seen['box']
+    # memory selection: tag feature i with the value i, read the tags the net receives
+    p = rt.USOTConfig()
+    p.sf_size = p.score_size
+    trk.grids(p)
+    for n in (1, 2, 3, 5, 8, 20, 57, 200):
+        r = np.random.default_rng(7000 + n)
+        conf = [0.9] + list(r.uniform(0.1, 1.0, n - 1))
+        feats = [torch.full((1, 2, 7, 7), float(i)) for i in range(n)]
+        got = {}
+
+        class TagNet:
+            def track(self, x, template_mem=None, score_mem=None):
+                got['tags'] = template_mem[:, 0, 0, 0].numpy().copy()
+                got['score'] = score_mem.numpy().copy()
+                S = p.score_size
+                return (torch.zeros(1, 1, S, S), torch.full((1, 4, S, S), 20.0),
+                        torch.zeros(1, 1, S, S), torch.zeros(1, 2, 31, 31))
+
+            def extract_memory_feature(self, xf=None, search_bbox=None, ori_x=None):
+                return torch.zeros(1, 2, 7, 7)
+        S = p.score_size
+        state = dict(p=p, net=TagNet(), avg_chans=np.zeros(3), window=np.outer(np.hanning(S), np.hanning(S)),
+                     target_pos=np.array([320.0, 240.0]), target_sz=np.array([63.5, 63.5]),
+                     init_features=[torch.full((1, 2, 7, 7), -1.0), torch.full((1, 2, 7, 7), -2.0)],
+                     memory_features=list(feats), memory_confidences=list(conf), im_h=480, im_w=640)
+        trk.track(state, np.zeros((480, 640, 3), np.uint8))
+        idx_cases[str(n)] = {'conf': [float(c) for c in conf],
+                             'tags': [float(v) for v in got['tags']],
+                             'score': [float(v) for v in got['score'].reshape(-1)]}
+    np.savez_compressed(os.path.join(GOLD, 'golden_host.npz'), **g)
+    with open(os.path.join(GOLD, 'golden_memory_indices.json'), 'w') as f:
+        json.dump(idx_cases, f)
+    print('host goldens: %d arrays' % len(g))
+
+
+def do_e2e():
+    """Whole tracker (reference USOTTracker + reference USOT on CPU) over a synthetic video.
+    Third-party pieces the container lacks are substituted and declared unpinned:
+    cv2.resize -> usot_amd.hostutils.resize_bilinear_u8, imgaug Fliplr -> array flip,
+    PrRoIPool (GPU-only in the reference) -> oracle/prroi_pool_ref.c."""
+    from usot_amd import hostutils
+    sys.path.insert(3, os.path.join(REPO, 'oracle'))
+    import usot_oracle as orc
+    rt = _import_ref_tracker(resize=lambda img, size: hostutils.resize_bilinear_u8(img, size[0], size[1]))
+
+    def prroi(features, rois, ph, pw, scale):
+        return orc.prroi_pool(features, rois, ph, pw, scale)
+    ref_models.prroi_pool2d = prroi
+    import lib.models.connect as rc
+    rc.PrRoIPool2D.forward = lambda self, f, r: prroi(f, r, self.pooled_height, self.pooled_width,
+                                                      self.spatial_scale)
+    net, _ = build(calibrated=True)
+    net.eval()
+    out = {}
+    for vid, (seed, nframes, sz) in enumerate(((11, 6, (52.0, 38.0)), (12, 4, (16.0, 12.0)))):
+        trk = rt.USOTTracker(_Info())
+        with torch.no_grad():
+            im, (cx, cy) = synth.frame(seed, t=0)
+            state = trk.init(im, np.array([cx, cy]), np.array(sz), net)
+            rows = [[cx, cy, sz[0], sz[1], 0.0]]
+            for f in range(1, nframes):
+                im, _ = synth.frame(seed, t=f)
+                state = trk.track(state, im)
+                rows.append([*state['target_pos'], *state['target_sz'], float(state['cls_score'])])
+        out['video%d/seed_frames_sz' % vid] = np.array([seed, nframes, *sz])
+        out['video%d/track' % vid] = np.array(rows, np.float64)
+        out['video%d/instance_size' % vid] = np.array(state['p'].instance_size)
+        print('video', vid, 'instance', state['p'].instance_size, '\n', np.array(rows))
+    np.savez_compressed(os.path.join(GOLD, 'golden_e2e.npz'), **out)
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['calib', 'model', 'host']
+    for w in what:
+        {'calib': do_calib, 'model': do_model, 'host': do_host, 'e2e': do_e2e}[w]()

@@ -1,0 +1,122 @@
+"""Synthetic, reproducible weights and inputs for the tracking forward pass.
+
+No checkpoint ships with the reference (README.md:88-95 points at Google Drive) and
+default init with raw 0..255 pixels overflows `exp` in the box head, so
+tests and benchmarks use:
+
+* conv weights / biases / BN affine drawn from a counter-based generator keyed by the
+  state-dict name (identical on every machine with the same numpy), and
+* BN running statistics measured once on the reference model (train mode, momentum 1)
+  by `tests/golden/make_golden.py`, committed as `usot_amd/data/calib_bn_seed0.npz`,
+  so that every layer's activations are O(1).
+
+Inputs follow the reference's convention: BGR planes, float32, 0..255, no mean/std
+(lib/utils/track_utils.py:24-27).
+"""
+import os
+import zlib
+
+import numpy as np
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
+CALIB_FILE = os.path.join(DATA_DIR, 'calib_bn_seed0.npz')
+
+
+def _rng(seed, name):
+    return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
+
+
+def make_param(name, shape, seed=0):
+    """One state-dict entry (numpy) for `name` with `shape`."""
+    shape = tuple(int(s) for s in shape)
+    g = _rng(seed, name)
+    leaf = name.rsplit('.', 1)[-1]
+    if leaf == 'num_batches_tracked':
+        return np.array(1, dtype=np.int64)
+    if leaf == 'running_mean':
+        return np.zeros(shape, np.float32)
+    if leaf == 'running_var':
+        return np.ones(shape, np.float32)
+    if name.endswith('connect_model.adjust'):
+        return np.full(shape, 0.1, np.float32)
+    if name.endswith('connect_model.bias'):              # exp(.) of ~3.4 -> boxes of ~30 px
+        return (3.4 + 0.25 * g.standard_normal(shape)).astype(np.float32)
+    if name.endswith('bbox_pred.weight'):                # x adjust(0.1): log-box spread ~0.5
+        return (g.standard_normal(shape) * 5.0 * np.sqrt(2.0 / (shape[1] * 9))).astype(np.float32)
+    if name.endswith('cls_pred.weight') or name.endswith('cls_memory_pred.weight'):
+        return (g.standard_normal(shape) * 20.0 * np.sqrt(2.0 / (shape[1] * 9))).astype(np.float32)
+    if name.endswith('_dw.weight'):                      # GroupDW branch logits
+        return (0.5 * g.standard_normal(shape)).astype(np.float32)
+    if len(shape) == 4:                                  # conv weight OIHW
+        fan_in = shape[1] * shape[2] * shape[3]
+        return (g.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+    if leaf == 'weight':                                 # BN gamma
+        return g.uniform(0.6, 1.4, shape).astype(np.float32)
+    if leaf == 'bias':                                   # BN beta or conv bias
+        return (0.1 * g.standard_normal(shape)).astype(np.float32)
+    raise KeyError('no synthetic rule for %s %s' % (name, shape))
+
+
+def make_state_dict(shapes, seed=0, calibrated=True):
+    """`shapes`: {name: shape}.  Returns {name: np.ndarray}."""
+    sd = {k: make_param(k, s, seed) for k, s in shapes.items()}
+    if calibrated:
+        if seed != 0:
+            raise ValueError('BN calibration is only recorded for seed 0')
+        with np.load(CALIB_FILE) as z:
+            for k in z.files:
+                if k in sd:
+                    assert sd[k].shape == z[k].shape, k
+                    sd[k] = z[k].astype(np.float32)
+    return sd
+
+
+def torch_state_dict(model, seed=0, calibrated=True):
+    """State dict (torch CPU tensors) for any module exposing the reference's keys."""
+    import torch
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = make_state_dict(shapes, seed, calibrated)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+def crop(seed, batch, size):
+    """Synthetic crop batch [B,3,size,size] float32 in [0,255): smooth blobs + noise.
+
+    Pure white noise would make every crop statistically identical; a few random
+    Gaussian blobs per image give the response maps structure (a real argmax).
+    """
+    g = np.random.default_rng([int(seed), size, batch, 0xC0FFEE])
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    out = np.empty((batch, 3, size, size), np.float32)
+    for b in range(batch):
+        img = g.uniform(90, 110, (3, 1, 1)).astype(np.float32) * np.ones((3, size, size), np.float32)
+        for _ in range(10):
+            cx, cy = g.uniform(0, size, 2)
+            s = g.uniform(size / 16, size / 4)
+            amp = g.uniform(-70, 70, (3, 1, 1)).astype(np.float32)
+            img += amp * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))[None]
+        img += g.uniform(-12, 12, img.shape).astype(np.float32)
+        out[b] = np.clip(img, 0, 254.99)
+    return out
+
+
+def memory_kernels(seed, n, c=256, hw=7, scale=1.0):
+    """Stand-in for PrPool-ed memory features [n,c,hw,hw]; `scale` ~ the std of the neck
+    output under the calibrated weights (see tests/golden/golden_model.npz stats)."""
+    g = np.random.default_rng([int(seed), n, c, hw, 0xBEEF])
+    return (scale * g.standard_normal((n, c, hw, hw))).astype(np.float32)
+
+
+def frame(seed, h=360, w=480, t=0):
+    """Synthetic uint8 BGR video frame with a textured moving target."""
+    g = np.random.default_rng([int(seed), h, w, 0xF00D])
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    bg = (90 + 40 * np.sin(xx / 37.0 + 0.3 * np.arange(3)[:, None, None])
+          + 30 * np.cos(yy / 23.0 + 0.7 * np.arange(3)[:, None, None])).astype(np.float32)
+    cx = w * 0.5 + 60 * np.sin(0.11 * t)
+    cy = h * 0.5 + 40 * np.cos(0.07 * t)
+    amp = g.uniform(60, 120, (3, 1, 1)).astype(np.float32)
+    blob = amp * np.exp(-(((xx - cx) / 28.0) ** 2 + ((yy - cy) / 20.0) ** 2))
+    tex = 15 * np.sin((xx - cx) / 3.0) * np.cos((yy - cy) / 4.0) * (blob.sum(0) > 30)
+    img = bg + blob + tex[None]
+    return np.clip(img, 0, 255).transpose(1, 2, 0).astype(np.uint8), (cx, cy)
