@@ -1,0 +1,188 @@
+/* usot_hip.h — C ABI of libusot_hip.so: hand-written gfx950 (MI355X) kernels for the
+ * USOT Siamese-tracking forward pass.
+ *
+ * Conventions (mirroring the reference's only native ABI,
+ * lib/models/prroi_pool/src/prroi_pooling_gpu_impl.cuh:20-28):
+ *   - the caller owns every buffer; kernels borrow raw DEVICE pointers for the duration
+ *     of the enqueue; nothing is allocated or retained by the library (plans excepted);
+ *   - every call enqueues asynchronously on the given hipStream_t (passed as void*);
+ *   - every entry point returns 0 on success or a negative USOT_E* code — never exit()
+ *     (the reference's launcher calls exit(-1), prroi_pooling_gpu_impl.cu:20-27);
+ *   - all tensors are float32 unless a name says otherwise; "NHWC" = channels innermost.
+ *
+ * Each entry point cites the reference code it replaces.
+ */
+#ifndef USOT_HIP_H
+#define USOT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define USOT_OK            0
+#define USOT_EINVAL       -1   /* bad shape / unsupported geometry */
+#define USOT_ELAUNCH      -2   /* hipGetLastError() after launch   */
+#define USOT_ENOMEM       -3
+#define USOT_ESTATE       -4   /* plan used in the wrong state     */
+
+/* activation codes of the conv epilogue */
+#define USOT_ACT_NONE      0
+#define USOT_ACT_RELU      1
+#define USOT_ACT_EXP       2   /* exp(x)                  connect.py:236-237 (bbox head)      */
+#define USOT_ACT_CONF      3   /* exp(min(max(x,0),4))    connect.py:128-131 (ReLU then clamp) */
+
+int usot_abi_version(void);
+const char *usot_strerror(int code);
+
+/* ---- convolution as implicit GEMM on fp32 MFMA (v_mfma_f32_16x16x4_f32) -------------
+ * y = act(conv(x, w) + bias [+ res]).  BatchNorm is folded into w/bias by the host.
+ * Replaces every nn.Conv2d + nn.BatchNorm2d (+ReLU, +residual add) launch of
+ * lib/models/modules.py:37-56,138-146 and lib/models/connect.py:19-53,110-119,178-215.
+ *   x    NHWC  [N][H][W][Cin], Cin % 32 == 0
+ *   w    packed [Cout][KH*KW*Cin], k = (kh*KW + kw)*Cin + ci
+ *   y    NHWC  [N][OH][OW] with pixel stride y_cstride and channel offset y_coff, or
+ *        NCHW  [N][Cout][OH][OW] when y_nchw != 0
+ *   res  optional, laid out like an NHWC y with (res_cstride, res_coff)
+ *   groups > 1 runs `groups` independent problems of identical geometry in one launch
+ *   (pointer strides *_gs in elements): the three head towers, connect.py:178-207.
+ *   act applies to channels [0, act_split) and act2 to [act_split, Cout) (act_split >= Cout
+ *   means act everywhere): lets conf_gen|value_gen run as one Cout=512 conv.
+ *   ksplit > 1 splits the K loop over `ksplit` workgroups; partials go to `ws`
+ *   ([ksplit][groups][M][Cout] floats) and a second launch applies the epilogue.
+ *   tile: 0 = heuristic, else one of USOT_TILE_* ids (see usot_conv_tile_count).
+ */
+typedef struct usot_conv_desc {
+    const float *x, *w, *bias, *res;
+    float *y;
+    float *ws;
+    int32_t N, H, W, Cin, OH, OW, Cout;
+    int32_t KH, KW, stride, pad_h, pad_w, dil_h, dil_w;
+    int32_t y_cstride, y_coff, res_cstride, res_coff, y_nchw;
+    int32_t act, act2, act_split;
+    int32_t groups;
+    int64_t x_gs, w_gs, b_gs, y_gs, r_gs;
+    int32_t ksplit, tile;
+} usot_conv_desc;
+
+int usot_conv2d_f32(void *stream, const usot_conv_desc *d);
+int usot_conv_tile_count(void);
+int usot_conv_tile_info(int tile, int *bm, int *bn);           /* tile ids are 1..count */
+int64_t usot_conv_ws_floats(const usot_conv_desc *d);          /* workspace need for ksplit */
+
+/* ---- stem: 7x7 / stride 2 / pad 0 conv, 3 -> 64 channels, + folded BN + ReLU ---------
+ * modules.py:70-72,138-140.  x NCHW [N][3][H][W] (the API-edge crop, BGR 0..255),
+ * w packed [147][64] with row = (ci*7 + kh)*7 + kw, y NHWC [N][OH][OW][64].            */
+int usot_stem_conv_f32(void *stream, const float *x, const float *w, const float *bias,
+                       float *y, int N, int H, int W, int OH, int OW);
+
+/* ---- max-pool 3x3 / stride 2 / pad 1 on NHWC (modules.py:74,141) ------------------- */
+int usot_maxpool3x3s2_f32(void *stream, const float *x, float *y,
+                          int N, int H, int W, int C, int OH, int OW);
+
+/* ---- depthwise cross-correlation, NCHW planes (drop-in for xcorr_depthwise,
+ * lib/models/connect.py:147-157): out[p][i][j] = sum_uv x[p][i+u][j+v] * k[p][u][v]
+ * for P = B*C planes; one wavefront per plane pair, template tile in LDS, window taps
+ * exchanged between lanes with DPP/shuffles.  Wx <= 64.                                */
+int usot_xcorr_depthwise_f32(void *stream, const float *x, const float *k, float *out,
+                             int P, int Hx, int Wx, int Hk, int Wk);
+
+/* ---- fused GroupDW on NHWC (connect.py:86-102): three depthwise xcorrs and the
+ * softmax(weight)-weighted sum in one pass, no intermediate maps.
+ *   branch b: x_b NHWC [XS][OH+hk_b-1][OW+wk_b-1] (pixel stride x_cs, channel offset x_co)
+ *             z_b NHWC [S][hk_b][wk_b]            (pixel stride z_cs, channel offset z_co)
+ *   sample s uses search map s / x_rep (x_rep = N_q for the memory branch, where the
+ *   reference materialises a 7x repeat, connect.py:258-264) and template s.
+ *   out NHWC [S][OH][OW][C];  wsm = softmax(weight) (3 floats, host pointer).          */
+typedef struct usot_groupdw_desc {
+    const float *x[3];
+    const float *z[3];
+    float *out;
+    int32_t hk[3], wk[3];
+    int32_t x_cs[3], x_co[3], z_cs[3], z_co[3];
+    float wsm[3];
+    int32_t S, x_rep, OH, OW, C;
+    int32_t cols_per_thread;     /* 0 = heuristic, 1 or 5 */
+} usot_groupdw_desc;
+int usot_groupdw_f32(void *stream, const usot_groupdw_desc *d);
+
+/* ---- Conf_Fusion reduction (connect.py:132-142): cv NHWC [B*M][P][2C] holding
+ * conf = exp(clamp) in channels [0,C) and value in [C,2C) -> out [B][P][C] =
+ * sum_m conf*value / sum_m conf.                                                       */
+int usot_conf_fusion_reduce_f32(void *stream, const float *cv, float *out,
+                                int B, int M, int P, int C);
+
+/* ---- Precise RoI Pooling forward.  Replaces PrRoIPoolingForwardGpu
+ * (prroi_pooling_gpu_impl.cuh:20-28 / .cu:149-212,387-402) with explicit strides so the
+ * same kernel reads NCHW (API edge) or NHWC (engine) features and writes either layout.
+ *   feat element (b,c,h,w) at b*f_sb + c*f_sc + h*f_sh + w*f_sw
+ *   rois [R][5] = (batch, x1, y1, x2, y2);  out element (r,c,ph,pw) at
+ *   r*o_sr + c*o_sc + ph*o_sh + pw*o_sw                                                */
+int usot_prroi_pool_forward_f32(void *stream, const float *feat, const float *rois, float *out,
+                                int R, int C, int H, int W, int PH, int PW, float scale,
+                                int64_t f_sb, int64_t f_sc, int64_t f_sh, int64_t f_sw,
+                                int64_t o_sr, int64_t o_sc, int64_t o_sh, int64_t o_sw);
+
+/* ---- layout changes at the API edge: generic 4-D strided copy ----------------------
+ * dst[n][a][b][c] (dense) = src[n*s0 + a*s1 + b*s2 + c*s3]                              */
+int usot_permute4_f32(void *stream, const float *src, float *dst,
+                      int D0, int D1, int D2, int D3,
+                      int64_t s0, int64_t s1, int64_t s2, int64_t s3);
+
+/* ---- on-device decode of one frame (usot_tracker.py:138-163): float32 sigmoid and
+ * offline/online blend, then (in float64, as numpy promotes there because the grids are
+ * float64) box decode, size/ratio penalty, cosine window and first-max argmax.
+ * cls/cls_mem [S*S] logits, bbox [4][S*S], window [S*S] float64;
+ * out[8] = {best_index, blended_score, penalty, x1, y1, x2, y2, pscore} (float64).
+ * tw/th = target size already multiplied by scale_z (usot_tracker.py:258).              */
+int usot_decode_f32(void *stream, const float *cls, const float *cls_mem, const float *bbox,
+                    const double *window, double *out, int S, int instance_size, int stride,
+                    float ratio, double penalty_k, double window_influence,
+                    double tw, double th);
+
+/* same, with the target size read from device memory (double[2]) and, if roi_out != NULL,
+ * the PrRoIPool box of the winning cell (usot_tracker.py:196, 329-350) written to
+ * roi_out[5] = (0, x1, y1, x2, y2) in feature coordinates: no host round trip between
+ * decode and memory-feature pooling.                                                    */
+int usot_decode_dev_f32(void *stream, const float *cls, const float *cls_mem, const float *bbox,
+                        const double *window, double *out, int S, int instance_size, int stride,
+                        float ratio, double penalty_k, double window_influence,
+                        const double *tsz_dev, float *roi_out);
+
+/* ---- launch plans: record the per-frame kernel sequence once, replay it natively, or
+ * capture it into a hipGraph (one hipGraphLaunch per frame).  Pointers are baked at add
+ * time, so they must refer to buffers that outlive the plan (the engine's workspace).
+ * fork(lane>0): that lane waits for lane 0, following ops go to `lane`; fork(0): back to
+ * lane 0 without waiting; join(lane): lane 0 waits for `lane`.  Lanes are extra streams
+ * (parallel graph branches after capture); run() on an uncaptured plan ignores lanes and
+ * issues everything in program order on the caller's stream.                             */
+void *usot_plan_create(void);
+void usot_plan_destroy(void *plan);
+int usot_plan_size(void *plan);
+int usot_plan_add_conv(void *plan, const usot_conv_desc *d);
+int usot_plan_add_groupdw(void *plan, const usot_groupdw_desc *d);
+int usot_plan_add_stem(void *plan, const float *x, const float *w, const float *bias, float *y,
+                       int N, int H, int W, int OH, int OW);
+int usot_plan_add_maxpool(void *plan, const float *x, float *y, int N, int H, int W, int C,
+                          int OH, int OW);
+int usot_plan_add_conf_reduce(void *plan, const float *cv, float *out, int B, int M, int P, int C);
+int usot_plan_add_prroi(void *plan, const float *feat, const float *rois, float *out,
+                        int R, int C, int H, int W, int PH, int PW, float scale,
+                        int64_t f_sb, int64_t f_sc, int64_t f_sh, int64_t f_sw,
+                        int64_t o_sr, int64_t o_sc, int64_t o_sh, int64_t o_sw);
+int usot_plan_add_permute(void *plan, const float *src, float *dst, int D0, int D1, int D2, int D3,
+                          int64_t s0, int64_t s1, int64_t s2, int64_t s3);
+int usot_plan_add_decode(void *plan, const float *cls, const float *cls_mem, const float *bbox,
+                         const double *window, double *out, int S, int instance_size, int stride,
+                         float ratio, double penalty_k, double window_influence,
+                         const double *tsz_dev, float *roi_out);
+int usot_plan_fork(void *plan, int lane);
+int usot_plan_join(void *plan, int lane);
+int usot_plan_capture(void *plan, void *stream);
+int usot_plan_run(void *plan, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USOT_HIP_H */

@@ -1,0 +1,219 @@
+"""GPU parity of each C-ABI entry point against the CPU oracle (torch-CPU functional ops,
+oracle/prroi_pool_ref.c) on seeded inputs.  Tolerances are scaled-relative:
+|got-ref| / max(|ref|, mean|ref|) — fp32 MFMA is an exact fmaf chain, so the only
+difference to the oracle is summation order (K up to 4608)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import usot_oracle as orc  # noqa: E402
+from usot_amd import hip  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def rel_err(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    scale = np.maximum(np.abs(ref), np.abs(ref).mean() + 1e-30)
+    return float(np.max(np.abs(got - ref) / scale))
+
+
+def pack_w(w):          # OIHW -> [O][kh][kw][I]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, dil
+    (1, 64, 17, 19, 64, 1, 1, (0, 0), (1, 1)),
+    (1, 64, 17, 19, 96, 3, 1, (1, 1), (1, 1)),
+    (2, 128, 15, 15, 128, 3, 2, (0, 0), (1, 1)),      # layer2.0 geometry
+    (1, 256, 13, 13, 256, 3, 1, (2, 2), (2, 2)),      # layer3.x geometry
+    (1, 256, 11, 12, 256, 3, 1, (0, 0), (2, 1)),      # encoder (2,1)
+    (1, 256, 12, 11, 256, 3, 1, (0, 0), (1, 2)),      # encoder (1,2)
+    (1, 512, 9, 9, 1024, 3, 1, (1, 1), (1, 1)),       # layer3.0 shortcut geometry
+    (3, 256, 7, 7, 512, 3, 1, (0, 0), (1, 1)),        # template-side encoders
+    (1, 256, 25, 25, 4, 3, 1, (1, 1), (1, 1)),        # bbox_pred (Cout 4)
+    (1, 256, 25, 25, 1, 3, 1, (1, 1), (1, 1)),        # cls_pred  (Cout 1)
+    (1, 1024, 31, 31, 256, 1, 1, (0, 0), (1, 1)),     # neck, full size
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('tile', [0, 4, 7, 8])
+def test_conv_igemm(case, tile):
+    N, Cin, H, W, Cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, stride, pad, dil)
+    res = torch.randn_like(ref)
+    ref_r = F.relu(ref + res)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd, bd = pack_w(w).to(DEV), b.to(DEV)
+    y = hip.conv2d(xd, wd, bd, KH=k, KW=k, stride=stride, pad=pad, dil=dil, tile=tile)
+    assert rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 2e-5
+    rd = res.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = hip.conv2d(xd, wd, bd, KH=k, KW=k, stride=stride, pad=pad, dil=dil, res=rd, act=hip.ACT_RELU, tile=tile)
+    assert rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), ref_r.numpy()) < 2e-5
+    y = hip.conv2d(xd, wd, bd, KH=k, KW=k, stride=stride, pad=pad, dil=dil, tile=tile, y_nchw=True)
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('ksplit', [2, 3, 9])
+def test_conv_splitk(ksplit):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 256, 25, 25, generator=g)
+    w = torch.randn(256, 256, 3, 3, generator=g) / 48
+    b = torch.randn(256, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, 1, 1))
+    y = hip.conv2d(x.permute(0, 2, 3, 1).contiguous().to(DEV), pack_w(w).to(DEV), b.to(DEV), KH=3, KW=3,
+                   pad=(1, 1), act=hip.ACT_RELU, ksplit=ksplit, tile=4)
+    assert rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 2e-5
+
+
+def test_conv_activations():
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 64, 9, 9, generator=g)
+    w = torch.randn(32, 64, 3, 3, generator=g) / 8
+    b = torch.randn(32, generator=g)
+    ref = F.conv2d(x, w, b, 1, 1)
+    xd, wd, bd = x.permute(0, 2, 3, 1).contiguous().to(DEV), pack_w(w).to(DEV), b.to(DEV)
+    y = hip.conv2d(xd, wd, bd, KH=3, KW=3, pad=(1, 1), act=hip.ACT_EXP)
+    assert rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), torch.exp(ref).numpy()) < 2e-5
+    y = hip.conv2d(xd, wd, bd, KH=3, KW=3, pad=(1, 1), act=hip.ACT_CONF)
+    want = torch.exp(torch.clamp(F.relu(4 * ref) / 4 * 4, min=-6, max=4)) if False else torch.exp(torch.clamp(F.relu(ref), min=-6, max=4))
+    assert rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), want.numpy()) < 2e-5
+
+
+def test_conv_rejects_bad_geometry():
+    x = torch.zeros(1, 5, 5, 48, device=DEV)                 # Cin not a multiple of 32
+    w = torch.zeros(16, 48 * 9, device=DEV)
+    with pytest.raises(hip.HipError):
+        hip.conv2d(x, w, None, KH=3, KW=3)
+    with pytest.raises(hip.HipError):
+        hip.conv2d(torch.zeros(1, 5, 5, 64), torch.zeros(16, 64), None, KH=1, KW=1)   # CPU tensors
+
+
+@pytest.mark.parametrize('size,n', [(127, 1), (255, 2), (271, 1), (64, 1)])
+def test_stem_and_maxpool(size, n):
+    g = torch.Generator().manual_seed(size)
+    x = torch.rand(n, 3, size, size, generator=g) * 255
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12
+    b = torch.randn(64, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, 2, 0))
+    wd = w.permute(1, 2, 3, 0).reshape(147, 64).contiguous().to(DEV)
+    y = hip.stem_conv(x.to(DEV), wd, b.to(DEV))
+    assert rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 1e-5
+    p = hip.maxpool3x3s2(y)
+    want = F.max_pool2d(y.permute(0, 3, 1, 2).cpu(), 3, 2, 1)
+    assert torch.equal(p.permute(0, 3, 1, 2).cpu(), want)         # max-pool is exact
+
+
+XC = [(29, 29, 5, 5), (27, 29, 3, 5), (29, 27, 5, 3), (31, 31, 5, 5), (33, 31, 5, 3), (12, 9, 4, 2),
+      (64, 64, 5, 5), (70, 70, 5, 5), (7, 7, 7, 7)]
+
+
+@pytest.mark.parametrize('hx,wx,hk,wk', XC)
+@pytest.mark.parametrize('planes', [(1, 1), (2, 24), (3, 257)])
+def test_xcorr_depthwise_planes(hx, wx, hk, wk, planes):
+    b, c = planes
+    g = torch.Generator().manual_seed(hx * 100 + wk)
+    x, k = torch.randn(b, c, hx, wx, generator=g), torch.randn(b, c, hk, wk, generator=g)
+    ref = orc.xcorr_depthwise(x, k)
+    out = hip.xcorr_depthwise(x.to(DEV), k.to(DEV))
+    assert out.shape == ref.shape
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_xcorr_golden(gold_model):
+    """the reference's own xcorr_depthwise outputs (tests/golden/make_golden.py)."""
+    for i in range(5):
+        out = hip.xcorr_depthwise(torch.from_numpy(gold_model['xcorr%d/x' % i]).to(DEV),
+                                  torch.from_numpy(gold_model['xcorr%d/k' % i]).to(DEV))
+        assert rel_err(out.cpu().numpy(), gold_model['xcorr%d/out' % i]) < 1e-5
+
+
+@pytest.mark.parametrize('S,x_rep,OW,cols', [(1, 1, 25, 1), (7, 7, 25, 1), (14, 7, 25, 5), (3, 1, 27, 1),
+                                             (2, 1, 25, 5), (4, 2, 27, 5)])
+def test_groupdw_fused(S, x_rep, OW, cols):
+    g = torch.Generator().manual_seed(S * 31 + OW)
+    XS = S // x_rep
+    geo = ((5, 5), (3, 5), (5, 3))
+    xs = [torch.randn(XS, 256, OW + hk - 1, OW + wk - 1, generator=g) for hk, wk in geo]
+    zs = [torch.randn(S, 256, hk, wk, generator=g) for hk, wk in geo]
+    wlog = torch.randn(3, generator=g)
+    wsm = torch.softmax(wlog, 0)
+    ref = 0
+    for i in range(3):
+        ref = ref + wsm[i] * orc.xcorr_depthwise(xs[i].repeat_interleave(x_rep, 0), zs[i])
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = hip.groupdw([nh(t) for t in xs], [nh(t) for t in zs], wsm.numpy(), x_rep=x_rep, cols=cols)
+    assert rel_err(out.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('B,M', [(1, 7), (2, 7), (1, 1), (3, 4)])
+def test_conf_fusion_reduce(B, M):
+    g = torch.Generator().manual_seed(B * 10 + M)
+    conf = torch.exp(torch.clamp(torch.randn(B, M, 256, 5, 6, generator=g) * 3, 0, 4))
+    val = F.relu(torch.randn(B, M, 256, 5, 6, generator=g))
+    ref = ((conf / conf.sum(1, keepdim=True)) * val).sum(1)
+    cv = torch.cat([conf, val], 2).reshape(B * M, 512, 5, 6).permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = hip.conf_fusion_reduce(cv, B, M)
+    assert rel_err(out.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 1e-5
+
+
+ROIS = [[0, 2.3, 3.1, 9.7, 11.2], [1, -3.0, -2.0, 5.0, 6.0], [0, 10.0, 10.0, 40.0, 40.0], [1, 4.0, 4.0, 4.0, 9.0],
+        [0, 0.0, 0.0, 14.0, 14.0], [1, 6.5, 6.5, 7.0, 7.0], [0, 50.0, 50.0, 60.0, 60.0]]
+
+
+@pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
+def test_prroi_pool_vs_c_oracle(layout):
+    g = torch.Generator().manual_seed(77)
+    f = torch.randn(2, 256, 15, 17, generator=g)
+    rois = torch.tensor(ROIS, dtype=torch.float32)
+    ref = orc.prroi_pool(f, rois, 7, 7, 1.0)
+    fd = f.to(DEV)
+    if layout == 'nhwc':
+        fd = fd.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    out = hip.prroi_pool(fd, rois.to(DEV), 7, 7, 1.0, out_nhwc=(layout == 'nhwc'))
+    assert out.shape == ref.shape
+    got = out.cpu().numpy()
+    # same float32 operation order as the restated .cu: agree to a few ulp
+    assert np.max(np.abs(got - ref.numpy())) < 2e-6 * max(1.0, float(ref.abs().max()))
+    assert np.all(got[3] == 0) and np.all(got[6] == 0)        # zero-width roi, fully outside roi
+    empty = hip.prroi_pool(fd, torch.zeros(0, 5, device=DEV), 7, 7, 1.0)
+    assert tuple(empty.shape) == (0, 256, 7, 7)
+
+
+def test_permutes_roundtrip():
+    t = torch.randn(3, 40, 7, 9)
+    d = t.to(DEV)
+    nh = hip.to_nhwc(d)
+    assert torch.equal(nh.cpu(), t.permute(0, 2, 3, 1))
+    back = hip.to_nchw(nh.contiguous())
+    assert torch.equal(back.cpu(), t)
+    crop = hip.to_nhwc(d[:, :, 2:-2, 1:-3])
+    assert torch.equal(crop.cpu(), t[:, :, 2:-2, 1:-3].permute(0, 2, 3, 1))
+
+
+def test_decode_matches_oracle(gold_host):
+    for inst in (255, 271):
+        p = orc.Hyper(inst)
+        S = p.score_size
+        window = np.outer(np.hanning(S), np.hanning(S))
+        for case in range(4):
+            c = 'i%d/decode%d' % (inst, case)
+            cls, cm, bbox = gold_host[c + '/cls'], gold_host[c + '/cls_mem'], gold_host[c + '/bbox']
+            tsz, sz = gold_host[c + '/tsz'], float(gold_host[c + '/scale_z'])
+            out = hip.decode(torch.from_numpy(cls).to(DEV).reshape(-1), torch.from_numpy(cm).to(DEV).reshape(-1),
+                             torch.from_numpy(bbox).to(DEV).reshape(4, -1), torch.from_numpy(window).to(DEV).reshape(-1),
+                             S, inst, 8, p.ratio, p.penalty_k, p.window_influence, tsz[0] * sz, tsz[1] * sz).cpu().numpy()
+            pos, szo, score, box, rc = orc.decode(p, cls[0, 0], cm[0, 0], bbox[0], gold_host[c + '/tpos'],
+                                                  tsz * sz, window, sz)
+            assert int(out[0]) == rc[0] * S + rc[1]
+            assert abs(out[1] - score) < 1e-6
+            np.testing.assert_allclose(out[3:7], box, rtol=1e-9)

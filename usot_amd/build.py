@@ -1,0 +1,57 @@
+"""Builds usot_amd/csrc/libusot_hip.so for gfx950 with hipcc (in-tree, no JIT cache)."""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+LIB = os.path.join(CSRC, 'libusot_hip.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC]
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.sep not in c or os.path.exists(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(INCLUDE, '*.h'))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every .hip translation unit and link the shared library."""
+    if not force and not is_stale():
+        return LIB
+    cc = _hipcc()
+    objs = []
+    procs = []
+    for src in sources():
+        obj = src[:-4] + '.o'
+        objs.append(obj)
+        cmd = [cc] + FLAGS + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed on %s:\n%s' % (src, out.decode(errors='replace')))
+    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,385 @@
+// Convolution as implicit GEMM on the gfx950 fp32 matrix cores.
+//
+// GEMM view (per group):  D[co][m] = sum_k Wp[co][k] * A[m][k]
+//   m = (n, oh, ow) output pixel,  k = (kh, kw, ci) with ci innermost (NHWC input),
+//   A[m][k] = x[n][oh*s - ph + kh*dh][ow*s - pw + kw*dw][ci]   (0 outside the image).
+// The weight tile is the MFMA "A" operand and the activation tile the "B" operand, so a
+// lane's four accumulator registers are four CONSECUTIVE output channels of one pixel:
+// the epilogue (bias, residual, activation) and the NHWC store are 16-byte accesses.
+//
+// v_mfma_f32_16x16x4_f32 is exact fp32 (an fmaf chain, one rounding per product) at
+// 64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak: this is the roofline the fp32 path is
+// measured against.  Each lane feeds it one float of W and one of A per instruction; a
+// lane reads 4 consecutive k of its row with one ds_read_b128 and issues 4 MFMAs from
+// it (lane quad q owns k-slot q of every 4x16 step, so a 16-wide k round costs one
+// b128 read per 16x16 block row/column).
+//
+// Tiling: 256 threads = 4 wavefronts; workgroup tile BM(pixels) x BN(channels) x 32(k);
+// register-staged double buffering: global loads for tile t+1 are issued before the
+// MFMAs of tile t and written to the other LDS buffer after them; one barrier per tile.
+// LDS rows are padded to 36 floats (144 B, keeps 16-B alignment, spreads rows over banks).
+// Small M (batch 1: M = 961 or 625) is handled by small tiles and optional split-K, not
+// by padding up to a big tile — see DESIGN.md "filling 1024 SIMDs at M = 961".
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "usot_hip.h"
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvK {
+    const float *x, *w, *bias, *res;
+    float *y, *ws;
+    int N, H, W, Cin, OH, OW, Cout;
+    int KH, KW, stride, pad_h, pad_w, dil_h, dil_w;
+    int y_cstride, y_coff, res_cstride, res_coff, y_nchw;
+    int act, act2, act_split;
+    int groups;
+    long x_gs, w_gs, b_gs, y_gs, r_gs;
+    int ksplit;
+    int M, K, KT, cchunks, MT, NT, P;   // P = OH*OW
+    int vec_store;
+};
+
+__device__ __forceinline__ float apply_act(float v, int a)
+{
+    switch (a) {
+    case USOT_ACT_RELU: return fmaxf(v, 0.0f);
+    case USOT_ACT_EXP:  return expf(v);
+    case USOT_ACT_CONF: return expf(fminf(fmaxf(v, 0.0f), 4.0f));
+    default:            return v;
+    }
+}
+
+// XCD-aware, bijective block remap: the dispatcher places block b on XCD b % 8; give each
+// XCD a contiguous chunk of the tile space so the M-tiles that share a weight strip (and
+// the neighbouring pixels' input rows) meet in one L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int b, int total)
+{
+    const int q = total >> 3, r = total & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+constexpr int LDK = 36;   // padded k-extent of an LDS row (floats)
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p)
+{
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    static_assert(TM >= 1 && TN >= 1, "wave tile at least 16x16");
+    constexpr int XI = (BM + 31) / 32, WI = (BN + 31) / 32;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sX = smem;                   // [2][BM][LDK]
+    float *sW = smem + 2 * BM * LDK;    // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int tiles = p.MT * p.NT;
+    const int total = tiles * p.groups * p.ksplit;
+    const int b = xcd_remap(blockIdx.x, total);
+    const int z = b / tiles, t = b - z * tiles;
+    const int g = z / p.ksplit, ks = z - g * p.ksplit;
+    const int bn0 = (t / p.MT) * BN, bm0 = (t % p.MT) * BM;
+    const int kt0 = (int)((long)p.KT * ks / p.ksplit);
+    const int kt1 = (int)((long)p.KT * (ks + 1) / p.ksplit);
+
+    const float *__restrict__ xg = p.x + (long)g * p.x_gs;
+    const float *__restrict__ wg = p.w + (long)g * p.w_gs;
+
+    // ---- loader role: thread (lr, kc) moves 16-byte chunk kc of rows lr, lr+32, ...
+    const int lr = tid >> 3, kc = tid & 7;
+    int x_ih0[XI], x_iw0[XI];
+    long x_nb[XI];
+    bool x_ok[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = lr + 32 * i;
+        const int m = bm0 + row;
+        x_ok[i] = (row < BM) && (m < p.M);
+        const int mm = x_ok[i] ? m : 0;
+        const int n = mm / p.P, pix = mm - n * p.P;
+        const int oh = pix / p.OW, ow = pix - oh * p.OW;
+        x_ih0[i] = oh * p.stride - p.pad_h;
+        x_iw0[i] = ow * p.stride - p.pad_w;
+        x_nb[i] = (long)n * p.H * p.W * p.Cin + kc * 4;
+    }
+    long w_off[WI];
+    bool w_ok[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = lr + 32 * i;
+        const int co = bn0 + row;
+        w_ok[i] = (row < BN) && (co < p.Cout);
+        w_off[i] = (long)(w_ok[i] ? co : 0) * p.K + kc * 4;
+    }
+
+    f32x4 xr[XI], wr[WI];
+    auto load_tile = [&](int kt) {
+        const int tap = kt / p.cchunks, c0 = (kt - tap * p.cchunks) * 32;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int dh = kh * p.dil_h, dw = kw * p.dil_w;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int ih = x_ih0[i] + dh, iw = x_iw0[i] + dw;
+            const bool ok = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *(const f32x4 *)(xg + x_nb[i] + ((long)ih * p.W + iw) * p.Cin + c0);
+            xr[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (w_ok[i]) v = *(const f32x4 *)(wg + w_off[i] + (long)kt * 32);
+            wr[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            if (lr + 32 * i < BM)
+                *(f32x4 *)(sX + (buf * BM + lr + 32 * i) * LDK + kc * 4) = xr[i];
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+            if (lr + 32 * i < BN)
+                *(f32x4 *)(sW + (buf * BN + lr + 32 * i) * LDK + kc * 4) = wr[i];
+    };
+
+    // ---- MFMA role
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l15 = lane & 15, quad = lane >> 4;
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
+        if (more) load_tile(kt + 1);
+        const float *cX = sX + (cur * BM + wm * TM * 16 + l15) * LDK + quad * 4;
+        const float *cW = sW + (cur * BN + wn * TN * 16 + l15) * LDK + quad * 4;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            f32x4 wf[TN], xf[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) wf[i] = *(const f32x4 *)(cW + i * 16 * LDK + r * 16);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) xf[j] = *(const f32x4 *)(cX + j * 16 * LDK + r * 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][c], xf[j][c], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels co..co+3 (quad*4 + reg) of pixel m (l15)
+    if (p.ksplit > 1) {
+        float *wsg = p.ws + ((long)(ks * p.groups + g) * p.M) * p.Cout;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = bm0 + (wm * TM + j) * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+                if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
+                    *(f32x4 *)(wsg + (long)m * p.Cout + co) = acc[i][j];
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Cout) wsg[(long)m * p.Cout + co + e] = acc[i][j][e];
+                }
+            }
+        }
+        return;
+    }
+    const float *__restrict__ bg = p.bias ? p.bias + (long)g * p.b_gs : nullptr;
+    const float *__restrict__ rg = p.res ? p.res + (long)g * p.r_gs : nullptr;
+    float *__restrict__ yg = p.y + (long)g * p.y_gs;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = bm0 + (wm * TM + j) * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+            if (co >= p.Cout) continue;
+            f32x4 v = acc[i][j];
+            if (p.vec_store && co + 3 < p.Cout) {
+                if (bg) v += *(const f32x4 *)(bg + co);
+                if (rg) v += *(const f32x4 *)(rg + (long)m * p.res_cstride + p.res_coff + co);
+                const int a = co < p.act_split ? p.act : p.act2;
+                if (a != USOT_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a);
+                }
+                *(f32x4 *)(yg + (long)m * p.y_cstride + p.y_coff + co) = v;
+            } else {
+                const int n = m / p.P, pix = m - n * p.P;
+                for (int e = 0; e < 4; ++e) {
+                    const int c = co + e;
+                    if (c >= p.Cout) break;
+                    float s = v[e];
+                    if (bg) s += bg[c];
+                    if (rg) s += rg[(long)m * p.res_cstride + p.res_coff + c];
+                    s = apply_act(s, c < p.act_split ? p.act : p.act2);
+                    if (p.y_nchw) yg[((long)n * p.Cout + c) * p.P + pix] = s;
+                    else          yg[(long)m * p.y_cstride + p.y_coff + c] = s;
+                }
+            }
+        }
+    }
+}
+
+// split-K second pass: sum the partial slabs, then the same epilogue.
+__global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvK p)
+{
+    const long per_g = (long)p.M * p.Cout;
+    const long total = per_g * p.groups;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx / per_g);
+        const long r = idx - (long)g * per_g;
+        const int m = (int)(r / p.Cout), c = (int)(r - (long)m * p.Cout);
+        float s = 0.f;
+        for (int ks = 0; ks < p.ksplit; ++ks)
+            s += p.ws[((long)(ks * p.groups + g) * p.M + m) * p.Cout + c];
+        if (p.bias) s += p.bias[(long)g * p.b_gs + c];
+        if (p.res) s += p.res[(long)g * p.r_gs + (long)m * p.res_cstride + p.res_coff + c];
+        s = apply_act(s, c < p.act_split ? p.act : p.act2);
+        float *yg = p.y + (long)g * p.y_gs;
+        if (p.y_nchw) {
+            const int n = m / p.P, pix = m - n * p.P;
+            yg[((long)n * p.Cout + c) * p.P + pix] = s;
+        } else {
+            yg[(long)m * p.y_cstride + p.y_coff + c] = s;
+        }
+    }
+}
+
+struct TileCfg { int bm, bn; void (*fn)(const ConvK); };
+
+#define TILE(bm, bn, wm, wn) { bm, bn, conv_igemm_f32<bm, bn, wm, wn> }
+const TileCfg kTiles[] = {
+    TILE(128, 128, 2, 2),   // 1: batched backbone
+    TILE(128, 64, 2, 2),    // 2
+    TILE(64, 128, 2, 2),    // 3
+    TILE(64, 64, 2, 2),     // 4
+    TILE(32, 64, 2, 2),     // 5
+    TILE(64, 32, 2, 2),     // 6
+    TILE(32, 32, 2, 2),     // 7
+    TILE(16, 64, 1, 4),     // 8: tiny M (template-side encoders)
+    TILE(16, 128, 1, 4),    // 9
+    TILE(32, 128, 2, 2),    // 10
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+int pick_tile(const usot_conv_desc *d, int M)
+{
+    // Aim for >= ~1 wave of workgroups (256 CUs, up to 4 resident per CU for the small
+    // tiles) without shrinking below what the problem needs.
+    const int order[] = {1, 2, 4, 5, 7};
+    int best = 7;
+    for (int id : order) {
+        const TileCfg &t = kTiles[id - 1];
+        if (t.bn > ((d->Cout + 15) / 16) * 16 && t.bn > 32) continue;
+        long blocks = (long)((M + t.bm - 1) / t.bm) * ((d->Cout + t.bn - 1) / t.bn) * d->groups;
+        if (blocks >= 512) { best = id; break; }
+    }
+    if (M <= 16 * 12) best = 8;
+    return best;
+}
+
+}  // namespace
+
+extern "C" int usot_conv_tile_count(void) { return kNumTiles; }
+
+extern "C" int usot_conv_tile_info(int tile, int *bm, int *bn)
+{
+    if (tile < 1 || tile > kNumTiles) return USOT_EINVAL;
+    if (bm) *bm = kTiles[tile - 1].bm;
+    if (bn) *bn = kTiles[tile - 1].bn;
+    return USOT_OK;
+}
+
+extern "C" int64_t usot_conv_ws_floats(const usot_conv_desc *d)
+{
+    if (!d || d->ksplit <= 1) return 0;
+    return (int64_t)d->ksplit * d->groups * d->N * d->OH * d->OW * d->Cout;
+}
+
+extern "C" int usot_conv2d_f32(void *stream, const usot_conv_desc *d)
+{
+    if (!d || !d->x || !d->w || !d->y) return USOT_EINVAL;
+    if (d->Cin <= 0 || (d->Cin & 31) || d->Cout <= 0 || d->N <= 0) return USOT_EINVAL;
+    if (d->groups < 1 || d->stride < 1 || d->KH < 1 || d->KW < 1) return USOT_EINVAL;
+    const int oh = (d->H + 2 * d->pad_h - d->dil_h * (d->KH - 1) - 1) / d->stride + 1;
+    const int ow = (d->W + 2 * d->pad_w - d->dil_w * (d->KW - 1) - 1) / d->stride + 1;
+    if (oh != d->OH || ow != d->OW || oh <= 0 || ow <= 0) return USOT_EINVAL;
+    const int ksplit = d->ksplit > 1 ? d->ksplit : 1;
+    if (ksplit > 1 && !d->ws) return USOT_EINVAL;
+
+    ConvK p;
+    p.x = d->x; p.w = d->w; p.bias = d->bias; p.res = d->res; p.y = d->y; p.ws = d->ws;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+    p.dil_h = d->dil_h; p.dil_w = d->dil_w;
+    p.y_nchw = d->y_nchw;
+    p.y_cstride = d->y_cstride > 0 ? d->y_cstride : d->Cout;
+    p.y_coff = d->y_coff;
+    p.res_cstride = d->res_cstride > 0 ? d->res_cstride : d->Cout;
+    p.res_coff = d->res_coff;
+    p.act = d->act; p.act2 = d->act2;
+    p.act_split = d->act_split > 0 ? d->act_split : (1 << 30);
+    p.groups = d->groups;
+    p.x_gs = d->x_gs; p.w_gs = d->w_gs; p.b_gs = d->b_gs; p.y_gs = d->y_gs; p.r_gs = d->r_gs;
+    p.ksplit = ksplit;
+    p.P = d->OH * d->OW;
+    p.M = d->N * p.P;
+    p.K = d->KH * d->KW * d->Cin;
+    p.cchunks = d->Cin / 32;
+    p.KT = d->KH * d->KW * p.cchunks;
+    if (ksplit > p.KT) return USOT_EINVAL;
+    p.vec_store = !d->y_nchw && (p.y_cstride % 4 == 0) && (p.y_coff % 4 == 0) &&
+                  (!d->res || (p.res_cstride % 4 == 0 && p.res_coff % 4 == 0)) &&
+                  ((uintptr_t)d->y % 16 == 0) && (!d->res || (uintptr_t)d->res % 16 == 0) &&
+                  (!d->bias || (uintptr_t)d->bias % 16 == 0) &&
+                  (d->y_gs % 4 == 0) && (d->r_gs % 4 == 0) && (d->b_gs % 4 == 0);
+    if (((uintptr_t)d->x % 16) || ((uintptr_t)d->w % 16) || (d->x_gs % 4) || (d->w_gs % 4))
+        return USOT_EINVAL;
+
+    int tile = d->tile;
+    if (tile == 0) tile = pick_tile(d, p.M);
+    if (tile < 1 || tile > kNumTiles) return USOT_EINVAL;
+    const TileCfg &tc = kTiles[tile - 1];
+    p.MT = (p.M + tc.bm - 1) / tc.bm;
+    p.NT = (d->Cout + tc.bn - 1) / tc.bn;
+    const long blocks = (long)p.MT * p.NT * p.groups * ksplit;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
+    const size_t lds = (size_t)2 * (tc.bm + tc.bn) * LDK * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tc.fn, dim3((unsigned)blocks), dim3(256), lds, s, p);
+    if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
+    if (ksplit > 1) {
+        const long total = (long)p.M * p.Cout * p.groups;
+        const int gb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        hipLaunchKernelGGL(conv_splitk_epilogue, dim3(gb), dim3(256), 0, s, p);
+        if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
+    }
+    return USOT_OK;
+}

@@ -1,0 +1,301 @@
+// Small head-side kernels: Conf_Fusion reduction, Precise RoI Pooling forward, layout
+// permutes at the API edge, and the on-device decode of a frame's response maps.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "usot_hip.h"
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- Conf_Fusion (connect.py:132-142): out = sum_m conf_m * value_m / sum_m conf_m -------
+__global__ __launch_bounds__(256) void conf_fusion_reduce_kernel(
+    const float *__restrict__ cv, float *__restrict__ out, int B, int M, int P, int C4)
+{
+    const long total = (long)B * P * C4;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C4);
+        const long bp = idx / C4;
+        const int pix = (int)(bp % P);
+        const int b = (int)(bp / P);
+        f32x4 den = {0.f, 0.f, 0.f, 0.f}, num = {0.f, 0.f, 0.f, 0.f};
+        const float *base = cv + ((long)b * M * P + pix) * 2 * C4 * 4 + c * 4;
+        const long mstride = (long)P * 2 * C4 * 4;
+        for (int m = 0; m < M; ++m) den += *(const f32x4 *)(base + m * mstride);
+        // same association as the reference: normalise each conf, then weight and add
+        for (int m = 0; m < M; ++m) {
+            const f32x4 c4 = *(const f32x4 *)(base + m * mstride);        // L1/L2 hit
+            const f32x4 v4 = *(const f32x4 *)(base + m * mstride + C4 * 4);
+            num += (c4 / den) * v4;
+        }
+        *(f32x4 *)(out + idx * 4) = num;
+    }
+}
+
+// ---- Precise RoI Pooling forward (prroi_pooling_gpu_impl.cu:37-42,71-106,149-212) --------
+struct PrK {
+    const float *feat, *rois;
+    float *out;
+    int R, C, H, W, PH, PW;
+    float scale;
+    long f_sb, f_sc, f_sh, f_sw, o_sr, o_sc, o_sh, o_sw;
+};
+
+__device__ __forceinline__ float pr_tap(const float *d, int h, int w, const PrK &p)
+{
+    if (h < 0 || w < 0 || h >= p.H || w >= p.W) return 0.f;
+    return d[h * p.f_sh + w * p.f_sw];
+}
+
+__device__ __forceinline__ float pr_cell(const float *d, int s_h, int s_w, float y0, float x0,
+                                         float y1, float x1, const PrK &p)
+{
+    const int e_h = s_h + 1, e_w = s_w + 1;
+    float alpha = x0 - (float)s_w, beta = y0 - (float)s_h;
+    float lim_alpha = x1 - (float)s_w, lim_beta = y1 - (float)s_h;
+    float tmp = (lim_alpha - 0.5f * lim_alpha * lim_alpha - alpha + 0.5f * alpha * alpha)
+              * (lim_beta - 0.5f * lim_beta * lim_beta - beta + 0.5f * beta * beta);
+    float sum = pr_tap(d, s_h, s_w, p) * tmp;
+
+    alpha = (float)e_w - x1; lim_alpha = (float)e_w - x0;
+    tmp = (lim_alpha - 0.5f * lim_alpha * lim_alpha - alpha + 0.5f * alpha * alpha)
+        * (lim_beta - 0.5f * lim_beta * lim_beta - beta + 0.5f * beta * beta);
+    sum += pr_tap(d, s_h, e_w, p) * tmp;
+
+    alpha = x0 - (float)s_w; beta = (float)e_h - y1;
+    lim_alpha = x1 - (float)s_w; lim_beta = (float)e_h - y0;
+    tmp = (lim_alpha - 0.5f * lim_alpha * lim_alpha - alpha + 0.5f * alpha * alpha)
+        * (lim_beta - 0.5f * lim_beta * lim_beta - beta + 0.5f * beta * beta);
+    sum += pr_tap(d, e_h, s_w, p) * tmp;
+
+    alpha = (float)e_w - x1; lim_alpha = (float)e_w - x0;
+    tmp = (lim_alpha - 0.5f * lim_alpha * lim_alpha - alpha + 0.5f * alpha * alpha)
+        * (lim_beta - 0.5f * lim_beta * lim_beta - beta + 0.5f * beta * beta);
+    sum += pr_tap(d, e_h, e_w, p) * tmp;
+    return sum;
+}
+
+// channel is the fastest-varying index of the thread map: coalesced on NHWC features
+__global__ __launch_bounds__(256) void prroi_forward_kernel(const PrK p)
+{
+    const long total = (long)p.R * p.PH * p.PW * p.C;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % p.C);
+        long r = idx / p.C;
+        const int pw = (int)(r % p.PW); r /= p.PW;
+        const int ph = (int)(r % p.PH);
+        const int n = (int)(r / p.PH);
+        const float *roi = p.rois + (long)n * 5;
+        const int b = (int)roi[0];
+        const float rsw = roi[1] * p.scale, rsh = roi[2] * p.scale;
+        const float rew = roi[3] * p.scale, reh = roi[4] * p.scale;
+        const float rw = fmaxf(rew - rsw, 0.f), rh = fmaxf(reh - rsh, 0.f);
+        const float bh = rh / (float)p.PH, bw = rw / (float)p.PW;
+        const float win = fmaxf(0.f, bw * bh);
+        float *o = p.out + n * p.o_sr + c * p.o_sc + ph * p.o_sh + pw * p.o_sw;
+        if (win == 0.f) { *o = 0.f; continue; }
+        const float *d = p.feat + b * p.f_sb + c * p.f_sc;
+        const float wsw = rsw + bw * pw, wsh = rsh + bh * ph;
+        const float wew = wsw + bw, weh = wsh + bh;
+        const int s_w = (int)floorf(wsw), e_w = (int)ceilf(wew);
+        const int s_h = (int)floorf(wsh), e_h = (int)ceilf(weh);
+        float sum = 0.f;
+        for (int wi = s_w; wi < e_w; ++wi)
+            for (int hi = s_h; hi < e_h; ++hi)
+                sum += pr_cell(d, hi, wi, fmaxf(wsh, (float)hi), fmaxf(wsw, (float)wi),
+                               fminf(weh, (float)hi + 1.0f), fminf(wew, (float)wi + 1.0f), p);
+        *o = sum / win;
+    }
+}
+
+// ---- generic 4-D permute: dst dense [D0][D1][D2][D3] <- strided src ------------------------
+__global__ __launch_bounds__(256) void permute4_kernel(
+    const float *__restrict__ src, float *__restrict__ dst, int D1, int D2, int D3, long total,
+    long s0, long s1, long s2, long s3)
+{
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % D3);
+        long r = idx / D3;
+        const int b = (int)(r % D2); r /= D2;
+        const int a = (int)(r % D1);
+        const long n = r / D1;
+        dst[idx] = src[n * s0 + a * s1 + b * s2 + c * s3];
+    }
+}
+
+// ---- decode (usot_tracker.py:138-163): one workgroup, double precision like the numpy
+// reference (its grids are float64, so everything after the float32 sigmoid promotes) -------
+__global__ __launch_bounds__(256) void decode_kernel(
+    const float *__restrict__ cls, const float *__restrict__ cls_mem, const float *__restrict__ bbox,
+    const double *__restrict__ window, double *__restrict__ out, int S, int instance_size, int stride,
+    float ratio, double penalty_k, double window_influence, double tw, double th,
+    const double *__restrict__ tsz_dev, float *__restrict__ roi_out)
+{
+    if (tsz_dev) { tw = tsz_dev[0]; th = tsz_dev[1]; }
+    __shared__ double best_v[256];
+    __shared__ int best_i[256];
+    const int n = S * S;
+    const double tpad = (tw + th) * 0.5;
+    const double tsz = sqrt((tw + tpad) * (th + tpad));
+    const double tratio = tw / th;
+    double bv = -1e300;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = i / S, c = i - r * S;
+        const double gx = (double)((c - S / 2) * stride + instance_size / 2);
+        const double gy = (double)((r - S / 2) * stride + instance_size / 2);
+        const float s0 = 1.0f / (1.0f + expf(-cls[i]));
+        const float s1 = 1.0f / (1.0f + expf(-cls_mem[i]));
+        const float sc = ratio * s0 + (1.0f - ratio) * s1;
+        const double x1 = gx - (double)bbox[i], y1 = gy - (double)bbox[n + i];
+        const double x2 = gx + (double)bbox[2 * n + i], y2 = gy + (double)bbox[3 * n + i];
+        const double w = x2 - x1, h = y2 - y1;
+        const double pad = (w + h) * 0.5;
+        double sr = sqrt((w + pad) * (h + pad)) / tsz;
+        sr = fmax(sr, 1.0 / sr);
+        double rr = tratio / (w / h);
+        rr = fmax(rr, 1.0 / rr);
+        const double pen = exp(-(rr * sr - 1.0) * penalty_k);
+        const double ps = pen * (double)sc * (1.0 - window_influence) + window[i] * window_influence;
+        if (ps > bv) { bv = ps; bi = i; }
+    }
+    best_v[threadIdx.x] = bv;
+    best_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            const double ov = best_v[threadIdx.x + off];
+            const int oi = best_i[threadIdx.x + off];
+            if (ov > best_v[threadIdx.x] || (ov == best_v[threadIdx.x] && oi < best_i[threadIdx.x])) {
+                best_v[threadIdx.x] = ov;
+                best_i[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int i = best_i[0];
+        const int r = i / S, c = i - r * S;
+        const double gx = (double)((c - S / 2) * stride + instance_size / 2);
+        const double gy = (double)((r - S / 2) * stride + instance_size / 2);
+        const float s0 = 1.0f / (1.0f + expf(-cls[i]));
+        const float s1 = 1.0f / (1.0f + expf(-cls_mem[i]));
+        const float sc = ratio * s0 + (1.0f - ratio) * s1;
+        const double x1 = gx - (double)bbox[i], y1 = gy - (double)bbox[n + i];
+        const double x2 = gx + (double)bbox[2 * n + i], y2 = gy + (double)bbox[3 * n + i];
+        const double w = x2 - x1, h = y2 - y1;
+        const double pad = (w + h) * 0.5;
+        double sr = sqrt((w + pad) * (h + pad)) / tsz;
+        sr = fmax(sr, 1.0 / sr);
+        double rr = tratio / (w / h);
+        rr = fmax(rr, 1.0 / rr);
+        out[0] = (double)i;
+        out[1] = (double)sc;
+        out[2] = exp(-(rr * sr - 1.0) * penalty_k);
+        out[3] = x1; out[4] = y1; out[5] = x2; out[6] = y2;
+        out[7] = best_v[0];
+        if (roi_out) {
+            // usot_tracker.py:329-350 (pool_label_search): the S-point axis of the response
+            // map applied to the search feature; box rounded to float32 first (np.array(...,
+            // np.float32)), arithmetic in float64, result stored as float32 (.float()).
+            const double lo = (double)((0 - S / 2) * stride + instance_size / 2);
+            const double hi = (double)((S - 1 - S / 2) * stride + instance_size / 2);
+            const double slope = (double)(2 * (S / 2)) / (hi - lo);
+            const double gap = 1.0 / slope;
+            const double bx[4] = {x1, y1, x2, y2};
+            roi_out[0] = 0.f;
+            for (int e = 0; e < 4; ++e) {
+                double v = (double)(float)bx[e];
+                v = fmin(fmax(v, lo - gap), hi + gap);
+                roi_out[1 + e] = (float)((v - lo) * slope);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int usot_conf_fusion_reduce_f32(void *stream, const float *cv, float *out,
+                                           int B, int M, int P, int C)
+{
+    if (!cv || !out || B <= 0 || M <= 0 || P <= 0 || C <= 0 || (C & 3)) return USOT_EINVAL;
+    if (((uintptr_t)cv % 16) || ((uintptr_t)out % 16)) return USOT_EINVAL;
+    const long total = (long)B * P * (C / 4);
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(conf_fusion_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       cv, out, B, M, P, C / 4);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+extern "C" int usot_prroi_pool_forward_f32(void *stream, const float *feat, const float *rois, float *out,
+                                           int R, int C, int H, int W, int PH, int PW, float scale,
+                                           int64_t f_sb, int64_t f_sc, int64_t f_sh, int64_t f_sw,
+                                           int64_t o_sr, int64_t o_sc, int64_t o_sh, int64_t o_sw)
+{
+    if (R < 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0) return USOT_EINVAL;
+    if (R == 0) return USOT_OK;      /* the reference binding early-returns on empty (…gpu.c:22-44) */
+    if (!feat || !rois || !out) return USOT_EINVAL;
+    PrK p{feat, rois, out, R, C, H, W, PH, PW, scale, f_sb, f_sc, f_sh, f_sw, o_sr, o_sc, o_sh, o_sw};
+    const long total = (long)R * C * PH * PW;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(prroi_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+extern "C" int usot_permute4_f32(void *stream, const float *src, float *dst,
+                                 int D0, int D1, int D2, int D3,
+                                 int64_t s0, int64_t s1, int64_t s2, int64_t s3)
+{
+    if (!src || !dst || D0 <= 0 || D1 <= 0 || D2 <= 0 || D3 <= 0) return USOT_EINVAL;
+    const long total = (long)D0 * D1 * D2 * D3;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(permute4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, D1, D2, D3, total, (long)s0, (long)s1, (long)s2, (long)s3);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+extern "C" int usot_decode_f32(void *stream, const float *cls, const float *cls_mem, const float *bbox,
+                               const double *window, double *out, int S, int instance_size, int stride,
+                               float ratio, double penalty_k, double window_influence,
+                               double tw, double th)
+{
+    if (!cls || !cls_mem || !bbox || !window || !out || S <= 0 || S > 64) return USOT_EINVAL;
+    hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cls, cls_mem, bbox,
+                       window, out, S, instance_size, stride, ratio, penalty_k, window_influence, tw, th,
+                       (const double *)nullptr, (float *)nullptr);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+/* plan-side variant: target size read from device memory, PrPool roi of the best box written
+ * to device memory, so a frame's decode + memory-feature pooling needs no host round trip */
+extern "C" int usot_decode_dev_f32(void *stream, const float *cls, const float *cls_mem,
+                                   const float *bbox, const double *window, double *out, int S,
+                                   int instance_size, int stride, float ratio, double penalty_k,
+                                   double window_influence, const double *tsz_dev, float *roi_out)
+{
+    if (!cls || !cls_mem || !bbox || !window || !out || !tsz_dev || S <= 0 || S > 64) return USOT_EINVAL;
+    hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cls, cls_mem, bbox,
+                       window, out, S, instance_size, stride, ratio, penalty_k, window_influence, 1.0, 1.0,
+                       tsz_dev, roi_out);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+extern "C" int usot_abi_version(void) { return 1; }
+
+extern "C" const char *usot_strerror(int code)
+{
+    switch (code) {
+    case USOT_OK: return "ok";
+    case USOT_EINVAL: return "invalid argument or unsupported geometry";
+    case USOT_ELAUNCH: return "kernel launch failed";
+    case USOT_ENOMEM: return "out of memory";
+    case USOT_ESTATE: return "object used in the wrong state";
+    default: return "unknown error";
+    }
+}

@@ -1,0 +1,302 @@
+// Launch plans: the native per-frame runtime.
+//
+// A tracked frame is ~70 dependent kernel launches of a few microseconds each; issued one
+// by one from Python the host, not the GPU, sets the frame rate.  A plan records the whole
+// sequence once (descriptors with baked device pointers into the engine's static
+// workspace), replays it from C++ with no per-launch Python, and can be captured into a
+// hipGraph so that a frame costs one hipGraphLaunch.  Independent branches of the head
+// (the cls / reg / memory chains, shortcut convs of the backbone) may be placed on side
+// "lanes": extra streams forked from and joined to the main stream with events, which
+// capture turns into parallel graph branches.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <new>
+#include <vector>
+#include "usot_hip.h"
+#include "common.h"
+
+extern "C" int usot_decode_dev_f32(void *stream, const float *cls, const float *cls_mem,
+                                   const float *bbox, const double *window, double *out, int S,
+                                   int instance_size, int stride, float ratio, double penalty_k,
+                                   double window_influence, const double *tsz_dev, float *roi_out);
+
+namespace {
+
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN };
+
+constexpr int kLanes = 4;     // lane 0 is the caller's stream
+
+struct Op {
+    Kind kind;
+    int lane;
+    usot_conv_desc conv;
+    usot_groupdw_desc gdw;
+    const void *p[6];
+    int i[8];
+    int64_t l[8];
+    float f[2];
+    double d[2];
+};
+
+struct Plan {
+    std::vector<Op> ops;
+    int cur_lane = 0;
+    hipStream_t side[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> events;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool captured = false;
+};
+
+int issue(Plan *pl, hipStream_t main_stream, bool lanes)
+{
+    hipStream_t st[kLanes];
+    st[0] = main_stream;
+    for (int k = 1; k < kLanes; ++k) st[k] = lanes ? pl->side[k] : main_stream;
+    size_t ev = 0;
+    for (const Op &op : pl->ops) {
+        hipStream_t s = st[op.lane];
+        int rc = USOT_OK;
+        switch (op.kind) {
+        case K_CONV: rc = usot_conv2d_f32(s, &op.conv); break;
+        case K_GDW:  rc = usot_groupdw_f32(s, &op.gdw); break;
+        case K_STEM:
+            rc = usot_stem_conv_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2],
+                                    (float *)op.p[3], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4]);
+            break;
+        case K_POOL:
+            rc = usot_maxpool3x3s2_f32(s, (const float *)op.p[0], (float *)op.p[1], op.i[0], op.i[1], op.i[2],
+                                       op.i[3], op.i[4], op.i[5]);
+            break;
+        case K_CONF:
+            rc = usot_conf_fusion_reduce_f32(s, (const float *)op.p[0], (float *)op.p[1], op.i[0], op.i[1],
+                                             op.i[2], op.i[3]);
+            break;
+        case K_PRROI:
+            rc = usot_prroi_pool_forward_f32(s, (const float *)op.p[0], (const float *)op.p[1], (float *)op.p[2],
+                                             op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.f[0],
+                                             op.l[0], op.l[1], op.l[2], op.l[3], op.l[4], op.l[5], op.l[6], op.l[7]);
+            break;
+        case K_PERM:
+            rc = usot_permute4_f32(s, (const float *)op.p[0], (float *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3],
+                                   op.l[0], op.l[1], op.l[2], op.l[3]);
+            break;
+        case K_DECODE:
+            rc = usot_decode_dev_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2],
+                                     (const double *)op.p[3], (double *)op.p[4], op.i[0], op.i[1], op.i[2],
+                                     op.f[0], op.d[0], op.d[1], (const double *)op.p[5], (float *)op.l[0]);
+            break;
+        case K_FORK:      // lane op.lane waits for everything issued so far on lane 0
+            if (lanes && op.lane != 0) {
+                if (ev >= pl->events.size()) return USOT_ESTATE;
+                hipEvent_t e = pl->events[ev++];
+                if (hipEventRecord(e, st[0]) != hipSuccess) return USOT_ELAUNCH;
+                if (hipStreamWaitEvent(st[op.lane], e, 0) != hipSuccess) return USOT_ELAUNCH;
+            }
+            break;
+        case K_JOIN:      // lane 0 waits for lane op.lane
+            if (lanes && op.lane != 0) {
+                if (ev >= pl->events.size()) return USOT_ESTATE;
+                hipEvent_t e = pl->events[ev++];
+                if (hipEventRecord(e, st[op.lane]) != hipSuccess) return USOT_ELAUNCH;
+                if (hipStreamWaitEvent(st[0], e, 0) != hipSuccess) return USOT_ELAUNCH;
+            }
+            break;
+        }
+        if (rc != USOT_OK) return rc;
+    }
+    return USOT_OK;
+}
+
+int prepare_lanes(Plan *pl)
+{
+    size_t need = 0;
+    bool any = false;
+    for (const Op &op : pl->ops) {
+        if (op.kind == K_FORK || op.kind == K_JOIN) ++need;
+        if (op.lane != 0) any = true;
+    }
+    if (!any) return USOT_OK;
+    for (int k = 1; k < kLanes; ++k)
+        if (!pl->side[k] && hipStreamCreateWithFlags(&pl->side[k], hipStreamNonBlocking) != hipSuccess)
+            return USOT_ENOMEM;
+    while (pl->events.size() < need) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return USOT_ENOMEM;
+        pl->events.push_back(e);
+    }
+    return USOT_OK;
+}
+
+Op *push(void *plan, Kind k)
+{
+    Plan *pl = (Plan *)plan;
+    if (!pl || pl->captured) return nullptr;
+    Op op{};
+    op.kind = k;
+    op.lane = pl->cur_lane;
+    pl->ops.push_back(op);
+    return &pl->ops.back();
+}
+
+}  // namespace
+
+extern "C" void *usot_plan_create(void) { return new (std::nothrow) Plan(); }
+
+extern "C" void usot_plan_destroy(void *plan)
+{
+    Plan *pl = (Plan *)plan;
+    if (!pl) return;
+    if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
+    if (pl->graph) (void)hipGraphDestroy(pl->graph);
+    for (hipEvent_t e : pl->events) (void)hipEventDestroy(e);
+    for (int k = 1; k < kLanes; ++k)
+        if (pl->side[k]) (void)hipStreamDestroy(pl->side[k]);
+    delete pl;
+}
+
+extern "C" int usot_plan_size(void *plan) { return plan ? (int)((Plan *)plan)->ops.size() : USOT_EINVAL; }
+
+extern "C" int usot_plan_add_conv(void *plan, const usot_conv_desc *d)
+{
+    if (!d) return USOT_EINVAL;
+    Op *op = push(plan, K_CONV);
+    if (!op) return USOT_ESTATE;
+    op->conv = *d;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_groupdw(void *plan, const usot_groupdw_desc *d)
+{
+    if (!d) return USOT_EINVAL;
+    Op *op = push(plan, K_GDW);
+    if (!op) return USOT_ESTATE;
+    op->gdw = *d;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_stem(void *plan, const float *x, const float *w, const float *bias, float *y,
+                                  int N, int H, int W, int OH, int OW)
+{
+    Op *op = push(plan, K_STEM);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = x; op->p[1] = w; op->p[2] = bias; op->p[3] = y;
+    op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = OH; op->i[4] = OW;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_maxpool(void *plan, const float *x, float *y, int N, int H, int W, int C,
+                                     int OH, int OW)
+{
+    Op *op = push(plan, K_POOL);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = x; op->p[1] = y;
+    op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = C; op->i[4] = OH; op->i[5] = OW;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_conf_reduce(void *plan, const float *cv, float *out, int B, int M, int P, int C)
+{
+    Op *op = push(plan, K_CONF);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = cv; op->p[1] = out;
+    op->i[0] = B; op->i[1] = M; op->i[2] = P; op->i[3] = C;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_prroi(void *plan, const float *feat, const float *rois, float *out,
+                                   int R, int C, int H, int W, int PH, int PW, float scale,
+                                   int64_t f_sb, int64_t f_sc, int64_t f_sh, int64_t f_sw,
+                                   int64_t o_sr, int64_t o_sc, int64_t o_sh, int64_t o_sw)
+{
+    Op *op = push(plan, K_PRROI);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = feat; op->p[1] = rois; op->p[2] = out;
+    op->i[0] = R; op->i[1] = C; op->i[2] = H; op->i[3] = W; op->i[4] = PH; op->i[5] = PW;
+    op->f[0] = scale;
+    op->l[0] = f_sb; op->l[1] = f_sc; op->l[2] = f_sh; op->l[3] = f_sw;
+    op->l[4] = o_sr; op->l[5] = o_sc; op->l[6] = o_sh; op->l[7] = o_sw;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_permute(void *plan, const float *src, float *dst, int D0, int D1, int D2, int D3,
+                                     int64_t s0, int64_t s1, int64_t s2, int64_t s3)
+{
+    Op *op = push(plan, K_PERM);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = src; op->p[1] = dst;
+    op->i[0] = D0; op->i[1] = D1; op->i[2] = D2; op->i[3] = D3;
+    op->l[0] = s0; op->l[1] = s1; op->l[2] = s2; op->l[3] = s3;
+    return USOT_OK;
+}
+
+/* tsz_dev: device double[2] = target size * scale_z, refreshed by the host per frame;
+ * roi_out: optional device float[5], receives (0, pool_label_search(best box)).          */
+extern "C" int usot_plan_add_decode(void *plan, const float *cls, const float *cls_mem, const float *bbox,
+                                    const double *window, double *out, int S, int instance_size, int stride,
+                                    float ratio, double penalty_k, double window_influence,
+                                    const double *tsz_dev, float *roi_out)
+{
+    Op *op = push(plan, K_DECODE);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = cls; op->p[1] = cls_mem; op->p[2] = bbox; op->p[3] = window; op->p[4] = out; op->p[5] = tsz_dev;
+    op->i[0] = S; op->i[1] = instance_size; op->i[2] = stride;
+    op->f[0] = ratio; op->d[0] = penalty_k; op->d[1] = window_influence;
+    op->l[0] = (int64_t)(uintptr_t)roi_out;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_fork(void *plan, int lane)
+{
+    Plan *pl = (Plan *)plan;
+    if (!pl || lane < 0 || lane >= kLanes) return USOT_EINVAL;
+    pl->cur_lane = lane;
+    Op *op = push(plan, K_FORK);
+    if (!op) return USOT_ESTATE;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_join(void *plan, int lane)
+{
+    Plan *pl = (Plan *)plan;
+    if (!pl || lane < 0 || lane >= kLanes) return USOT_EINVAL;
+    pl->cur_lane = lane;
+    Op *op = push(plan, K_JOIN);
+    if (!op) return USOT_ESTATE;
+    pl->cur_lane = 0;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_capture(void *plan, void *stream)
+{
+    Plan *pl = (Plan *)plan;
+    if (!pl || pl->captured || pl->ops.empty()) return USOT_ESTATE;
+    int rc = prepare_lanes(pl);
+    if (rc != USOT_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return USOT_ELAUNCH;
+    rc = issue(pl, s, true);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc != USOT_OK || e != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        return rc != USOT_OK ? rc : USOT_ELAUNCH;
+    }
+    if (hipGraphInstantiate(&pl->exec, g, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return USOT_ELAUNCH;
+    }
+    pl->graph = g;
+    pl->captured = true;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_run(void *plan, void *stream)
+{
+    Plan *pl = (Plan *)plan;
+    if (!pl) return USOT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (pl->captured) return hipGraphLaunch(pl->exec, s) == hipSuccess ? USOT_OK : USOT_ELAUNCH;
+    return issue(pl, s, false);
+}

@@ -1,0 +1,400 @@
+"""Lowers the USOT forward pass onto libusot_hip.so.
+
+Host-side responsibilities only (no tensor math on activations happens here):
+  * fold every BatchNorm into the preceding convolution in float64 and repack the filters
+    to the [Cout][kh][kw][Cin] layout the implicit-GEMM kernel streams;
+  * merge convolutions that share an input (cls|reg encoders, conf_gen|value_gen) and
+    group the three head towers into single launches;
+  * own a static NHWC workspace per (batch, crop size, memory size) and record the frame's
+    kernel sequence into a native launch plan (optionally a captured hipGraph).
+
+Activation layout is NHWC end to end; NCHW exists only at the API edge (input crop, the
+returned cls/bbox maps).  reference call graph: lib/models/models.py:173-206,
+lib/models/connect.py:221-281, lib/models/modules.py:137-151.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip
+from .net import ConvSlot, NormSlot
+
+ACT_NONE, ACT_RELU, ACT_EXP, ACT_CONF = hip.ACT_NONE, hip.ACT_RELU, hip.ACT_EXP, hip.ACT_CONF
+GEOMS = ('matrix11', 'matrix12', 'matrix21')
+KGEO = ((5, 5), (3, 5), (5, 3))       # template-side encoder output sizes for a 7x7 kernel
+
+
+def fold(conv, bn=None, scale=None, shift=None):
+    """(w[O,kh,kw,I] float64, b[O] float64) with eval-mode BN folded in.
+    Optional extra affine `scale*y + shift` applied after (bbox/cls head constants)."""
+    w = conv.weight.detach().double().cpu()
+    b = conv.bias.detach().double().cpu() if conv.bias is not None else torch.zeros(w.shape[0], dtype=torch.float64)
+    if bn is not None:
+        s = bn.weight.detach().double().cpu() / torch.sqrt(bn.running_var.detach().double().cpu() + bn.eps)
+        w = w * s.view(-1, 1, 1, 1)
+        b = (b - bn.running_mean.detach().double().cpu()) * s + bn.bias.detach().double().cpu()
+    if scale is not None:
+        w = w * scale
+        b = b * scale
+    if shift is not None:
+        b = b + shift
+    return w.permute(0, 2, 3, 1).contiguous(), b
+
+
+class PackedConv:
+    """Device-resident folded filter bank + geometry of one (possibly merged) convolution."""
+
+    def __init__(self, device, slots, ws, bs):
+        ref = slots[0]
+        self.cin, self.kh, self.kw = ref.cin, ref.kh, ref.kw
+        self.stride, self.pad, self.dil = ref.stride, ref.pad, ref.dil
+        w = torch.cat(ws, 0)
+        self.cout = w.shape[0]
+        self.w = w.reshape(self.cout, -1).float().contiguous().to(device)
+        self.b = torch.cat(bs, 0).float().contiguous().to(device)
+
+    def out_hw(self, h, w):
+        oh = (h + 2 * self.pad[0] - self.dil[0] * (self.kh - 1) - 1) // self.stride + 1
+        ow = (w + 2 * self.pad[1] - self.dil[1] * (self.kw - 1) - 1) // self.stride + 1
+        return oh, ow
+
+
+def pack(device, pairs, scale=None, shift=None):
+    """pairs: [(ConvSlot, NormSlot|None), ...] concatenated along Cout."""
+    ws, bs = zip(*[fold(c, n, scale, shift) for c, n in pairs])
+    return PackedConv(device, [c for c, _ in pairs], list(ws), list(bs))
+
+
+class Weights:
+    """All folded / packed parameters of one USOT model on one device."""
+
+    def __init__(self, model, device):
+        self.device = device
+        f = model.features.features
+        w = f.conv1.weight.detach().double().cpu()
+        s = f.bn1.weight.detach().double().cpu() / torch.sqrt(f.bn1.running_var.detach().double().cpu() + f.bn1.eps)
+        self.stem_w = (w * s.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(147, 64).float().contiguous().to(device)
+        self.stem_b = (f.bn1.bias.detach().double().cpu() - f.bn1.running_mean.detach().double().cpu() * s).float().to(device)
+        self.blocks = []
+        for layer in (f.layer1, f.layer2, f.layer3):
+            for blk in layer:
+                ds = pack(device, [(blk.downsample[0], blk.downsample[1])]) if blk.downsample is not None else None
+                self.blocks.append((pack(device, [(blk.conv1, blk.bn1)]), pack(device, [(blk.conv2, blk.bn2)]),
+                                    pack(device, [(blk.conv3, blk.bn3)]), ds))
+        self.neck = pack(device, [(model.neck.downsample[0], model.neck.downsample[1])])
+        cm = model.connect_model
+        enc = lambda e, g, side: (getattr(e, '%s_%s' % (g, side))[0], getattr(e, '%s_%s' % (g, side))[1])
+        # cls rows first, reg rows second: a Cout=256 launch on the same bank is the cls encoder
+        self.enc_s = [pack(device, [enc(cm.cls_encode, g, 's'), enc(cm.reg_encode, g, 's')]) for g in GEOMS]
+        self.enc_k = [pack(device, [enc(cm.cls_encode, g, 'k'), enc(cm.reg_encode, g, 'k')]) for g in GEOMS]
+        self.conf = pack(device, [(cm.conf_fusion.conf_gen[0], cm.conf_fusion.conf_gen[1]),
+                                  (cm.conf_fusion.value_gen[0], cm.conf_fusion.value_gen[1])])
+        towers = (cm.bbox_tower, cm.cls_tower, cm.cls_memory_tower)          # group order
+        self.tower = [pack(device, [(t[3 * i], t[3 * i + 1]) for t in towers]) for i in range(4)]
+        adjust = float(cm.adjust.detach().double().cpu())
+        shift = cm.bias.detach().double().cpu().reshape(4)
+        self.bbox_pred = pack(device, [(cm.bbox_pred, None)], scale=adjust, shift=shift)
+        self.cls_preds = pack(device, [(cm.cls_pred, None), (cm.cls_memory_pred, None)], scale=0.1)
+        sm = lambda p: torch.softmax(p.detach().float().cpu(), 0).numpy()
+        self.cls_wsm, self.reg_wsm = sm(cm.cls_dw.weight), sm(cm.reg_dw.weight)
+
+
+class Plan:
+    """Thin owner of a native launch plan."""
+
+    def __init__(self):
+        self.h = C.c_void_p(hip.lib().usot_plan_create())
+        if not self.h:
+            raise hip.HipError('usot_plan_create failed')
+        self.keep = []          # tensors whose pointers are baked into the plan
+        self.captured = False
+
+    def __del__(self):
+        try:
+            if self.h:
+                hip.lib().usot_plan_destroy(self.h)
+        except Exception:
+            pass
+
+    def run(self):
+        hip.check(hip.lib().usot_plan_run(self.h, hip.stream()), 'usot_plan_run')
+
+    def capture(self):
+        """Capture into a hipGraph on a side stream (legacy stream cannot capture)."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            hip.check(hip.lib().usot_plan_capture(self.h, hip.stream()), 'usot_plan_capture')
+        torch.cuda.current_stream().wait_stream(s)
+        self.captured = True
+
+    def fork(self, lane):
+        hip.check(hip.lib().usot_plan_fork(self.h, lane), 'usot_plan_fork')
+
+    def join(self, lane):
+        hip.check(hip.lib().usot_plan_join(self.h, lane), 'usot_plan_join')
+
+
+class Builder:
+    """Allocates static buffers and appends ops to a plan."""
+
+    def __init__(self, weights, tuning=None):
+        self.W = weights
+        self.dev = weights.device
+        self.plan = Plan()
+        self.tuning = tuning or {}
+        self.log = []           # (name, M, N, K, macs) per conv, for benchmarks
+
+    def buf(self, *shape, dtype=torch.float32):
+        t = torch.empty(shape, device=self.dev, dtype=dtype)
+        self.plan.keep.append(t)
+        return t
+
+    def conv(self, name, pc, x, n, h, w, *, cout=None, act=ACT_NONE, res=None, y=None, y_cstride=0, y_coff=0,
+             act2=ACT_NONE, act_split=0, y_nchw=False, groups=1, x_gs=0, y_gs=0, w_rows=None):
+        """x: tensor (NHWC dense, channels == pc.cin).  Returns (y, oh, ow)."""
+        cout = cout or pc.cout
+        oh, ow = pc.out_hw(h, w)
+        if y is None:
+            y = self.buf(groups, n, cout, oh, ow) if y_nchw else self.buf(groups, n, oh, ow, cout)
+            if groups == 1:
+                y = y[0]
+        k = pc.kh * pc.kw * pc.cin
+        m = n * oh * ow
+        tile, ksplit = self.tuning.get((m, cout, k, groups), (0, 1))
+        ws = None
+        if ksplit > 1:
+            ws = self.buf(ksplit * groups * m * cout)
+        d = hip.conv_desc(x.data_ptr(), pc.w.data_ptr(), pc.b.data_ptr(), y.data_ptr(),
+                          N=n, H=h, W=w, Cin=pc.cin, OH=oh, OW=ow, Cout=cout, KH=pc.kh, KW=pc.kw,
+                          stride=pc.stride, pad=pc.pad, dil=pc.dil,
+                          res=res.data_ptr() if res is not None else None, act=act, act2=act2,
+                          act_split=act_split, y_cstride=y_cstride, y_coff=y_coff, y_nchw=int(y_nchw),
+                          groups=groups, x_gs=x_gs, w_gs=(w_rows or cout) * k, b_gs=(w_rows or cout),
+                          y_gs=y_gs if y_gs else n * oh * ow * cout, r_gs=0,
+                          ksplit=ksplit, tile=tile, ws=ws.data_ptr() if ws is not None else None)
+        hip.check(hip.lib().usot_plan_add_conv(self.plan.h, C.byref(d)), 'plan_add_conv ' + name)
+        self.plan.keep += [x, pc.w, pc.b]
+        self.log.append((name, m, cout, k, groups, m * cout * k * groups))
+        return y, oh, ow
+
+    # ---- a1-a4: backbone + neck: x NCHW [n,3,s,s] -> xf NHWC [n,hf,wf,256]
+    def backbone(self, x, n, size):
+        W, L = self.W, hip.lib()
+        oh = (size - 7) // 2 + 1
+        s0 = self.buf(n, oh, oh, 64)
+        hip.check(L.usot_plan_add_stem(self.plan.h, hip.ptr(x), hip.ptr(W.stem_w), hip.ptr(W.stem_b), hip.ptr(s0),
+                                       n, size, size, oh, oh), 'plan_add_stem')
+        ph = (oh - 1) // 2 + 1
+        p0 = self.buf(n, ph, ph, 64)
+        hip.check(L.usot_plan_add_maxpool(self.plan.h, hip.ptr(s0), hip.ptr(p0), n, oh, oh, 64, ph, ph), 'plan_add_maxpool')
+        self.plan.keep += [x]
+        cur, h = p0, ph
+        stages = [s0]
+        for bi, (c1, c2, c3, ds) in enumerate(W.blocks):
+            t1, _, _ = self.conv('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU)
+            t2, h2, _ = self.conv('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
+            sc = cur
+            if ds is not None:
+                sc, hs, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
+                assert hs == h2
+            cur, _, _ = self.conv('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc)
+            h = h2
+            if bi in (2, 6, 12):                      # ends of layer1 / layer2 / layer3
+                stages.append(cur)
+        xf, _, _ = self.conv('neck', W.neck, cur, n, h, h)
+        self.stages = stages
+        return xf, h
+
+    # ---- a5 template side: zf NHWC [n,7,7,256] -> 3 maps NHWC [n,hk,wk,cout]
+    def encode_kernel(self, zf, n, cout, tag):
+        out = []
+        for g in range(3):
+            y, oh, ow = self.conv('enc_k%d.%s' % (g, tag), self.W.enc_k[g], zf, n, 7, 7, cout=cout, act=ACT_RELU)
+            assert (oh, ow) == KGEO[g]
+            out.append(y)
+        return out
+
+    def groupdw(self, xs, zs, out, wsm, S, x_rep, oh, ow, x_co, z_cs):
+        d = hip.groupdw_desc([t.data_ptr() for t in xs], [t.data_ptr() for t in zs], out.data_ptr(), wsm,
+                             S=S, x_rep=x_rep, OH=oh, OW=ow, Cc=256, x_cs=[512] * 3, x_co=[x_co] * 3,
+                             z_cs=[z_cs] * 3, z_co=[x_co if z_cs == 512 else 0] * 3)
+        hip.check(hip.lib().usot_plan_add_groupdw(self.plan.h, C.byref(d)), 'plan_add_groupdw')
+        self.plan.keep += list(xs) + list(zs) + [out]
+
+    # ---- a9: heads.  xf NHWC [b,hf,hf,256]; zk: 3 maps [b,hk,wk,512]; mem_nhwc [b*m,7,7,256] or None
+    def heads(self, xf, b, hf, zk, mem_nhwc, m):
+        W, L = self.W, hip.lib()
+        es = []
+        for g in range(3):
+            y, oh, ow = self.conv('enc_s%d' % g, W.enc_s[g], xf, b, hf, hf, act=ACT_RELU)
+            es.append(y)
+        S = hf - 6                                    # response size (25 for 31, 27 for 33)
+        ngroups = 3 if mem_nhwc is not None else 2
+        tin = self.buf(ngroups, b, S, S, 256)         # tower inputs: [reg, cls, (memory)]
+        self.groupdw(es, zk, tin[0], W.reg_wsm, b, 1, S, S, 256, 512)
+        self.groupdw(es, zk, tin[1], W.cls_wsm, b, 1, S, S, 0, 512)
+        if mem_nhwc is not None:
+            mk = self.encode_kernel(mem_nhwc, b * m, 256, 'mem')
+            dwm = self.buf(b * m, S, S, 256)
+            self.groupdw(es, mk, dwm, W.cls_wsm, b * m, m, S, S, 0, 256)
+            cv, _, _ = self.conv('conf_fusion', W.conf, dwm, b * m, S, S, act=ACT_CONF, act2=ACT_RELU, act_split=256)
+            hip.check(L.usot_plan_add_conf_reduce(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256),
+                      'plan_add_conf_reduce')
+        cur = tin
+        gs = b * S * S * 256
+        for i in range(4):
+            nxt = self.buf(ngroups, b, S, S, 256)
+            self.conv('tower%d' % i, W.tower[i], cur, b, S, S, cout=256, act=ACT_RELU, y=nxt, groups=ngroups,
+                      x_gs=gs, y_gs=gs)
+            cur = nxt
+        bbox = self.buf(b, 4, S, S)
+        self.conv('bbox_pred', W.bbox_pred, cur[0], b, S, S, act=ACT_EXP, y=bbox, y_nchw=True)
+        ncls = ngroups - 1
+        cls2 = self.buf(ncls, b, 1, S, S)             # [cls, (cls_mem)]
+        self.conv('cls_preds', W.cls_preds, cur[1], b, S, S, cout=1, y=cls2, y_nchw=True, groups=ncls,
+                  x_gs=gs, y_gs=b * S * S, w_rows=1)
+        return bbox, cls2, S
+
+
+def _as_dev_f32(t, device):
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t))
+    return t.to(device=device, dtype=torch.float32)
+
+
+class Engine:
+    """Per-model, per-device executor with cached plans.  Stateless w.r.t. tracking."""
+
+    def __init__(self, model, device, graphs=True, tuning=None):
+        if torch.device(device).type != 'cuda':
+            raise hip.HipError('the USOT HIP engine needs a GPU device; got %s (no CPU fallback)' % (device,))
+        hip.lib()
+        self.device = torch.device(device)
+        self.W = Weights(model, self.device)
+        self.graphs = graphs
+        self.tuning = tuning or {}
+        self._feat = {}       # (n, size) -> dict(x, xf, h, plan)
+        self._zenc = {}       # n -> dict(zf, zk, plan)
+        self._track = {}      # (b, size, m) -> dict
+        self._zk_key = None
+
+    # ------------------------------------------------------------------ features
+    def _feat_plan(self, n, size):
+        key = (n, size)
+        if key not in self._feat:
+            bld = Builder(self.W, self.tuning)
+            x = bld.buf(n, 3, size, size)
+            xf, h = bld.backbone(x, n, size)
+            self._finish(bld.plan)
+            self._feat[key] = dict(x=x, xf=xf, h=h, plan=bld.plan, log=bld.log, stages=bld.stages)
+        return self._feat[key]
+
+    def _finish(self, plan):
+        if self.graphs:
+            plan.run()                       # warm: module load, first-touch
+            torch.cuda.current_stream().synchronize()
+            plan.capture()
+
+    def features(self, x):
+        """x NCHW [n,3,s,s] -> xf as an NCHW-shaped view of the NHWC result [n,256,hf,hf].
+        The view aliases engine workspace: valid until the next call at this (n, s)."""
+        x = _as_dev_f32(x, self.device)
+        n, c, s, s2 = x.shape
+        assert c == 3 and s == s2
+        p = self._feat_plan(n, s)
+        p['x'].copy_(x)
+        p['plan'].run()
+        return p['xf'].permute(0, 3, 1, 2)
+
+    # ------------------------------------------------------------------ template side
+    def encode_template(self, zf_nchw):
+        """zf NCHW-shaped [n,256,7,7] (any strides) -> cached merged cls|reg kernel maps."""
+        n = zf_nchw.shape[0]
+        if n not in self._zenc:
+            bld = Builder(self.W, self.tuning)
+            zf = bld.buf(n, 7, 7, 256)
+            zk = bld.encode_kernel(zf, n, 512, 'z')
+            self._finish(bld.plan)
+            self._zenc[n] = dict(zf=zf, zk=zk, plan=bld.plan)
+        e = self._zenc[n]
+        src = hip.to_nhwc(zf_nchw)
+        if src.data_ptr() != e['zf'].data_ptr():
+            e['zf'].copy_(src)
+        e['plan'].run()
+        return e
+
+    def template(self, z, bbox=None, pr_pool=True):
+        """models.py:173-177.  Returns zf NCHW-shaped [n,256,7,7] (channels-last memory)."""
+        xf = self.features(z)                              # [n,256,15,15] view
+        n = xf.shape[0]
+        if pr_pool:
+            if bbox is None:
+                raise hip.HipError('template(pr_pool=True) needs template_bbox')
+            rois = self._rois(bbox, n)
+            zf = hip.prroi_pool(xf, rois, 7, 7, 1.0, out_nhwc=True)
+        else:
+            zf = hip.to_nhwc(xf[:, :, 4:-4, 4:-4]).permute(0, 3, 1, 2)      # connect.py:303-306
+        self.set_template(zf)
+        return zf
+
+    def set_template(self, zf):
+        e = self.encode_template(zf)
+        self._zk_key = (zf.data_ptr(), zf._version, tuple(zf.shape))
+        return e
+
+    def _rois(self, boxes, n):
+        boxes = _as_dev_f32(boxes, self.device).reshape(n, 4)
+        idx = torch.arange(n, device=self.device, dtype=torch.float32).reshape(n, 1)
+        return torch.cat([idx, boxes], 1).contiguous()
+
+    # ------------------------------------------------------------------ search side
+    def _track_plan(self, b, size, m):
+        key = (b, size, m)
+        if key not in self._track:
+            bld = Builder(self.W, self.tuning)
+            x = bld.buf(b, 3, size, size)
+            xf, hf = bld.backbone(x, b, size)
+            zk = self._zenc[b]['zk']
+            mem = bld.buf(b * m, 7, 7, 256) if m else None
+            bbox, cls2, S = bld.heads(xf, b, hf, zk, mem, m)
+            self._finish(bld.plan)
+            self._track[key] = dict(x=x, xf=xf, hf=hf, mem=mem, bbox=bbox, cls2=cls2, S=S, plan=bld.plan,
+                                    log=bld.log)
+        return self._track[key]
+
+    def track(self, x, zf, template_mem=None, score_mem=None, clone=True):
+        """models.py:179-198 -> (cls, bbox, cls_mem, xf) / (cls, bbox, None, None)."""
+        x = _as_dev_f32(x, self.device)
+        b, _, size, _ = x.shape
+        if zf is None:
+            raise hip.HipError('track() before template()')
+        if self._zk_key != (zf.data_ptr(), zf._version, tuple(zf.shape)) or b not in self._zenc:
+            self.set_template(zf)
+        m = 0
+        if template_mem is not None:
+            m = int(score_mem.shape[1]) if score_mem is not None else template_mem.shape[0] // b
+            if template_mem.shape[0] != b * m:
+                raise hip.HipError('template_mem has %d kernels, expected %d x %d' % (template_mem.shape[0], b, m))
+        p = self._track_plan(b, size, m)
+        p['x'].copy_(x)
+        if m:
+            tm = _as_dev_f32(template_mem, self.device)
+            src = hip.to_nhwc(tm)
+            if src.data_ptr() != p['mem'].data_ptr():
+                p['mem'].copy_(src)
+        p['plan'].run()
+        cls = p['cls2'][0]
+        bbox = p['bbox']
+        if clone:
+            cls, bbox = cls.clone(), bbox.clone()
+        if not m:
+            return cls, bbox, None, None
+        cls_mem = p['cls2'][1].clone() if clone else p['cls2'][1]
+        return cls, bbox, cls_mem, p['xf'].permute(0, 3, 1, 2)
+
+    def pool(self, xf, boxes):
+        """models.py:164-171: PrRoIPool 7x7, scale 1, batch index prepended -> NCHW dense."""
+        xf = _as_dev_f32(xf, self.device)
+        return hip.prroi_pool(xf, self._rois(boxes, xf.shape[0]), 7, 7, 1.0)

@@ -1,0 +1,299 @@
+"""ctypes binding of libusot_hip.so (the C ABI declared in include/usot_hip.h).
+
+There is no fallback: if the shared library is missing or an entry point fails, the call
+raises.  torch is used only for device memory and the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libusot_hip.so')
+
+ACT_NONE, ACT_RELU, ACT_EXP, ACT_CONF = 0, 1, 2, 3
+
+EXPORTS = (
+    'usot_abi_version', 'usot_strerror', 'usot_conv2d_f32', 'usot_conv_tile_count',
+    'usot_conv_tile_info', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
+    'usot_xcorr_depthwise_f32', 'usot_groupdw_f32', 'usot_conf_fusion_reduce_f32',
+    'usot_prroi_pool_forward_f32', 'usot_permute4_f32', 'usot_decode_f32',
+    'usot_plan_create', 'usot_plan_destroy', 'usot_plan_add_conv', 'usot_plan_add_stem',
+    'usot_plan_add_maxpool', 'usot_plan_add_groupdw', 'usot_plan_add_conf_reduce',
+    'usot_plan_add_prroi', 'usot_plan_add_permute', 'usot_plan_add_decode', 'usot_plan_run',
+    'usot_plan_fork', 'usot_plan_join', 'usot_plan_capture', 'usot_plan_size',
+)
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('bias', C.c_void_p), ('res', C.c_void_p),
+                ('y', C.c_void_p), ('ws', C.c_void_p),
+                ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('Cin', C.c_int32),
+                ('OH', C.c_int32), ('OW', C.c_int32), ('Cout', C.c_int32),
+                ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32),
+                ('pad_h', C.c_int32), ('pad_w', C.c_int32), ('dil_h', C.c_int32), ('dil_w', C.c_int32),
+                ('y_cstride', C.c_int32), ('y_coff', C.c_int32), ('res_cstride', C.c_int32),
+                ('res_coff', C.c_int32), ('y_nchw', C.c_int32),
+                ('act', C.c_int32), ('act2', C.c_int32), ('act_split', C.c_int32),
+                ('groups', C.c_int32),
+                ('x_gs', C.c_int64), ('w_gs', C.c_int64), ('b_gs', C.c_int64), ('y_gs', C.c_int64),
+                ('r_gs', C.c_int64),
+                ('ksplit', C.c_int32), ('tile', C.c_int32)]
+
+
+class GroupDWDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p * 3), ('z', C.c_void_p * 3), ('out', C.c_void_p),
+                ('hk', C.c_int32 * 3), ('wk', C.c_int32 * 3),
+                ('x_cs', C.c_int32 * 3), ('x_co', C.c_int32 * 3),
+                ('z_cs', C.c_int32 * 3), ('z_co', C.c_int32 * 3),
+                ('wsm', C.c_float * 3),
+                ('S', C.c_int32), ('x_rep', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
+                ('C', C.c_int32), ('cols_per_thread', C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises HipError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError('%s is missing: run `python -m usot_amd.build` (hipcc, gfx950). '
+                           'There is no CPU fallback for the tracking forward pass.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.usot_strerror.restype = C.c_char_p
+        L.usot_strerror.argtypes = [C.c_int]
+        L.usot_conv_ws_floats.restype = C.c_int64
+        L.usot_plan_create.restype = C.c_void_p
+        L.usot_plan_destroy.argtypes = [C.c_void_p]
+        for name in ('usot_plan_add_conv', 'usot_plan_add_groupdw'):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+        L.usot_plan_add_stem.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int] * 5
+        L.usot_plan_add_maxpool.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 6
+        L.usot_plan_add_conf_reduce.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 4
+        L.usot_plan_add_prroi.argtypes = ([C.c_void_p] + [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float]
+                                          + [C.c_int64] * 8)
+        L.usot_plan_add_permute.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_int64] * 4
+        L.usot_plan_add_decode.argtypes = ([C.c_void_p] + [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_float]
+                                           + [C.c_double] * 2 + [C.c_void_p])
+        L.usot_plan_fork.argtypes = [C.c_void_p, C.c_int]
+        L.usot_plan_join.argtypes = [C.c_void_p, C.c_int]
+        L.usot_plan_run.argtypes = [C.c_void_p, C.c_void_p]
+        L.usot_plan_capture.argtypes = [C.c_void_p, C.c_void_p]
+        L.usot_plan_size.argtypes = [C.c_void_p]
+        L.usot_conv2d_f32.argtypes = [C.c_void_p, C.c_void_p]
+        L.usot_groupdw_f32.argtypes = [C.c_void_p, C.c_void_p]
+        L.usot_stem_conv_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5
+        L.usot_maxpool3x3s2_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6
+        L.usot_xcorr_depthwise_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5
+        L.usot_conf_fusion_reduce_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4
+        L.usot_prroi_pool_forward_f32.argtypes = ([C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_float]
+                                                  + [C.c_int64] * 8)
+        L.usot_permute4_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_int64] * 4
+        L.usot_decode_f32.argtypes = ([C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_float]
+                                      + [C.c_double] * 4)
+        L.usot_conv_tile_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def check(code, what=''):
+    if code != 0:
+        raise HipError('%s failed: %s (%d)' % (what or 'usot call', lib().usot_strerror(code).decode(), code))
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype=torch.float32):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise HipError('expected a device tensor (the HIP path has no CPU implementation)')
+    if t.dtype != dtype:
+        raise HipError('expected %s, got %s' % (dtype, t.dtype))
+    return t
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def tile_table():
+    L = lib()
+    out = {}
+    for i in range(1, L.usot_conv_tile_count() + 1):
+        bm, bn = C.c_int(), C.c_int()
+        L.usot_conv_tile_info(i, C.byref(bm), C.byref(bn))
+        out[i] = (bm.value, bn.value)
+    return out
+
+
+# ------------------------------------------------------------------ tensor-level wrappers
+
+def conv_desc(x, w, bias, y, *, N, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, pad=(0, 0), dil=(1, 1),
+              res=None, act=ACT_NONE, act2=ACT_NONE, act_split=0, y_cstride=0, y_coff=0,
+              res_cstride=0, res_coff=0, y_nchw=0, groups=1, x_gs=0, w_gs=0, b_gs=0, y_gs=0, r_gs=0,
+              ksplit=1, tile=0, ws=None):
+    d = ConvDesc()
+    d.x, d.w, d.bias, d.res, d.y, d.ws = (x, w, bias or None, res or None, y, ws or None)
+    d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout = N, H, W, Cin, OH, OW, Cout
+    d.KH, d.KW, d.stride = KH, KW, stride
+    d.pad_h, d.pad_w, d.dil_h, d.dil_w = pad[0], pad[1], dil[0], dil[1]
+    d.y_cstride, d.y_coff, d.res_cstride, d.res_coff, d.y_nchw = y_cstride, y_coff, res_cstride, res_coff, y_nchw
+    d.act, d.act2, d.act_split = act, act2, act_split
+    d.groups = groups
+    d.x_gs, d.w_gs, d.b_gs, d.y_gs, d.r_gs = x_gs, w_gs, b_gs, y_gs, r_gs
+    d.ksplit, d.tile = ksplit, tile
+    return d
+
+
+def conv2d(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, act=ACT_NONE,
+           tile=0, ksplit=1, y_nchw=False):
+    """x NHWC [N,H,W,Cin] dense, w packed [Cout, KH*KW*Cin] -> y NHWC [N,OH,OW,Cout]."""
+    _dev(x), _dev(w)
+    N, H, W_, Cin = x.shape
+    Cout = w.shape[0]
+    OH = (H + 2 * pad[0] - dil[0] * (KH - 1) - 1) // stride + 1
+    OW = (W_ + 2 * pad[1] - dil[1] * (KW - 1) - 1) // stride + 1
+    shape = (N, Cout, OH, OW) if y_nchw else (N, OH, OW, Cout)
+    y = torch.empty(shape, device=x.device, dtype=torch.float32)
+    ws = None
+    if ksplit > 1:
+        ws = torch.empty(ksplit * N * OH * OW * Cout, device=x.device, dtype=torch.float32)
+    d = conv_desc(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                  N=N, H=H, W=W_, Cin=Cin, OH=OH, OW=OW, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad,
+                  dil=dil, res=res.data_ptr() if res is not None else None, act=act, tile=tile,
+                  ksplit=ksplit, ws=ws.data_ptr() if ws is not None else None, y_nchw=int(y_nchw))
+    check(lib().usot_conv2d_f32(stream(), C.byref(d)), 'usot_conv2d_f32')
+    return y
+
+
+def stem_conv(x, w, bias):
+    _dev(x), _dev(w), _dev(bias)
+    N, c, H, W_ = x.shape
+    assert c == 3 and x.is_contiguous()
+    OH, OW = (H - 7) // 2 + 1, (W_ - 7) // 2 + 1
+    y = torch.empty((N, OH, OW, 64), device=x.device, dtype=torch.float32)
+    check(lib().usot_stem_conv_f32(stream(), ptr(x), ptr(w), ptr(bias), ptr(y), N, H, W_, OH, OW), 'usot_stem_conv_f32')
+    return y
+
+
+def maxpool3x3s2(x):
+    _dev(x)
+    N, H, W_, c = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W_ - 1) // 2 + 1
+    y = torch.empty((N, OH, OW, c), device=x.device, dtype=torch.float32)
+    check(lib().usot_maxpool3x3s2_f32(stream(), ptr(x), ptr(y), N, H, W_, c, OH, OW), 'usot_maxpool3x3s2_f32')
+    return y
+
+
+def xcorr_depthwise(x, kernel):
+    """Drop-in for reference connect.py:147-157 on NCHW device tensors."""
+    _dev(x), _dev(kernel)
+    b, c, hk, wk = kernel.shape
+    hx, wx = x.shape[2], x.shape[3]
+    x = x.contiguous().view(-1, hx, wx)
+    k = kernel.contiguous().view(-1, hk, wk)
+    if x.shape[0] != k.shape[0]:
+        raise HipError('xcorr_depthwise: plane counts differ (%d vs %d)' % (x.shape[0], k.shape[0]))
+    out = torch.empty((b, c, hx - hk + 1, wx - wk + 1), device=x.device, dtype=torch.float32)
+    check(lib().usot_xcorr_depthwise_f32(stream(), ptr(x), ptr(k), ptr(out), b * c, hx, wx, hk, wk),
+          'usot_xcorr_depthwise_f32')
+    return out
+
+
+def groupdw_desc(xs, zs, out, wsm, *, S, x_rep, OH, OW, Cc, x_cs, x_co, z_cs, z_co, cols=0):
+    d = GroupDWDesc()
+    geo = ((5, 5), (3, 5), (5, 3))
+    for b in range(3):
+        d.x[b], d.z[b] = xs[b], zs[b]
+        d.hk[b], d.wk[b] = geo[b]
+        d.x_cs[b], d.x_co[b], d.z_cs[b], d.z_co[b] = x_cs[b], x_co[b], z_cs[b], z_co[b]
+        d.wsm[b] = float(wsm[b])
+    d.out = out
+    d.S, d.x_rep, d.OH, d.OW, d.C, d.cols_per_thread = S, x_rep, OH, OW, Cc, cols
+    return d
+
+
+def groupdw(xs, zs, wsm, x_rep=1, cols=0):
+    """xs: 3 NHWC search maps [XS,h,w,C]; zs: 3 NHWC templates [S,hk,wk,C] -> [S,OH,OW,C]."""
+    S, Cc = zs[0].shape[0], zs[0].shape[3]
+    OH, OW = xs[0].shape[1] - 4, xs[0].shape[2] - 4
+    for t in list(xs) + list(zs):
+        _dev(t)
+        assert t.is_contiguous()
+    out = torch.empty((S, OH, OW, Cc), device=xs[0].device, dtype=torch.float32)
+    d = groupdw_desc([t.data_ptr() for t in xs], [t.data_ptr() for t in zs], out.data_ptr(), wsm,
+                     S=S, x_rep=x_rep, OH=OH, OW=OW, Cc=Cc, x_cs=[Cc] * 3, x_co=[0] * 3,
+                     z_cs=[Cc] * 3, z_co=[0] * 3, cols=cols)
+    check(lib().usot_groupdw_f32(stream(), C.byref(d)), 'usot_groupdw_f32')
+    return out
+
+
+def conf_fusion_reduce(cv, B, M):
+    _dev(cv)
+    P, C2 = cv.shape[1] * cv.shape[2], cv.shape[3]
+    out = torch.empty((B, cv.shape[1], cv.shape[2], C2 // 2), device=cv.device, dtype=torch.float32)
+    check(lib().usot_conf_fusion_reduce_f32(stream(), ptr(cv), ptr(out), B, M, P, C2 // 2),
+          'usot_conf_fusion_reduce_f32')
+    return out
+
+
+def prroi_pool(features, rois, ph=7, pw=7, scale=1.0, out_nhwc=False):
+    """features: NCHW-shaped tensor with ANY strides (dense NCHW or channels_last view);
+    rois [R,5] device float32.  Returns NCHW-shaped [R,C,ph,pw] (channels_last strides when
+    out_nhwc)."""
+    _dev(features), _dev(rois)
+    B, Cc, H, W_ = features.shape
+    R = rois.shape[0]
+    rois = rois.contiguous()
+    if out_nhwc:
+        buf = torch.zeros((R, ph, pw, Cc), device=features.device, dtype=torch.float32)
+        out = buf.permute(0, 3, 1, 2)
+    else:
+        out = torch.zeros((R, Cc, ph, pw), device=features.device, dtype=torch.float32)
+    fs, os_ = features.stride(), out.stride()
+    check(lib().usot_prroi_pool_forward_f32(stream(), ptr(features), ptr(rois), ptr(out), R, Cc, H, W_, ph, pw,
+                                            float(scale), fs[0], fs[1], fs[2], fs[3],
+                                            os_[0], os_[1], os_[2], os_[3]), 'usot_prroi_pool_forward_f32')
+    return out
+
+
+def to_nhwc(t):
+    """NCHW-shaped tensor (any strides) -> dense NHWC buffer [N,H,W,C] via the permute kernel."""
+    _dev(t)
+    N, Cc, H, W_ = t.shape
+    s = t.stride()
+    if s[1] == 1 and s[3] == Cc and s[2] == W_ * Cc and s[0] == H * W_ * Cc:
+        return t.permute(0, 2, 3, 1)            # already channels-last in memory
+    out = torch.empty((N, H, W_, Cc), device=t.device, dtype=torch.float32)
+    check(lib().usot_permute4_f32(stream(), ptr(t), ptr(out), N, H, W_, Cc, s[0], s[2], s[3], s[1]),
+          'usot_permute4_f32')
+    return out
+
+
+def to_nchw(t_nhwc):
+    """Dense NHWC buffer -> dense NCHW tensor via the permute kernel."""
+    _dev(t_nhwc)
+    N, H, W_, Cc = t_nhwc.shape
+    s = t_nhwc.stride()
+    out = torch.empty((N, Cc, H, W_), device=t_nhwc.device, dtype=torch.float32)
+    check(lib().usot_permute4_f32(stream(), ptr(t_nhwc), ptr(out), N, Cc, H, W_, s[0], s[3], s[1], s[2]),
+          'usot_permute4_f32')
+    return out
+
+
+def decode(cls, cls_mem, bbox, window, S, instance_size, stride, ratio, penalty_k, window_influence, tw, th,
+           out=None):
+    _dev(cls), _dev(cls_mem), _dev(bbox), _dev(window, torch.float64)
+    if out is None:
+        out = torch.empty(8, device=cls.device, dtype=torch.float64)
+    check(lib().usot_decode_f32(stream(), ptr(cls), ptr(cls_mem), ptr(bbox), ptr(window), ptr(out), S,
+                                instance_size, stride, float(ratio), float(penalty_k),
+                                float(window_influence), float(tw), float(th)), 'usot_decode_f32')
+    return out

@@ -42,14 +42,23 @@ def make_param(name, shape, seed=0):
     if name.endswith('connect_model.bias'):              # exp(.) of ~3.4 -> boxes of ~30 px
         return (3.4 + 0.25 * g.standard_normal(shape)).astype(np.float32)
     if name.endswith('bbox_pred.weight'):                # x adjust(0.1): log-box spread ~0.5
-        return (g.standard_normal(shape) * 5.0 * np.sqrt(2.0 / (shape[1] * 9))).astype(np.float32)
+        w = g.standard_normal(shape) * 5.0 * np.sqrt(2.0 / (shape[1] * 9))
+        return (w - w.mean(axis=(1, 2, 3), keepdims=True)).astype(np.float32)
     if name.endswith('cls_pred.weight') or name.endswith('cls_memory_pred.weight'):
-        return (g.standard_normal(shape) * 20.0 * np.sqrt(2.0 / (shape[1] * 9))).astype(np.float32)
+        w = g.standard_normal(shape) * 20.0 * np.sqrt(2.0 / (shape[1] * 9))
+        return (w - w.mean(axis=(1, 2, 3), keepdims=True)).astype(np.float32)
     if name.endswith('_dw.weight'):                      # GroupDW branch logits
         return (0.5 * g.standard_normal(shape)).astype(np.float32)
     if len(shape) == 4:                                  # conv weight OIHW
         fan_in = shape[1] * shape[2] * shape[3]
-        return (g.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        w = g.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+        # zero-DC filters: post-ReLU inputs have mean ~ std, and a filter that passes that
+        # DC level makes the following BN subtract two large numbers (fp32 noise x10 per
+        # stage, every implementation alike).  Trained filters are near zero-mean too.
+        w -= w.mean(axis=(1, 2, 3), keepdims=True)
+        return w.astype(np.float32)
+    if name.endswith('.bn3.weight'):                     # small last-BN gain per bottleneck,
+        return g.uniform(0.08, 0.2, shape).astype(np.float32)    # cf. zero-init-residual
     if leaf == 'weight':                                 # BN gamma
         return g.uniform(0.6, 1.4, shape).astype(np.float32)
     if leaf == 'bias':                                   # BN beta or conv bias
