@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tracker FPS (255x255 search, ResNet-50) on N MI355X.
+
+A "step" is one tracked frame per rank: gather the N_q = 7 memory kernels, ResNet-50
+(layer3) backbone + neck over a resident 255x255 fp32 crop, cls/reg/memory heads with the
+fused depthwise xcorr, on-device decode, PrRoIPool of the new memory feature — the whole
+per-frame device path of `USOTTracker.track`, replayed as one hipGraph, with the 64-byte
+result read back to the host (the tracking loop is sequential per stream, so that sync is
+part of a frame).  Workload = BASELINE.json configs[1] (batch 1, fp32, one stream per GPU).
+Weights are synthetic (no checkpoint ships with the reference), broadcast once from rank 0
+over RCCL; streams are independent, so N GPUs = N streams, no data-path collective
+("scaling": "weak").
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the fp32-MFMA implicit-GEMM
+convolution, per-launch time from HIP events on the launching stream) and `cpu_baseline`
+(the CPU oracle restatement of the same frame, timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from usot_amd import hip, streams, synth  # noqa: E402
+from usot_amd.model import USOT  # noqa: E402
+from usot_amd.tracker import USOTConfig, select_memory  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+HBM_PEAK_GBPS = 8000.0
+GROUPDW_BYTES_PER_SAMPLE = 3161088   # x 2 464 768 + k 56 320 + out 640 000
+
+
+def build_model(rank, world, device):
+    m = USOT()
+    if rank == 0:
+        m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True), strict=True)
+    m.eval()
+    m = m.to(device)
+    nbytes = streams.broadcast_weights(m, src=0, device=device)
+    return m, nbytes
+
+
+def open_stream(model, device, seed, size=255):
+    """Template + memory seeds for one synthetic video stream; returns (session, crops)."""
+    p = USOTConfig()
+    p.instance_size = size
+    p.renew()
+    p.sf_size = p.score_size
+    t = lambda a: torch.from_numpy(a).to(device)
+    model.pr_pool = True
+    model.template(t(synth.crop(1000 + seed, 1, 127)), template_bbox=torch.tensor([[3.5, 3.5, 10.5, 10.5]], device=device))
+    crops = t(synth.crop(2000 + seed, 8, size))
+    roi = torch.tensor([[9.0, 9.0, 16.0, 16.0]], device=device)
+    feats = [model.extract_memory_feature(ori_x=crops[0:1], search_bbox=roi),
+             model.extract_memory_feature(ori_x=crops[0:1].flip(3), search_bbox=roi)]
+    window = np.outer(np.hanning(p.score_size), np.hanning(p.score_size))
+    return model.engine.open_session(p, window, feats), crops, p
+
+
+def run_frames(sess, crops, p, conf, n):
+    for i in range(n):
+        picks = select_memory(conf, p.mem_queue_size)
+        out = sess.frame(crops[i % crops.shape[0]], picks, (63.5, 63.5))
+        conf.append(float(out[1]))
+
+
+def roofline(sess, frames):
+    """Dominant kernel = the conv_igemm_f32 tile instance with the largest total time."""
+    prof = sess.plan.profile(frames=frames, reps=2)
+    tiles = hip.tile_table()
+    convs = iter(sess.log)
+    agg, total_ms, conv_ms, conv_flops = {}, 0.0, 0.0, 0.0
+    for kind, tile, ks, groups, ms in prof:
+        total_ms += ms
+        if kind != 0:
+            continue
+        name, M, N, K, g, macs = next(convs)
+        a = agg.setdefault(tile, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += ms
+        a[2] += 2.0 * macs
+        conv_ms += ms
+        conv_flops += 2.0 * macs
+    tile, (n, ms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
+    ach = fl / (ms * 1e-3) / 1e12
+    return {
+        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+        'kernel': 'conv_igemm_f32<%d,%d>' % tiles[tile], 'launches_per_frame': n,
+        'avg_launch_us': round(ms / n * 1e3, 2), 'algorithmic_gflop_per_frame': round(fl / 1e9, 3),
+        'all_convs': {'gflop_per_frame': round(conv_flops / 1e9, 3), 'us_per_frame': round(conv_ms * 1e3, 1),
+                      'tflops': round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
+                      'frac': round(conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
+        'frame_op_spans_us': round(total_ms * 1e3, 1),
+    }
+
+
+def xcorr_bandwidth(device, samples=128, iters=20):
+    """Fused GroupDW at a size beyond the 256 MiB Infinity Cache: achieved GB/s on the
+    ALGORITHMIC bytes of SURVEY §8(d) (3 161 088 B per sample), HIP events on the stream."""
+    g = torch.Generator(device='cpu').manual_seed(7)
+    geo = ((5, 5), (3, 5), (5, 3))
+    xs = [torch.randn(samples, 25 + hk - 1, 25 + wk - 1, 256, generator=g).to(device) for hk, wk in geo]
+    zs = [torch.randn(samples, hk, wk, 256, generator=g).to(device) for hk, wk in geo]
+    w = np.array([0.3, 0.3, 0.4], np.float32)
+    for _ in range(3):
+        hip.groupdw(xs, zs, w)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        hip.groupdw(xs, zs, w)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    gbps = samples * GROUPDW_BYTES_PER_SAMPLE / (ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernel': 'groupdw_nhwc_kernel', 'samples': samples, 'ms': round(ms, 4),
+            'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle's restatement of one tracked frame (models.py:179-198 + PrPool) on the host."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import usot_oracle as orc
+    m = USOT()
+    sd = synth.torch_state_dict(m, seed=0, calibrated=True)
+    t = torch.from_numpy
+    z, x = t(synth.crop(1000, 1, 127)), t(synth.crop(2000, 1, 255))
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        zf = orc.template(sd, z, torch.tensor([[3.5, 3.5, 10.5, 10.5]]), pr_pool=True)
+        mem = torch.cat([zf] * 7, 0)
+        frame = lambda: orc.prpool_feature(orc.track(sd, x, zf, mem, torch.ones(1, 7))[3], torch.tensor([[9.0, 9.0, 16.0, 16.0]]))
+        for _ in range(2):
+            frame()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            frame()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or n >= 200:
+                break
+    return {'value': round(n / dt, 3), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d frames of the same workload (1 crop 255x255, N_q=7, fp32) in %.1f s, torch-CPU oracle' % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--size', type=int, default=255)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-xcorr', action='store_true')
+    a = ap.parse_args()
+
+    rank, local, world = streams.init()
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit('--gpus %d needs: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                             '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (a.gpus, a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    model, wbytes = build_model(rank, world, device)
+    sess, crops, p = open_stream(model, device, seed=rank, size=a.size)
+    conf = [0.9]
+    run_frames(sess, crops, p, conf, a.warmup)
+
+    streams.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_frames(sess, crops, p, conf, a.steps)
+    torch.cuda.synchronize()
+    streams.barrier()
+    dt = streams.max_over_ranks(time.perf_counter() - t0, device=device)
+
+    if rank == 0:
+        fps = world * a.steps / dt
+        line = {
+            'metric': 'tracker FPS (255x255 search, ResNet-50)', 'value': round(fps, 2), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: batch=1 ResNet-50(layer3)+neck, fused depthwise xcorr, cls/reg/'
+                                   'memory heads (N_q=7), decode + PrRoIPool, fp32, 1 stream per GPU',
+                       'search': a.size, 'template': 127, 'streams': world, 'weights': 'synthetic seed 0 '
+                       '(calibrated BN), RCCL broadcast %d B' % wbytes, 'hipgraph': True},
+        }
+        line['roofline'] = roofline(sess, frames=10)
+        if not a.no_xcorr:
+            line['xcorr_hbm'] = xcorr_bandwidth(device)
+        if world == 1 and not a.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line))
+    streams.barrier()
+
+
+if __name__ == '__main__':
+    main()

@@ -150,6 +150,13 @@ int usot_decode_dev_f32(void *stream, const float *cls, const float *cls_mem, co
                         float ratio, double penalty_k, double window_influence,
                         const double *tsz_dev, float *roi_out);
 
+/* ---- row gather (scatter = 0: dst[i] = src[idx[i]]) / scatter (dst[idx[i]] = src[i]) of
+ * `n_rows` rows of `row_len` floats with indices read from DEVICE memory: selects the
+ * memory-queue kernels of a frame (usot_tracker.py:222-256) and appends the new one
+ * (:264) inside a captured graph.                                                        */
+int usot_rows_copy_f32(void *stream, const float *src, const int32_t *idx_dev, float *dst,
+                       int n_rows, int row_len, int scatter);
+
 /* ---- launch plans: record the per-frame kernel sequence once, replay it natively, or
  * capture it into a hipGraph (one hipGraphLaunch per frame).  Pointers are baked at add
  * time, so they must refer to buffers that outlive the plan (the engine's workspace).
@@ -177,10 +184,19 @@ int usot_plan_add_decode(void *plan, const float *cls, const float *cls_mem, con
                          const double *window, double *out, int S, int instance_size, int stride,
                          float ratio, double penalty_k, double window_influence,
                          const double *tsz_dev, float *roi_out);
+int usot_plan_add_rows_copy(void *plan, const float *src, const int32_t *idx_dev, float *dst,
+                            int n_rows, int row_len, int scatter);
 int usot_plan_fork(void *plan, int lane);
 int usot_plan_join(void *plan, int lane);
 int usot_plan_capture(void *plan, void *stream);
 int usot_plan_run(void *plan, void *stream);
+/* per-op mean milliseconds per launch (HIP events on `stream`, eager, program order, each op
+ * launched `reps` times between its two events), blocking */
+int usot_plan_profile(void *plan, void *stream, int frames, int reps, float *ms_per_op);
+/* info[4] = {kind, conv tile id, ksplit, groups} of op i (kind: 0 conv, 1 stem, 2 maxpool,
+ * 3 groupdw, 4 conf_reduce, 5 prroi, 6 permute, 7 decode, 8 fork, 9 join)                */
+int usot_plan_op_info(void *plan, int i, int *info);
+int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 #ifdef __cplusplus
 }

@@ -24,9 +24,12 @@ import numpy as np
 REF = '/root/reference'
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 GOLD = os.path.join(REPO, 'tests', 'golden')
-sys.path.insert(0, REF)           # `lib` must resolve to the reference here
-sys.path.insert(1, REPO)
-sys.path.insert(2, GOLD)
+# `lib` must resolve to the REFERENCE here.  The reference's lib/ has no __init__.py (a
+# namespace package) while this repo's lib/ is a regular package, which would win whatever
+# the path order — so the repo root joins sys.path only after the reference is imported.
+sys.path = [p for p in sys.path if os.path.realpath(p or '.') not in (REPO, os.path.realpath('.'))] \
+    if os.path.realpath('.') == REPO else sys.path
+sys.path.insert(0, REF)
 
 import torch  # noqa: E402
 
@@ -43,6 +46,10 @@ def _no_jit():
 _prf._import_prroi_pooling = _no_jit
 
 import lib.models.models as ref_models  # noqa: E402
+import lib.models.connect  # noqa: E402,F401
+
+sys.path.insert(1, REPO)
+sys.path.insert(2, GOLD)
 from usot_amd import synth  # noqa: E402
 from sampling import summarize  # noqa: E402
 

@@ -1,0 +1,66 @@
+"""CPU: the C-ABI library is built for gfx950 and exports every symbol include/usot_hip.h
+declares; the product path fails loudly without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from usot_amd import build, hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def libpath():
+    return build.build(force=False)
+
+
+def declared_symbols():
+    with open(os.path.join(ROOT, 'include', 'usot_hip.h')) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    return sorted(set(re.findall(r'\b(usot_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    L = ctypes.CDLL(libpath)
+    for s in syms:
+        assert hasattr(L, s), s
+    assert set(hip.EXPORTS) <= set(syms)
+    L.usot_abi_version.restype = ctypes.c_int
+    assert L.usot_abi_version() == 1
+    L.usot_strerror.restype = ctypes.c_char_p
+    assert b'invalid' in L.usot_strerror(-1)
+
+
+def test_code_object_is_gfx950(libpath):
+    with open(libpath, 'rb') as f:
+        blob = f.read()
+    assert b'gfx950' in blob and b'gfx942' not in blob and b'sm_' not in blob
+
+
+def test_no_cpu_fallback():
+    from usot_amd.model import USOT
+    m = USOT()
+    with pytest.raises(hip.HipError):
+        m.template(torch.zeros(1, 3, 127, 127))
+    with pytest.raises(hip.HipError):
+        hip.xcorr_depthwise(torch.zeros(1, 4, 9, 9), torch.zeros(1, 4, 3, 3))
+    with pytest.raises(NotImplementedError):
+        from lib.models.prroi_pool import PrRoIPool2D
+        PrRoIPool2D(7, 7, 1.0)(torch.zeros(1, 4, 9, 9), torch.zeros(1, 5))
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1), torch.zeros(1))
+
+
+def test_product_path_never_imports_the_oracle():
+    pat = re.compile(r'^\s*(from|import)\s+(usot_oracle|oracle)\b', re.M)
+    for d in ('usot_amd', 'lib'):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, d)):
+            for fn in files:
+                if fn.endswith('.py'):
+                    with open(os.path.join(dirpath, fn)) as f:
+                        assert not pat.search(f.read()), os.path.join(dirpath, fn)

@@ -1,0 +1,193 @@
+"""CPU: tracker host logic (grids, box->feature maps, decode, memory selection), crop
+helpers and the module surface, against goldens captured from the reference's own
+lib/tracker/usot_tracker.py (tests/golden/make_golden.py host) and the oracle restatement."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import usot_oracle as orc
+from usot_amd import hostutils
+from usot_amd.tracker import USOTConfig, USOTTracker, select_memory
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+class Info:
+    arch = 'USOT'
+
+
+def cfg(inst):
+    p = USOTConfig()
+    p.instance_size = inst
+    p.renew()
+    p.sf_size = p.score_size
+    return p
+
+
+@pytest.mark.parametrize('inst', [255, 271])
+def test_grids_and_pool_labels(gold_host, inst):
+    p, trk = cfg(inst), USOTTracker(Info())
+    trk.grids(p)
+    tag = 'i%d' % inst
+    assert np.array_equal(trk.grid_to_search_x, gold_host[tag + '/grid_x'])
+    assert np.array_equal(trk.grid_to_search_y, gold_host[tag + '/grid_y'])
+    assert np.array_equal(trk.search_area_x_axis, gold_host[tag + '/search_axis'])
+    boxes = gold_host[tag + '/boxes']
+    got_t = np.stack([trk.pool_label_template(p, b) for b in boxes])
+    got_s = np.stack([trk.pool_label_search(p, b) for b in boxes])
+    np.testing.assert_array_equal(got_t, gold_host[tag + '/pool_template'])
+    np.testing.assert_array_equal(got_s, gold_host[tag + '/pool_search'])
+    # oracle restatement agrees too
+    op = orc.Hyper(inst)
+    np.testing.assert_array_equal(np.stack([orc.pool_label_search(op, b) for b in boxes]), got_s)
+    np.testing.assert_array_equal(np.stack([orc.pool_label_template(op, b) for b in boxes]), got_t)
+
+
+@pytest.mark.parametrize('inst', [255, 271])
+@pytest.mark.parametrize('case', range(4))
+def test_update_decode_vs_reference(gold_host, inst, case):
+    p, trk = cfg(inst), USOTTracker(Info())
+    trk.grids(p)
+    c = 'i%d/decode%d' % (inst, case)
+    t = torch.from_numpy
+    seen = {}
+
+    class Net:
+        def track(self, x, template_mem=None, score_mem=None):
+            return t(gold_host[c + '/cls']), t(gold_host[c + '/bbox']), t(gold_host[c + '/cls_mem']), torch.zeros(1, 4, 31, 31)
+
+        def extract_memory_feature(self, xf=None, search_bbox=None, ori_x=None):
+            seen['box'] = search_bbox.numpy().copy()
+            return torch.zeros(1, 4, 7, 7)
+    S = p.score_size
+    window = np.outer(np.hanning(S), np.hanning(S))
+    tsz, sz = gold_host[c + '/tsz'], float(gold_host[c + '/scale_z'])
+    pos, size, score, _ = trk.update(Net(), None, gold_host[c + '/tpos'].copy(), tsz * sz, window, sz, p)
+    np.testing.assert_allclose(pos, gold_host[c + '/out_pos'], rtol=1e-12)
+    np.testing.assert_allclose(size, gold_host[c + '/out_sz'], rtol=1e-12)
+    assert score == gold_host[c + '/out_score']
+    np.testing.assert_array_equal(seen['box'], gold_host[c + '/out_poolbox'])
+    # the oracle's decode restates the same arithmetic
+    opos, osz, oscore, obox, _ = orc.decode(orc.Hyper(inst), gold_host[c + '/cls'][0, 0], gold_host[c + '/cls_mem'][0, 0],
+                                            gold_host[c + '/bbox'][0], gold_host[c + '/tpos'], tsz * sz, window, sz)
+    np.testing.assert_allclose(opos, gold_host[c + '/out_pos'], rtol=1e-12)
+    np.testing.assert_allclose(osz, gold_host[c + '/out_sz'], rtol=1e-12)
+
+
+def test_memory_selection_vs_reference():
+    with open(os.path.join(GOLD, 'golden_memory_indices.json')) as f:
+        cases = json.load(f)
+    assert set(cases) == {'1', '2', '3', '5', '8', '20', '57', '200'}
+    for n, c in cases.items():
+        picks = select_memory(c['conf'], 7)
+        assert [-1.0, -2.0] + [float(i) for i in picks] == c['tags'], n
+        assert orc.select_memory(orc.Hyper(), c['conf']) == picks
+        want_scores = np.array([0.9, 0.9] + [c['conf'][i] for i in picks], np.float32)
+        np.testing.assert_allclose(want_scores, np.array(c['score'], np.float32), rtol=1e-6)
+
+
+def test_python2round_and_crop_geometry():
+    assert hostutils.python2round(2.5) == 3.0 and hostutils.python2round(3.5) == 4
+    assert hostutils.python2round(254.5) == 255.0 and hostutils.python2round(254.4) == 254
+    im = (np.arange(60 * 80 * 3) % 251).astype(np.uint8).reshape(60, 80, 3)
+    avg = np.mean(im, axis=(0, 1))
+    # inside the image, no resize
+    patch, info = hostutils.get_subwindow_tracking(im, np.array([40.0, 30.0]), 21, 21, avg, out_mode='raw')
+    assert patch.shape == (21, 21, 3) and info['pad_info'][:2] == [0, 0]
+    assert np.array_equal(patch, im[19:40, 29:50])
+    # overlapping the border: mean-colour padding, truncated to uint8 like the reference's assignment
+    patch, info = hostutils.get_subwindow_tracking(im, np.array([2.0, 3.0]), 21, 21, avg, out_mode='raw')
+    top, left = info['pad_info'][:2]
+    assert top > 0 and left > 0
+    assert np.array_equal(patch[0, 0], avg.astype(np.uint8))
+    assert np.array_equal(patch[top:, left:], im[:21 - top, :21 - left])
+    # torch output is CHW float32 with raw 0..255 values
+    tpatch, _ = hostutils.get_subwindow_tracking(im, np.array([40.0, 30.0]), 21, 21, avg)
+    assert tpatch.dtype == torch.float32 and tuple(tpatch.shape) == (3, 21, 21)
+    assert torch.equal(tpatch, torch.from_numpy(im[19:40, 29:50].transpose(2, 0, 1).astype(np.float32)))
+
+
+def test_resize_builtin_properties():
+    g = np.random.default_rng(0)
+    img = g.integers(0, 256, (37, 41, 3), dtype=np.uint8)
+    assert np.array_equal(hostutils.resize_bilinear_u8(img, 41, 37), img)
+    const = np.full((30, 30, 3), 77, np.uint8)
+    assert np.all(hostutils.resize_bilinear_u8(const, 55, 47) == 77)
+    up = hostutils.resize_bilinear_u8(img, 82, 74)
+    assert up.shape == (74, 82, 3) and up.dtype == np.uint8
+    ramp = np.tile(np.arange(64, dtype=np.uint8)[None, :, None] * 4, (8, 1, 3))
+    out = hostutils.resize_bilinear_u8(ramp, 128, 8).astype(int)
+    assert np.all(np.diff(out[0, :, 0]) >= 0)          # monotone ramp stays monotone
+
+
+def test_flip_matches_imgaug_convention():
+    img = np.arange(2 * 5 * 3, dtype=np.uint8).reshape(2, 5, 3)
+    f, box = hostutils.flip_lr(img, [1.0, 0.5, 3.5, 1.5])
+    assert np.array_equal(f, img[:, ::-1]) and box == [1.5, 0.5, 4.0, 1.5]
+
+
+def test_module_surface_of_the_reference():
+    import lib.models.models as models
+    from lib.tracker.usot_tracker import USOTConfig as C2, USOTTracker as T2
+    from lib.utils.train_utils import load_pretrain  # noqa: F401
+    from lib.utils.test_utils import cxy_wh_2_rect, get_axis_aligned_bbox, poly_iou  # noqa: F401
+    from lib.dataset_loader.benchmark import load_dataset  # noqa: F401
+    from lib.utils.track_utils import load_yaml, get_subwindow_tracking, python2round, im_to_torch  # noqa: F401
+    from lib.models.connect import xcorr_depthwise, AdjustLayer, box_tower_reg  # noqa: F401
+    from lib.models.prroi_pool import PrRoIPool2D  # noqa: F401
+    net = models.__dict__['USOT']()
+    assert isinstance(net, torch.nn.Module) and net.pr_pool is True and net.zf is None
+    with open(os.path.join(GOLD, 'state_dict_keys.json')) as f:
+        ref = json.load(f)
+    sd = net.state_dict()
+    assert set(sd) == set(ref) and all(list(sd[k].shape) == ref[k] for k in ref)
+    assert sum(p.numel() for p in net.parameters()) == 29414993
+    assert C2().score_size == 25 and T2 is USOTTracker
+    here = os.path.dirname(os.path.abspath(__file__))
+    hp = load_yaml(os.path.join(here, '..', 'experiments', 'test', 'USOT.yaml'))
+    assert hp == {'penalty_k': 0.021, 'lr': 0.73, 'window_influence': 0.321, 'small_sz': 255, 'big_sz': 271,
+                  'ratio': 0.3, 'mem_queue_size': 7}
+
+
+def test_load_pretrain_prefixes_and_moco(tmp_path):
+    import lib.models.models as models
+    from lib.utils.train_utils import load_pretrain
+    from usot_amd import synth
+    net = models.USOT()
+    sd = synth.torch_state_dict(net, seed=0, calibrated=True)
+    path = str(tmp_path / 'ckpt.pth')
+    torch.save({'state_dict': {'module.' + k: v for k, v in sd.items()}, 'epoch': 3}, path)
+    out = load_pretrain(models.USOT(), path)
+    for k, v in out.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # MoCo-style backbone: encoder_q.* keys, 1x1 shortcuts widened to centred 3x3
+    moco = {}
+    for k, v in sd.items():
+        if k.startswith('features.features.'):
+            kk = k.replace('features.features', 'encoder_q')
+            if kk in ('encoder_q.layer2.0.downsample.0.weight', 'encoder_q.layer3.0.downsample.0.weight'):
+                v = v[:, :, 1:2, 1:2].clone()
+            moco[kk] = v
+    mpath = str(tmp_path / 'moco_v2.pth')
+    torch.save(moco, mpath)
+    out = load_pretrain(models.USOT(), mpath)
+    w = out.state_dict()['features.features.layer2.0.downsample.0.weight']
+    assert torch.equal(w[:, :, 1, 1], sd['features.features.layer2.0.downsample.0.weight'][:, :, 1, 1])
+    assert float(w[:, :, 0, 0].abs().max()) == 0.0
+    with pytest.raises(AssertionError):
+        bad = str(tmp_path / 'bad.pth')
+        torch.save({'nothing': torch.zeros(1)}, bad)
+        load_pretrain(models.USOT(), bad)
+
+
+def test_poly_iou_and_rect_helpers():
+    from lib.utils.test_utils import cxy_wh_2_rect, get_axis_aligned_bbox, poly_iou
+    assert abs(float(poly_iou(np.array([0, 0, 10, 10.]), np.array([5, 5, 10, 10.]))[0]) - 25 / 175) < 1e-12
+    assert abs(float(poly_iou(np.array([5, 0, 10, 5, 5, 10, 0, 5.]), np.array([0, 0, 10, 10.]))[0]) - 0.5) < 1e-12
+    assert float(poly_iou(np.array([0, 0, 1, 1.]), np.array([5, 5, 1, 1.]))[0]) == 0.0
+    assert cxy_wh_2_rect(np.array([10.0, 8.0]), np.array([4.0, 6.0])) == [8.0, 5.0, 4.0, 6.0]
+    cx, cy, w, h = get_axis_aligned_bbox(np.array([2.0, 3.0, 10.0, 20.0]))
+    assert (cx, cy, w, h) == (7.0, 13.0, 10.0, 20.0)

@@ -317,6 +317,13 @@ extern "C" int usot_conv_tile_info(int tile, int *bm, int *bn)
     return USOT_OK;
 }
 
+extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d)
+{
+    if (!d) return USOT_EINVAL;
+    if (d->tile != 0) return d->tile;
+    return pick_tile(d, d->N * d->OH * d->OW);
+}
+
 extern "C" int64_t usot_conv_ws_floats(const usot_conv_desc *d)
 {
     if (!d || d->ksplit <= 1) return 0;

@@ -124,6 +124,20 @@ __global__ __launch_bounds__(256) void permute4_kernel(
     }
 }
 
+// ---- row gather / scatter with DEVICE-resident indices: lets a captured graph pick the
+// memory-queue kernels of a frame (usot_tracker.py:222-256) and append the new one --------
+__global__ __launch_bounds__(256) void rows_copy_kernel(
+    const float *__restrict__ src, const int *__restrict__ idx, float *__restrict__ dst,
+    int n_rows, int row_len4, int scatter)
+{
+    const long total = (long)n_rows * row_len4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / row_len4), e = (int)(i - (long)r * row_len4);
+        const long sr = scatter ? r : idx[r], dr = scatter ? idx[r] : r;
+        ((f32x4 *)dst)[dr * row_len4 + e] = ((const f32x4 *)src)[sr * row_len4 + e];
+    }
+}
+
 // ---- decode (usot_tracker.py:138-163): one workgroup, double precision like the numpy
 // reference (its grids are float64, so everything after the float32 sigmoid promotes) -------
 __global__ __launch_bounds__(256) void decode_kernel(
@@ -282,6 +296,19 @@ extern "C" int usot_decode_dev_f32(void *stream, const float *cls, const float *
     hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cls, cls_mem, bbox,
                        window, out, S, instance_size, stride, ratio, penalty_k, window_influence, 1.0, 1.0,
                        tsz_dev, roi_out);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+extern "C" int usot_rows_copy_f32(void *stream, const float *src, const int32_t *idx_dev, float *dst,
+                                  int n_rows, int row_len, int scatter)
+{
+    if (!src || !idx_dev || !dst || n_rows <= 0 || row_len <= 0 || (row_len & 3)) return USOT_EINVAL;
+    if (((uintptr_t)src % 16) || ((uintptr_t)dst % 16)) return USOT_EINVAL;
+    const long total = (long)n_rows * (row_len / 4);
+    const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(rows_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       src, (const int *)idx_dev, dst, n_rows, row_len / 4, scatter);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }

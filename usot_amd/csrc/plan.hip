@@ -20,9 +20,11 @@ extern "C" int usot_decode_dev_f32(void *stream, const float *cls, const float *
                                    int instance_size, int stride, float ratio, double penalty_k,
                                    double window_influence, const double *tsz_dev, float *roi_out);
 
+extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
+
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -48,15 +50,19 @@ struct Plan {
     bool captured = false;
 };
 
-int issue(Plan *pl, hipStream_t main_stream, bool lanes)
+int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nullptr, int reps = 1)
 {
     hipStream_t st[kLanes];
     st[0] = main_stream;
     for (int k = 1; k < kLanes; ++k) st[k] = lanes ? pl->side[k] : main_stream;
     size_t ev = 0;
+    size_t opi = 0;
     for (const Op &op : pl->ops) {
         hipStream_t s = st[op.lane];
         int rc = USOT_OK;
+        if (marks && hipEventRecord(marks[opi], s) != hipSuccess) return USOT_ELAUNCH;
+        ++opi;
+        for (int rep = 0; rep < reps && rc == USOT_OK; ++rep)
         switch (op.kind) {
         case K_CONV: rc = usot_conv2d_f32(s, &op.conv); break;
         case K_GDW:  rc = usot_groupdw_f32(s, &op.gdw); break;
@@ -86,6 +92,10 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes)
                                      (const double *)op.p[3], (double *)op.p[4], op.i[0], op.i[1], op.i[2],
                                      op.f[0], op.d[0], op.d[1], (const double *)op.p[5], (float *)op.l[0]);
             break;
+        case K_ROWS:
+            rc = usot_rows_copy_f32(s, (const float *)op.p[0], (const int32_t *)op.p[1], (float *)op.p[2],
+                                    op.i[0], op.i[1], op.i[2]);
+            break;
         case K_FORK:      // lane op.lane waits for everything issued so far on lane 0
             if (lanes && op.lane != 0) {
                 if (ev >= pl->events.size()) return USOT_ESTATE;
@@ -105,6 +115,7 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes)
         }
         if (rc != USOT_OK) return rc;
     }
+    if (marks && hipEventRecord(marks[opi], main_stream) != hipSuccess) return USOT_ELAUNCH;
     return USOT_OK;
 }
 
@@ -246,6 +257,16 @@ extern "C" int usot_plan_add_decode(void *plan, const float *cls, const float *c
     return USOT_OK;
 }
 
+extern "C" int usot_plan_add_rows_copy(void *plan, const float *src, const int32_t *idx_dev, float *dst,
+                                       int n_rows, int row_len, int scatter)
+{
+    Op *op = push(plan, K_ROWS);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = src; op->p[1] = idx_dev; op->p[2] = dst;
+    op->i[0] = n_rows; op->i[1] = row_len; op->i[2] = scatter;
+    return USOT_OK;
+}
+
 extern "C" int usot_plan_fork(void *plan, int lane)
 {
     Plan *pl = (Plan *)plan;
@@ -299,4 +320,53 @@ extern "C" int usot_plan_run(void *plan, void *stream)
     hipStream_t s = (hipStream_t)stream;
     if (pl->captured) return hipGraphLaunch(pl->exec, s) == hipSuccess ? USOT_OK : USOT_ELAUNCH;
     return issue(pl, s, false);
+}
+
+/* Per-op timing with HIP events on the launching stream: issues the plan `frames` times in
+ * program order on `stream` (lanes ignored, no graph) with an event before every op, each op
+ * launched `reps` times back to back (amortises the event's own cost), and returns the mean
+ * milliseconds per launch in ms_per_op[usot_plan_size()].
+ * Blocks until done.  Used by bench.py for the roofline object.                           */
+extern "C" int usot_plan_profile(void *plan, void *stream, int frames, int reps, float *ms_per_op)
+{
+    Plan *pl = (Plan *)plan;
+    if (!pl || !ms_per_op || frames < 1 || reps < 1 || pl->ops.empty()) return USOT_EINVAL;
+    const size_t n = pl->ops.size();
+    std::vector<hipEvent_t> marks(n + 1);
+    for (auto &e : marks)
+        if (hipEventCreate(&e) != hipSuccess) return USOT_ENOMEM;
+    std::vector<double> acc(n, 0.0);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = USOT_OK;
+    for (int f = 0; f < frames && rc == USOT_OK; ++f) {
+        rc = issue(pl, s, false, marks.data(), reps);
+        if (rc != USOT_OK) break;
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = USOT_ELAUNCH; break; }
+        for (size_t i = 0; i < n; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, marks[i], marks[i + 1]) != hipSuccess) { rc = USOT_ELAUNCH; break; }
+            acc[i] += ms;
+        }
+    }
+    for (auto &e : marks) (void)hipEventDestroy(e);
+    if (rc == USOT_OK)
+        for (size_t i = 0; i < n; ++i) ms_per_op[i] = (float)(acc[i] / frames / reps);
+    return rc;
+}
+
+/* kind of op i: 0 conv, 1 stem, 2 maxpool, 3 groupdw, 4 conf_reduce, 5 prroi, 6 permute,
+ * 7 decode, 8 fork, 9 join; for convs also the tile the launcher would pick (info[0..3] =
+ * kind, tile, ksplit, groups). */
+extern "C" int usot_plan_op_info(void *plan, int i, int *info)
+{
+    Plan *pl = (Plan *)plan;
+    if (!pl || !info || i < 0 || i >= (int)pl->ops.size()) return USOT_EINVAL;
+    const Op &op = pl->ops[i];
+    info[0] = (int)op.kind; info[1] = 0; info[2] = 1; info[3] = 1;
+    if (op.kind == K_CONV) {
+        info[1] = usot_conv_resolve_tile(&op.conv);
+        info[2] = op.conv.ksplit > 1 ? op.conv.ksplit : 1;
+        info[3] = op.conv.groups;
+    }
+    return USOT_OK;
 }

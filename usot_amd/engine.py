@@ -129,6 +129,19 @@ class Plan:
         torch.cuda.current_stream().wait_stream(s)
         self.captured = True
 
+    def profile(self, frames=10, reps=1):
+        """[(kind, tile, ksplit, groups, ms)] per op, eager, HIP events on the current stream."""
+        L = hip.lib()
+        n = L.usot_plan_size(self.h)
+        ms = (C.c_float * n)()
+        hip.check(L.usot_plan_profile(self.h, hip.stream(), frames, reps, ms), 'usot_plan_profile')
+        out = []
+        for i in range(n):
+            info = (C.c_int * 4)()
+            hip.check(L.usot_plan_op_info(self.h, i, info), 'usot_plan_op_info')
+            out.append((info[0], info[1], info[2], info[3], float(ms[i])))
+        return out
+
     def fork(self, lane):
         hip.check(hip.lib().usot_plan_fork(self.h, lane), 'usot_plan_fork')
 
@@ -398,3 +411,109 @@ class Engine:
         """models.py:164-171: PrRoIPool 7x7, scale 1, batch index prepended -> NCHW dense."""
         xf = _as_dev_f32(xf, self.device)
         return hip.prroi_pool(xf, self._rois(boxes, xf.shape[0]), 7, 7, 1.0)
+
+    # ------------------------------------------------------------------ sessions
+    def open_session(self, p, window, init_feats):
+        """Device-resident tracking state for one video (see Session).  Must be called
+        right after template(): it snapshots the current template encodes."""
+        return Session(self, p, window, init_feats)
+
+
+class Session:
+    """One video's state kept in HBM + its per-frame launch plan (a captured hipGraph).
+
+    bank rows: 0 = init-frame feature, 1 = its left/right flip, 2+i = memory feature i
+    (the reference keeps these as CPU tensors in python lists and re-uploads seven per
+    frame, usot_tracker.py:222-258,264).  One frame =
+        gather 7 rows by device indices -> backbone -> neck -> heads -> decode
+        -> PrRoIPool of the winning box -> scatter the new row,
+    with one 64-byte control upload before and one 64-byte result download after.
+    """
+
+    ROW = 7 * 7 * 256
+
+    def __init__(self, engine, p, window, init_feats, capacity=1024):
+        self.e = engine
+        self.p = p
+        dev = engine.device
+        self.size, self.S = int(p.instance_size), int(p.score_size)
+        self.zk = [t.clone() for t in engine._zenc[1]['zk']]
+        self.window = torch.from_numpy(np.ascontiguousarray(window, dtype=np.float64)).reshape(-1).to(dev)
+        self.cap = capacity
+        self.bank = torch.zeros(capacity, 7, 7, 256, device=dev)
+        for i, f in enumerate((init_feats[0], init_feats[1], init_feats[0])):
+            self.bank[i].copy_(hip.to_nhwc(f)[0])
+        self.n = 1                                   # memory features stored so far
+        self.ctl = torch.zeros(64, dtype=torch.uint8, device=dev)
+        self.ctl_host = torch.zeros(64, dtype=torch.uint8).pin_memory()
+        self.out8 = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.out_host = torch.zeros(8, dtype=torch.float64).pin_memory()
+        self.x_host = torch.zeros(1, 3, self.size, self.size).pin_memory()
+        self._build()
+
+    def _build(self):
+        e, L = self.e, hip.lib()
+        bld = Builder(e.W, e.tuning)
+        pl = bld.plan
+        self.x = bld.buf(1, 3, self.size, self.size)
+        self.mem_in = bld.buf(7, 7, 7, 256)
+        tsz_dev = self.ctl[0:16].view(torch.float64)
+        idx_dev = self.ctl[16:48].view(torch.int32)          # 7 gather rows + 1 scatter row
+        hip.check(L.usot_plan_add_rows_copy(pl.h, hip.ptr(self.bank), hip.ptr(idx_dev), hip.ptr(self.mem_in),
+                                            7, Session.ROW, 0), 'plan_add_rows_copy')
+        xf, hf = bld.backbone(self.x, 1, self.size)
+        bbox, cls2, S = bld.heads(xf, 1, hf, self.zk, self.mem_in, 7)
+        assert S == self.S
+        self.roi = bld.buf(5)
+        self.feat = bld.buf(1, 7, 7, 256)
+        p = self.p
+        hip.check(L.usot_plan_add_decode(pl.h, hip.ptr(cls2[0]), hip.ptr(cls2[1]), hip.ptr(bbox), hip.ptr(self.window),
+                                         hip.ptr(self.out8), S, self.size, int(p.total_stride), float(p.ratio),
+                                         float(p.penalty_k), float(p.window_influence), hip.ptr(tsz_dev),
+                                         hip.ptr(self.roi)), 'plan_add_decode')
+        c = 256
+        hip.check(L.usot_plan_add_prroi(pl.h, hip.ptr(xf), hip.ptr(self.roi), hip.ptr(self.feat), 1, c, hf, hf, 7, 7, 1.0,
+                                        hf * hf * c, 1, hf * c, c, 49 * c, 1, 7 * c, c), 'plan_add_prroi')
+        idx_slot = self.ctl[44:48].view(torch.int32)
+        hip.check(L.usot_plan_add_rows_copy(pl.h, hip.ptr(self.feat), hip.ptr(idx_slot), hip.ptr(self.bank),
+                                            1, Session.ROW, 1), 'plan_add_rows_copy')
+        pl.keep += [self.bank, self.ctl, self.window, self.out8, tsz_dev, idx_dev, idx_slot] + self.zk
+        self.xf, self.cls2, self.bbox, self.plan, self.log = xf, cls2, bbox, pl, bld.log
+        # warm-up must not leave a stray row in the bank: point the scatter at a scratch row
+        self._set_ctl([0, 1, 2, 2, 2, 2, 2], self.cap - 1, (64.0, 64.0))
+        e._finish(pl)
+
+    def _set_ctl(self, rows, slot, tsz):
+        h = self.ctl_host
+        h[0:16].view(torch.float64)[:] = torch.tensor([float(tsz[0]), float(tsz[1])], dtype=torch.float64)
+        h[16:48].view(torch.int32)[:] = torch.tensor(list(rows) + [slot], dtype=torch.int32)
+        self.ctl.copy_(h, non_blocking=True)
+
+    def _grow(self):
+        bank = torch.zeros(self.cap * 2, 7, 7, 256, device=self.e.device)
+        bank[:self.cap].copy_(self.bank)
+        self.bank, self.cap = bank, self.cap * 2
+        self._build()
+
+    def frame(self, x_crop, picks, tsz_scaled, resident=False):
+        """Run one frame.  x_crop: CHW float tensor (host or device); picks: memory indices
+        of the N_q-2 sampled slots; tsz_scaled: target size * scale_z.
+        Returns float64[8] = (argmax, score, penalty, x1, y1, x2, y2, pscore)."""
+        if 2 + self.n >= self.cap - 1:
+            self._grow()
+        if not resident:
+            if x_crop.is_cuda:
+                self.x.copy_(x_crop.reshape(self.x.shape))
+            else:
+                self.x_host.copy_(x_crop.reshape(self.x.shape))
+                self.x.copy_(self.x_host, non_blocking=True)
+        self._set_ctl([0, 1] + [2 + int(i) for i in picks], 2 + self.n, tsz_scaled)
+        self.plan.run()
+        self.out_host.copy_(self.out8, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        self.n += 1
+        return self.out_host.numpy().copy()
+
+    def memory_feature(self, i):
+        """Memory feature i as an NCHW-shaped view [1,256,7,7] of its bank row."""
+        return self.bank[2 + i:3 + i].permute(0, 3, 1, 2)

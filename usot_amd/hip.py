@@ -22,6 +22,7 @@ EXPORTS = (
     'usot_plan_add_maxpool', 'usot_plan_add_groupdw', 'usot_plan_add_conf_reduce',
     'usot_plan_add_prroi', 'usot_plan_add_permute', 'usot_plan_add_decode', 'usot_plan_run',
     'usot_plan_fork', 'usot_plan_join', 'usot_plan_capture', 'usot_plan_size',
+    'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
 )
 
 
@@ -80,12 +81,16 @@ def lib():
                                           + [C.c_int64] * 8)
         L.usot_plan_add_permute.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_int64] * 4
         L.usot_plan_add_decode.argtypes = ([C.c_void_p] + [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_float]
-                                           + [C.c_double] * 2 + [C.c_void_p])
+                                           + [C.c_double] * 2 + [C.c_void_p] * 2)
+        L.usot_plan_add_rows_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int] * 3
+        L.usot_rows_copy_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
         L.usot_plan_fork.argtypes = [C.c_void_p, C.c_int]
         L.usot_plan_join.argtypes = [C.c_void_p, C.c_int]
         L.usot_plan_run.argtypes = [C.c_void_p, C.c_void_p]
         L.usot_plan_capture.argtypes = [C.c_void_p, C.c_void_p]
         L.usot_plan_size.argtypes = [C.c_void_p]
+        L.usot_plan_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.usot_plan_op_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.usot_conv2d_f32.argtypes = [C.c_void_p, C.c_void_p]
         L.usot_groupdw_f32.argtypes = [C.c_void_p, C.c_void_p]
         L.usot_stem_conv_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5

@@ -1,0 +1,74 @@
+"""Multi-GPU plumbing: one process per GPU, independent video streams sharded across ranks.
+
+The tracking path has no per-frame exchange: the only shared data are the
+read-only weights, broadcast ONCE from rank 0 as a single flat buffer (RCCL over xGMI with
+backend "nccl" on ROCm; gloo on CPU for tests).  There is deliberately no all-reduce.
+The reference's only multi-GPU inference mechanism is process fan-out via mpiexec
+(scripts/test_epochs_usot.py:19-49), which sends no message at all.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return (int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)),
+            int(os.environ.get('WORLD_SIZE', 1)))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    rank, local, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def broadcast_weights(model, src=0, device=None):
+    """One flat float32 broadcast of every parameter and float buffer (29.4 M params +
+    BN statistics = 117.8 MB) plus one tiny int64 broadcast for num_batches_tracked."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    sd = model.state_dict()
+    fkeys = [k for k, v in sd.items() if v.is_floating_point()]
+    ikeys = [k for k, v in sd.items() if not v.is_floating_point()]
+    dev = device if device is not None else sd[fkeys[0]].device
+    flat = torch.cat([sd[k].detach().reshape(-1).float().to(dev) for k in fkeys])
+    dist.broadcast(flat, src=src)
+    ints = torch.stack([sd[k].detach().reshape(()).to(dev) for k in ikeys]) if ikeys else None
+    if ints is not None:
+        dist.broadcast(ints, src=src)
+    out, off = {}, 0
+    for k in fkeys:
+        n = sd[k].numel()
+        out[k] = flat[off:off + n].reshape(sd[k].shape).to(sd[k].device)
+        off += n
+    for i, k in enumerate(ikeys):
+        out[k] = ints[i].to(sd[k].device)
+    model.load_state_dict(out, strict=True)
+    return flat.numel() * 4
+
+
+def shard(items, rank, world):
+    """Stream s runs on rank s mod world."""
+    return list(items)[rank::world]
+
+
+def max_over_ranks(value, device=None):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)          # timing scalar only, not on the data path
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

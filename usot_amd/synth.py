@@ -85,7 +85,7 @@ def torch_state_dict(model, seed=0, calibrated=True):
     import torch
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = make_state_dict(shapes, seed, calibrated)
-    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).reshape(shapes[k]) for k, v in sd.items()}
 
 
 def crop(seed, batch, size):
