@@ -124,6 +124,20 @@ def xcorr_bandwidth(device, samples=128, iters=20):
             'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}
 
 
+def host_threads(cap=32):
+    """Threads for the CPU leg: the cores this process may actually use (affinity mask and
+    cgroup quota), capped — torch-CPU on every hardware thread of a 2-socket host thrashes."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(budget_s=12.0):
     """The oracle's restatement of one tracked frame (models.py:179-198 + PrPool) on the host."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -132,13 +146,15 @@ def cpu_baseline(budget_s=12.0):
     sd = synth.torch_state_dict(m, seed=0, calibrated=True)
     t = torch.from_numpy
     z, x = t(synth.crop(1000, 1, 127)), t(synth.crop(2000, 1, 255))
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     torch.set_num_threads(cores)
     with torch.no_grad():
         zf = orc.template(sd, z, torch.tensor([[3.5, 3.5, 10.5, 10.5]]), pr_pool=True)
         mem = torch.cat([zf] * 7, 0)
         frame = lambda: orc.prpool_feature(orc.track(sd, x, zf, mem, torch.ones(1, 7))[3], torch.tensor([[9.0, 9.0, 16.0, 16.0]]))
-        for _ in range(2):
+        t0 = time.perf_counter()
+        frame()                                   # warm-up (also guards the time budget)
+        if time.perf_counter() - t0 < budget_s / 4:
             frame()
         n, t0 = 0, time.perf_counter()
         while True:
