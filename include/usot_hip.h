@@ -103,9 +103,12 @@ typedef struct usot_groupdw_desc {
     int32_t x_cs[3], x_co[3], z_cs[3], z_co[3];
     float wsm[3];
     int32_t S, x_rep, OH, OW, C;
-    int32_t cols_per_thread;     /* 0 = heuristic, 1 or 5 */
+    int32_t cols_per_thread;     /* output patch per thread: 0 or 5 -> 5x5, 1 -> 5x1 */
 } usot_groupdw_desc;
 int usot_groupdw_f32(void *stream, const usot_groupdw_desc *d);
+/* up to three segments of identical geometry (the cls, reg and memory GroupDWs of a frame)
+ * in ONE launch */
+int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, int nseg);
 
 /* ---- Conf_Fusion reduction (connect.py:132-142): cv NHWC [B*M][P][2C] holding
  * conf = exp(clamp) in channels [0,C) and value in [C,2C) -> out [B][P][C] =
@@ -169,6 +172,7 @@ void usot_plan_destroy(void *plan);
 int usot_plan_size(void *plan);
 int usot_plan_add_conv(void *plan, const usot_conv_desc *d);
 int usot_plan_add_groupdw(void *plan, const usot_groupdw_desc *d);
+int usot_plan_add_groupdw_multi(void *plan, const usot_groupdw_desc *d, int nseg);
 int usot_plan_add_stem(void *plan, const float *x, const float *w, const float *bias, float *y,
                        int N, int H, int W, int OH, int OW);
 int usot_plan_add_maxpool(void *plan, const float *x, float *y, int N, int H, int W, int C,

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Autotune the implicit-GEMM tile and split-K factor for every distinct convolution shape of
+the tracked frame (batch B) on the GPU at hand; writes usot_amd/data/tuning_gfx950.json,
+which the engine loads by default.  Timing: HIP events around R back-to-back launches."""
+import argparse, ctypes as C, json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from usot_amd import hip, synth
+from usot_amd.engine import Builder, Weights
+from usot_amd.model import USOT
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, nargs='+', default=[1])
+ap.add_argument('--sizes', type=int, nargs='+', default=[255, 127, 271])
+ap.add_argument('--reps', type=int, default=12)
+ap.add_argument('--out', default=os.path.join(ROOT, 'usot_amd', 'data', 'tuning_gfx950.json'))
+ap.add_argument('--verbose', action='store_true')
+a = ap.parse_args()
+
+dev = torch.device('cuda:0')
+m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to(dev)
+W = Weights(m, dev)
+shapes = {}
+for B in a.batch:
+    for size in a.sizes:
+        bld = Builder(W, {})
+        x = bld.buf(B, 3, size, size)
+        xf, hf = bld.backbone(x, B, size)
+        if size == 127:
+            zf = bld.buf(B, 7, 7, 256)
+            bld.encode_kernel(zf, B, 512, 'z')
+        else:
+            zk = [bld.buf(B, hk, wk, 512) for hk, wk in ((5, 5), (3, 5), (5, 3))]
+            mem = bld.buf(B * 7, 7, 7, 256)
+            bld.heads(xf, B, hf, zk, mem, 7)
+        for g in bld.geoms:
+            key = (g['N'] * ((g['H'] + 2 * g['pad'][0] - g['dil'][0] * (g['KH'] - 1) - 1) // g['stride'] + 1)
+                   * ((g['W'] + 2 * g['pad'][1] - g['dil'][1] * (g['KW'] - 1) - 1) // g['stride'] + 1),
+                   g['Cout'], g['KH'] * g['KW'] * g['Cin'], g['groups'])
+            shapes.setdefault(key, g)
+        del bld
+tiles = hip.tile_table()
+L = hip.lib()
+table = {}
+if os.path.exists(a.out):
+    with open(a.out) as f:
+        table = json.load(f)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for key, g in sorted(shapes.items()):
+    M, Cout, K, groups = key
+    N, H, Wd, Cin = g['N'], g['H'], g['W'], g['Cin']
+    OH = (H + 2 * g['pad'][0] - g['dil'][0] * (g['KH'] - 1) - 1) // g['stride'] + 1
+    OW = (Wd + 2 * g['pad'][1] - g['dil'][1] * (g['KW'] - 1) - 1) // g['stride'] + 1
+    x = torch.randn(groups, N, H, Wd, Cin, device=dev)
+    w = torch.randn(groups, Cout, K, device=dev) * 0.02
+    b = torch.randn(groups, Cout, device=dev)
+    y = torch.empty(groups, N, OH, OW, Cout, device=dev)
+    res = torch.randn_like(y) if g['has_res'] else None
+    KT = g['KH'] * g['KW'] * (Cin // 32)
+    best = None
+    rows = []
+    for tile, (bm, bn) in tiles.items():
+        if bn >= 2 * max(16, Cout) and bn > 32: continue
+        if bm >= 4 * M and bm > 16: continue
+        blocks = -(-M // bm) * -(-Cout // bn) * groups
+        for ks in (1, 2, 3, 4, 6, 8, 12, 16):
+            if ks > 1 and (ks > KT // 2 or blocks * ks > 2048 or blocks >= 512): continue
+            ws = torch.empty(ks * groups * M * Cout, device=dev) if ks > 1 else None
+            d = hip.conv_desc(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N=N, H=H, W=Wd, Cin=Cin, OH=OH, OW=OW,
+                              Cout=Cout, KH=g['KH'], KW=g['KW'], stride=g['stride'], pad=g['pad'], dil=g['dil'],
+                              res=res.data_ptr() if res is not None else None, act=1, groups=groups,
+                              x_gs=N * H * Wd * Cin, w_gs=Cout * K, b_gs=Cout, y_gs=M * Cout, r_gs=M * Cout,
+                              ksplit=ks, tile=tile, ws=ws.data_ptr() if ws is not None else None)
+            for _ in range(2):
+                hip.check(L.usot_conv2d_f32(hip.stream(), C.byref(d)))
+            e0.record()
+            for _ in range(a.reps):
+                L.usot_conv2d_f32(hip.stream(), C.byref(d))
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / a.reps * 1e3
+            rows.append((us, tile, ks))
+            if best is None or us < best[0]:
+                best = (us, tile, ks)
+    us, tile, ks = best
+    tf = 2.0 * M * Cout * K * groups / us / 1e6
+    table['%d,%d,%d,%d' % key] = [tile, ks]
+    print('%-14s M=%6d N=%5d K=%5d g=%d -> tile %dx%d ksplit %d: %7.1f us %6.1f TFLOP/s' % (
+        g['name'], M, Cout, K, groups, tiles[tile][0], tiles[tile][1], ks, us, tf), flush=True)
+    if a.verbose:
+        for us2, t2, k2 in sorted(rows)[:6]:
+            print('      %3dx%-3d ks%-2d %7.1f us' % (tiles[t2][0], tiles[t2][1], k2, us2))
+with open(a.out, 'w') as f:
+    json.dump(table, f, indent=0, sort_keys=True)
+print('wrote', a.out, len(table), 'shapes')

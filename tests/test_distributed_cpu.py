@@ -1,0 +1,63 @@
+"""CPU, world size 2 over gloo: the N>1 path of bench.py — rank 0's weights reach every
+rank through ONE flat broadcast, streams shard by rank, and the only other collective is
+the max over ranks of the timing scalar."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from usot_amd import streams, synth
+    from usot_amd.model import USOT
+    r, _, w = streams.init(backend='gloo')
+    assert (r, w) == (rank, world)
+    m = USOT()
+    if rank == 0:
+        m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True), strict=True)
+    nbytes = streams.broadcast_weights(m, src=0)
+    sd = m.state_dict()
+    want = synth.torch_state_dict(m, seed=0, calibrated=True)
+    same = all(torch.equal(sd[k].reshape(-1), want[k].reshape(-1).to(sd[k].dtype)) for k in want)
+    t = streams.max_over_ranks(1.0 + rank)
+    q.put((rank, nbytes, same, streams.shard(range(8), rank, world), t))
+    streams.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_shard_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, nbytes, same, mine, t in out:
+        assert same, 'rank %d did not receive rank 0 weights' % rank
+        assert nbytes == (29414993 + 44486 - 70) * 4       # params + BN float buffers (70 int counters apart)
+        assert mine == list(range(8))[rank::2]
+        assert t == 2.0
+
+
+def test_single_process_is_a_noop():
+    from usot_amd import streams
+    from usot_amd.model import USOT
+    assert streams.broadcast_weights(USOT(), src=0) == 0
+    assert streams.shard('abcdef', 1, 3) == ['b', 'e']
+    assert streams.max_over_ranks(3.5) == 3.5

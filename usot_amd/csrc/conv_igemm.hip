@@ -65,7 +65,7 @@ __device__ __forceinline__ int xcd_remap(int b, int total)
 
 constexpr int LDK = 36;   // padded k-extent of an LDS row (floats)
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int DBG = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p)
 {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
@@ -166,16 +166,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p)
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
         const bool more = kt + 1 < kt1;
-        if (more) load_tile(kt + 1);
+        if (more && DBG < 1) load_tile(kt + 1);
         const float *cX = sX + (cur * BM + wm * TM * 16 + l15) * LDK + quad * 4;
         const float *cW = sW + (cur * BN + wn * TN * 16 + l15) * LDK + quad * 4;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             f32x4 wf[TN], xf[TM];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) wf[i] = *(const f32x4 *)(cW + i * 16 * LDK + r * 16);
+            for (int i = 0; i < TN; ++i) wf[i] = DBG < 2 ? *(const f32x4 *)(cW + i * 16 * LDK + r * 16) : f32x4{1.f + kt, 2.f, 3.f, 4.f + i};
 #pragma unroll
-            for (int j = 0; j < TM; ++j) xf[j] = *(const f32x4 *)(cX + j * 16 * LDK + r * 16);
+            for (int j = 0; j < TM; ++j) xf[j] = DBG < 2 ? *(const f32x4 *)(cX + j * 16 * LDK + r * 16) : f32x4{1.f, 2.f + kt, 3.f + j, 4.f};
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p)
                     for (int j = 0; j < TM; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][c], xf[j][c], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(cur ^ 1);
+        if (more && DBG < 1) store_tile(cur ^ 1);
         __syncthreads();
     }
 
@@ -286,6 +286,10 @@ const TileCfg kTiles[] = {
     TILE(16, 64, 1, 4),     // 8: tiny M (template-side encoders)
     TILE(16, 128, 1, 4),    // 9
     TILE(32, 128, 2, 2),    // 10
+    { 128, 128, conv_igemm_f32<128, 128, 2, 2, 1> },   // 11 DBG: no global loads / LDS stores
+    { 128, 128, conv_igemm_f32<128, 128, 2, 2, 2> },   // 12 DBG: MFMA + barrier only
+    { 64, 64, conv_igemm_f32<64, 64, 2, 2, 1> },       // 13
+    { 64, 64, conv_igemm_f32<64, 64, 2, 2, 2> },       // 14
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 

@@ -32,7 +32,8 @@ struct Op {
     Kind kind;
     int lane;
     usot_conv_desc conv;
-    usot_groupdw_desc gdw;
+    usot_groupdw_desc gdw[3];
+    int ngdw;
     const void *p[6];
     int i[8];
     int64_t l[8];
@@ -65,7 +66,7 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
         for (int rep = 0; rep < reps && rc == USOT_OK; ++rep)
         switch (op.kind) {
         case K_CONV: rc = usot_conv2d_f32(s, &op.conv); break;
-        case K_GDW:  rc = usot_groupdw_f32(s, &op.gdw); break;
+        case K_GDW:  rc = usot_groupdw_multi_f32(s, op.gdw, op.ngdw); break;
         case K_STEM:
             rc = usot_stem_conv_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2],
                                     (float *)op.p[3], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4]);
@@ -180,9 +181,16 @@ extern "C" int usot_plan_add_conv(void *plan, const usot_conv_desc *d)
 extern "C" int usot_plan_add_groupdw(void *plan, const usot_groupdw_desc *d)
 {
     if (!d) return USOT_EINVAL;
+    return usot_plan_add_groupdw_multi(plan, d, 1);
+}
+
+extern "C" int usot_plan_add_groupdw_multi(void *plan, const usot_groupdw_desc *d, int nseg)
+{
+    if (!d || nseg < 1 || nseg > 3) return USOT_EINVAL;
     Op *op = push(plan, K_GDW);
     if (!op) return USOT_ESTATE;
-    op->gdw = *d;
+    for (int i = 0; i < nseg; ++i) op->gdw[i] = d[i];
+    op->ngdw = nseg;
     return USOT_OK;
 }
 

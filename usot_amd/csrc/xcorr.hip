@@ -24,121 +24,150 @@ namespace {
 // -------------------------------------------------------------------------------------
 // (1) fused GroupDW, NHWC
 // -------------------------------------------------------------------------------------
-struct GdwK {
+// One launch covers up to three "segments" (the cls, reg and memory GroupDWs of a frame:
+// different template sets / channel halves / branch weights, same geometry), so a frame
+// pays one launch instead of three.  A thread owns one channel (lane = channel: every
+// global access of a wavefront is a contiguous 256-byte row) and an RS x CW patch of
+// output pixels; the 55 template taps live in registers pre-scaled by softmax(weight), each
+// search row of the patch is loaded once and feeds up to 5 output rows x 5 taps
+// (5.2 FMA per load).  Loop bounds are compile-time: no accumulator rotation, the
+// compiler is free to hoist the next row's loads above the current row's FMAs.
+struct GdwSeg {
     const float *x[3];
     const float *z[3];
     float *out;
     int x_cs[3], x_co[3], z_cs[3], z_co[3];
     float wsm[3];
-    int S, x_rep, OH, OW, C;
-    int ncg;      // column groups
+    int S, x_rep;
+};
+struct GdwK {
+    GdwSeg seg[3];
+    int nseg, OH, OW, C;
+    int nty, ntx;      // patch grid
+    int total;         // samples over all segments
 };
 
-// branch geometry is fixed by the 7x7 template and the three encoder dilations
-template <int B> struct Geo;
-template <> struct Geo<0> { static constexpr int HK = 5, WK = 5; };
-template <> struct Geo<1> { static constexpr int HK = 3, WK = 5; };
-template <> struct Geo<2> { static constexpr int HK = 5, WK = 3; };
-
-template <int CW>
+template <int RS, int CW>
 __global__ __launch_bounds__(256) void groupdw_nhwc_kernel(const GdwK p)
 {
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-    const int cgp = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int s = blockIdx.z;
-    if (cgp >= p.ncg || c >= p.C) return;
-    const int j0 = cgp * CW;
-    const int xs = s / p.x_rep;
+    // Work unit = (sample, patch); channel group = 64 lanes.  With C = 256 the 1-D grid is
+    // laid out so that XCD x (= block id % 8, observed dispatch order; speed only) always
+    // works on channel group x % 4: each XCD's L2 then holds one quarter of the search maps
+    // instead of every XCD pulling all of them across the fabric.
+    const int ntile = p.nty * p.ntx;
+    const int units = p.total * ntile;
+    const int wave = threadIdx.x >> 6;
+    int cgi, unit;
+    if (p.C == 256) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        cgi = xcd & 3;
+        unit = (slot * 4 + wave) * 2 + (xcd >> 2);
+    } else {
+        const int ncg = p.C >> 6;
+        cgi = blockIdx.x % ncg;
+        unit = (blockIdx.x / ncg) * 4 + wave;
+    }
+    if (unit >= units) return;
+    const int c = cgi * 64 + (threadIdx.x & 63);
+    int s = unit / ntile, sg = 0;
+    const int tile = unit - s * ntile;
+    while (sg + 1 < p.nseg && s >= p.seg[sg].S) { s -= p.seg[sg].S; ++sg; }
+    const GdwSeg &g = p.seg[sg];
+    const int i0 = (tile / p.ntx) * RS, j0 = (tile % p.ntx) * CW;
+    const int xs = s / g.x_rep;
 
-    // taps, pre-scaled by softmax(weight)[b]
     float k0[5][5], k1[3][5], k2[5][3];
     {
-        const float *z0 = p.z[0] + (long)s * 25 * p.z_cs[0] + p.z_co[0] + c;
+        const float *z0 = g.z[0] + (long)s * 25 * g.z_cs[0] + g.z_co[0] + c;
 #pragma unroll
         for (int u = 0; u < 5; ++u)
 #pragma unroll
-            for (int v = 0; v < 5; ++v) k0[u][v] = p.wsm[0] * z0[(u * 5 + v) * p.z_cs[0]];
-        const float *z1 = p.z[1] + (long)s * 15 * p.z_cs[1] + p.z_co[1] + c;
+            for (int v = 0; v < 5; ++v) k0[u][v] = g.wsm[0] * z0[(u * 5 + v) * g.z_cs[0]];
+        const float *z1 = g.z[1] + (long)s * 15 * g.z_cs[1] + g.z_co[1] + c;
 #pragma unroll
         for (int u = 0; u < 3; ++u)
 #pragma unroll
-            for (int v = 0; v < 5; ++v) k1[u][v] = p.wsm[1] * z1[(u * 5 + v) * p.z_cs[1]];
-        const float *z2 = p.z[2] + (long)s * 15 * p.z_cs[2] + p.z_co[2] + c;
+            for (int v = 0; v < 5; ++v) k1[u][v] = g.wsm[1] * z1[(u * 5 + v) * g.z_cs[1]];
+        const float *z2 = g.z[2] + (long)s * 15 * g.z_cs[2] + g.z_co[2] + c;
 #pragma unroll
         for (int u = 0; u < 5; ++u)
 #pragma unroll
-            for (int v = 0; v < 3; ++v) k2[u][v] = p.wsm[2] * z2[(u * 3 + v) * p.z_cs[2]];
+            for (int v = 0; v < 3; ++v) k2[u][v] = g.wsm[2] * z2[(u * 3 + v) * g.z_cs[2]];
     }
-    const int W0 = p.OW + 4, W1 = p.OW + 4, W2 = p.OW + 2;      // search-map widths
-    const int H0 = p.OH + 4, H1 = p.OH + 2, H2 = p.OH + 4;
-    const float *x0 = p.x[0] + (long)xs * H0 * W0 * p.x_cs[0] + p.x_co[0] + c;
-    const float *x1 = p.x[1] + (long)xs * H1 * W1 * p.x_cs[1] + p.x_co[1] + c;
-    const float *x2 = p.x[2] + (long)xs * H2 * W2 * p.x_cs[2] + p.x_co[2] + c;
-    float *o = p.out + ((long)s * p.OH * p.OW) * p.C + c;
-
-    // A[u][j]: partial sum of output row (r - u) after consuming input row r
-    float A[5][CW];
+    float acc[RS][CW];
 #pragma unroll
-    for (int u = 0; u < 5; ++u)
+    for (int i = 0; i < RS; ++i)
 #pragma unroll
-        for (int j = 0; j < CW; ++j) A[u][j] = 0.f;
+        for (int j = 0; j < CW; ++j) acc[i][j] = 0.f;
 
-    for (int r = 0; r < p.OH + 4; ++r) {
-        {   // 5x5 branch: row r of x0
+    // rows/cols past the map edge (partial patches only) are clamped: they feed only outputs
+    // that are never stored
+    {   // 5x5 branch
+        const int H = p.OH + 4, W = p.OW + 4;
+        const float *x = g.x[0] + (long)xs * H * W * g.x_cs[0] + g.x_co[0] + c;
+#pragma unroll
+        for (int rr = 0; rr < RS + 4; ++rr) {
+            const int row = min(i0 + rr, H - 1);
             float xv[CW + 4];
 #pragma unroll
-            for (int q = 0; q < CW + 4; ++q) {
-                const int col = j0 + q;
-                xv[q] = col < W0 ? x0[((long)r * W0 + col) * p.x_cs[0]] : 0.f;
-            }
+            for (int q = 0; q < CW + 4; ++q) xv[q] = x[((long)row * W + min(j0 + q, W - 1)) * g.x_cs[0]];
 #pragma unroll
-            for (int u = 0; u < 5; ++u)
+            for (int u = 0; u < 5; ++u) {
+                const int i = rr - u;
+                if (i < 0 || i >= RS) continue;
 #pragma unroll
                 for (int j = 0; j < CW; ++j)
 #pragma unroll
-                    for (int v = 0; v < 5; ++v) A[u][j] = fmaf(xv[j + v], k0[u][v], A[u][j]);
+                    for (int v = 0; v < 5; ++v) acc[i][j] = fmaf(xv[j + v], k0[u][v], acc[i][j]);
+            }
         }
-        if (r < H1) {   // 3x5 branch
+    }
+    {   // 3x5 branch
+        const int H = p.OH + 2, W = p.OW + 4;
+        const float *x = g.x[1] + (long)xs * H * W * g.x_cs[1] + g.x_co[1] + c;
+#pragma unroll
+        for (int rr = 0; rr < RS + 2; ++rr) {
+            const int row = min(i0 + rr, H - 1);
             float xv[CW + 4];
 #pragma unroll
-            for (int q = 0; q < CW + 4; ++q) {
-                const int col = j0 + q;
-                xv[q] = col < W1 ? x1[((long)r * W1 + col) * p.x_cs[1]] : 0.f;
-            }
+            for (int q = 0; q < CW + 4; ++q) xv[q] = x[((long)row * W + min(j0 + q, W - 1)) * g.x_cs[1]];
 #pragma unroll
-            for (int u = 0; u < 3; ++u)
+            for (int u = 0; u < 3; ++u) {
+                const int i = rr - u;
+                if (i < 0 || i >= RS) continue;
 #pragma unroll
                 for (int j = 0; j < CW; ++j)
 #pragma unroll
-                    for (int v = 0; v < 5; ++v) A[u][j] = fmaf(xv[j + v], k1[u][v], A[u][j]);
+                    for (int v = 0; v < 5; ++v) acc[i][j] = fmaf(xv[j + v], k1[u][v], acc[i][j]);
+            }
         }
-        {   // 5x3 branch
+    }
+    {   // 5x3 branch
+        const int H = p.OH + 4, W = p.OW + 2;
+        const float *x = g.x[2] + (long)xs * H * W * g.x_cs[2] + g.x_co[2] + c;
+#pragma unroll
+        for (int rr = 0; rr < RS + 4; ++rr) {
+            const int row = min(i0 + rr, H - 1);
             float xv[CW + 2];
 #pragma unroll
-            for (int q = 0; q < CW + 2; ++q) {
-                const int col = j0 + q;
-                xv[q] = col < W2 ? x2[((long)r * W2 + col) * p.x_cs[2]] : 0.f;
-            }
+            for (int q = 0; q < CW + 2; ++q) xv[q] = x[((long)row * W + min(j0 + q, W - 1)) * g.x_cs[2]];
 #pragma unroll
-            for (int u = 0; u < 5; ++u)
+            for (int u = 0; u < 5; ++u) {
+                const int i = rr - u;
+                if (i < 0 || i >= RS) continue;
 #pragma unroll
                 for (int j = 0; j < CW; ++j)
 #pragma unroll
-                    for (int v = 0; v < 3; ++v) A[u][j] = fmaf(xv[j + v], k2[u][v], A[u][j]);
+                    for (int v = 0; v < 3; ++v) acc[i][j] = fmaf(xv[j + v], k2[u][v], acc[i][j]);
+            }
         }
-        const int done = r - 4;       // output row finished by this input row
-        if (done >= 0) {
-#pragma unroll
-            for (int j = 0; j < CW; ++j)
-                if (j0 + j < p.OW) o[((long)done * p.OW + j0 + j) * p.C] = A[4][j];
-        }
-#pragma unroll
-        for (int u = 4; u > 0; --u)
-#pragma unroll
-            for (int j = 0; j < CW; ++j) A[u][j] = A[u - 1][j];
-#pragma unroll
-        for (int j = 0; j < CW; ++j) A[0][j] = 0.f;
     }
+    float *o = g.out + ((long)s * p.OH * p.OW) * p.C + c;
+#pragma unroll
+    for (int i = 0; i < RS; ++i)
+#pragma unroll
+        for (int j = 0; j < CW; ++j)
+            if (i0 + i < p.OH && j0 + j < p.OW) o[((long)(i0 + i) * p.OW + j0 + j) * p.C] = acc[i][j];
 }
 
 // -------------------------------------------------------------------------------------
@@ -253,28 +282,44 @@ extern "C" int usot_xcorr_depthwise_f32(void *stream, const float *x, const floa
     return USOT_OK;
 }
 
-extern "C" int usot_groupdw_f32(void *stream, const usot_groupdw_desc *d)
+extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, int nseg)
 {
-    if (!d || !d->out || d->S <= 0 || d->x_rep < 1 || d->OH < 1 || d->OW < 1) return USOT_EINVAL;
-    if (d->C <= 0 || (d->C & 63)) return USOT_EINVAL;
+    if (!d || nseg < 1 || nseg > 3) return USOT_EINVAL;
     static const int hk[3] = {5, 3, 5}, wk[3] = {5, 5, 3};
     GdwK p;
-    for (int b = 0; b < 3; ++b) {
-        if (!d->x[b] || !d->z[b] || d->hk[b] != hk[b] || d->wk[b] != wk[b]) return USOT_EINVAL;
-        p.x[b] = d->x[b]; p.z[b] = d->z[b];
-        p.x_cs[b] = d->x_cs[b] > 0 ? d->x_cs[b] : d->C; p.x_co[b] = d->x_co[b];
-        p.z_cs[b] = d->z_cs[b] > 0 ? d->z_cs[b] : d->C; p.z_co[b] = d->z_co[b];
-        p.wsm[b] = d->wsm[b];
+    p.nseg = nseg; p.OH = d[0].OH; p.OW = d[0].OW; p.C = d[0].C;
+    if (p.OH < 1 || p.OW < 1 || p.C <= 0 || (p.C & 63)) return USOT_EINVAL;
+    int total = 0;
+    for (int sidx = 0; sidx < nseg; ++sidx) {
+        const usot_groupdw_desc &q = d[sidx];
+        if (!q.out || q.S <= 0 || q.x_rep < 1 || q.OH != p.OH || q.OW != p.OW || q.C != p.C) return USOT_EINVAL;
+        GdwSeg &g = p.seg[sidx];
+        for (int b = 0; b < 3; ++b) {
+            if (!q.x[b] || !q.z[b] || q.hk[b] != hk[b] || q.wk[b] != wk[b]) return USOT_EINVAL;
+            g.x[b] = q.x[b]; g.z[b] = q.z[b];
+            g.x_cs[b] = q.x_cs[b] > 0 ? q.x_cs[b] : q.C; g.x_co[b] = q.x_co[b];
+            g.z_cs[b] = q.z_cs[b] > 0 ? q.z_cs[b] : q.C; g.z_co[b] = q.z_co[b];
+            g.wsm[b] = q.wsm[b];
+        }
+        g.out = q.out; g.S = q.S; g.x_rep = q.x_rep;
+        total += q.S;
     }
-    p.out = d->out; p.S = d->S; p.x_rep = d->x_rep; p.OH = d->OH; p.OW = d->OW; p.C = d->C;
-    int cw = d->cols_per_thread;
-    if (cw == 0) cw = (d->S >= 64 && d->OW % 5 == 0) ? 5 : 1;
-    if (cw != 1 && cw != 5) return USOT_EINVAL;
-    p.ncg = (d->OW + cw - 1) / cw;
-    dim3 grid((p.ncg + 3) / 4, d->C / 64, d->S);
+    const int mode = d[0].cols_per_thread;      // 0/5: 5x5 patches; 1: 5x1 strips (more waves)
     hipStream_t s = (hipStream_t)stream;
-    if (cw == 5) hipLaunchKernelGGL(groupdw_nhwc_kernel<5>, grid, dim3(256), 0, s, p);
-    else         hipLaunchKernelGGL(groupdw_nhwc_kernel<1>, grid, dim3(256), 0, s, p);
+    if (mode != 0 && mode != 1 && mode != 5) return USOT_EINVAL;
+    p.total = total;
+    p.nty = (p.OH + 4) / 5;
+    p.ntx = mode == 1 ? p.OW : (p.OW + 4) / 5;
+    const long units = (long)total * p.nty * p.ntx;
+    const long blocks = p.C == 256 ? 8 * (((units + 1) / 2 + 3) / 4) : (long)(p.C / 64) * ((units + 3) / 4);
+    if (blocks > 0x7fffffffL) return USOT_EINVAL;
+    if (mode == 1) hipLaunchKernelGGL((groupdw_nhwc_kernel<5, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else           hipLaunchKernelGGL((groupdw_nhwc_kernel<5, 5>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
+}
+
+extern "C" int usot_groupdw_f32(void *stream, const usot_groupdw_desc *d)
+{
+    return usot_groupdw_multi_f32(stream, d, 1);
 }

@@ -157,7 +157,8 @@ class Builder:
         self.dev = weights.device
         self.plan = Plan()
         self.tuning = tuning or {}
-        self.log = []           # (name, M, N, K, macs) per conv, for benchmarks
+        self.log = []           # (name, M, N, K, groups, macs) per conv, for benchmarks
+        self.geoms = []         # full geometry per conv, for the tuner
 
     def buf(self, *shape, dtype=torch.float32):
         t = torch.empty(shape, device=self.dev, dtype=dtype)
@@ -190,6 +191,8 @@ class Builder:
         hip.check(hip.lib().usot_plan_add_conv(self.plan.h, C.byref(d)), 'plan_add_conv ' + name)
         self.plan.keep += [x, pc.w, pc.b]
         self.log.append((name, m, cout, k, groups, m * cout * k * groups))
+        self.geoms.append(dict(name=name, N=n, H=h, W=w, Cin=pc.cin, Cout=cout, KH=pc.kh, KW=pc.kw, stride=pc.stride,
+                               pad=list(pc.pad), dil=list(pc.dil), groups=groups, has_res=res is not None))
         return y, oh, ow
 
     # ---- a1-a4: backbone + neck: x NCHW [n,3,s,s] -> xf NHWC [n,hf,wf,256]
@@ -233,8 +236,12 @@ class Builder:
         d = hip.groupdw_desc([t.data_ptr() for t in xs], [t.data_ptr() for t in zs], out.data_ptr(), wsm,
                              S=S, x_rep=x_rep, OH=oh, OW=ow, Cc=256, x_cs=[512] * 3, x_co=[x_co] * 3,
                              z_cs=[z_cs] * 3, z_co=[x_co if z_cs == 512 else 0] * 3)
-        hip.check(hip.lib().usot_plan_add_groupdw(self.plan.h, C.byref(d)), 'plan_add_groupdw')
         self.plan.keep += list(xs) + list(zs) + [out]
+        return d
+
+    def groupdw_flush(self, descs):
+        arr = (hip.GroupDWDesc * len(descs))(*descs)
+        hip.check(hip.lib().usot_plan_add_groupdw_multi(self.plan.h, arr, len(descs)), 'plan_add_groupdw_multi')
 
     # ---- a9: heads.  xf NHWC [b,hf,hf,256]; zk: 3 maps [b,hk,wk,512]; mem_nhwc [b*m,7,7,256] or None
     def heads(self, xf, b, hf, zk, mem_nhwc, m):
@@ -246,12 +253,14 @@ class Builder:
         S = hf - 6                                    # response size (25 for 31, 27 for 33)
         ngroups = 3 if mem_nhwc is not None else 2
         tin = self.buf(ngroups, b, S, S, 256)         # tower inputs: [reg, cls, (memory)]
-        self.groupdw(es, zk, tin[0], W.reg_wsm, b, 1, S, S, 256, 512)
-        self.groupdw(es, zk, tin[1], W.cls_wsm, b, 1, S, S, 0, 512)
+        segs = [self.groupdw(es, zk, tin[0], W.reg_wsm, b, 1, S, S, 256, 512),
+                self.groupdw(es, zk, tin[1], W.cls_wsm, b, 1, S, S, 0, 512)]
         if mem_nhwc is not None:
             mk = self.encode_kernel(mem_nhwc, b * m, 256, 'mem')
             dwm = self.buf(b * m, S, S, 256)
-            self.groupdw(es, mk, dwm, W.cls_wsm, b * m, m, S, S, 0, 256)
+            segs.append(self.groupdw(es, mk, dwm, W.cls_wsm, b * m, m, S, S, 0, 256))
+        self.groupdw_flush(segs)
+        if mem_nhwc is not None:
             cv, _, _ = self.conv('conf_fusion', W.conf, dwm, b * m, S, S, act=ACT_CONF, act2=ACT_RELU, act_split=256)
             hip.check(L.usot_plan_add_conf_reduce(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256),
                       'plan_add_conf_reduce')
@@ -277,6 +286,19 @@ def _as_dev_f32(t, device):
     return t.to(device=device, dtype=torch.float32)
 
 
+def load_tuning(path=None):
+    """{(M, Cout, K, groups): (tile, ksplit)} measured by scripts/tune_conv.py on gfx950.
+    Shapes missing from the table fall back to the launcher's heuristic."""
+    import json
+    import os
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'tuning_gfx950.json')
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        raw = json.load(f)
+    return {tuple(int(v) for v in k.split(',')): (int(t), int(ks)) for k, (t, ks) in raw.items()}
+
+
 class Engine:
     """Per-model, per-device executor with cached plans.  Stateless w.r.t. tracking."""
 
@@ -287,7 +309,7 @@ class Engine:
         self.device = torch.device(device)
         self.W = Weights(model, self.device)
         self.graphs = graphs
-        self.tuning = tuning or {}
+        self.tuning = load_tuning() if tuning is None else tuning
         self._feat = {}       # (n, size) -> dict(x, xf, h, plan)
         self._zenc = {}       # n -> dict(zf, zk, plan)
         self._track = {}      # (b, size, m) -> dict

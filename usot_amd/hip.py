@@ -22,7 +22,7 @@ EXPORTS = (
     'usot_plan_add_maxpool', 'usot_plan_add_groupdw', 'usot_plan_add_conf_reduce',
     'usot_plan_add_prroi', 'usot_plan_add_permute', 'usot_plan_add_decode', 'usot_plan_run',
     'usot_plan_fork', 'usot_plan_join', 'usot_plan_capture', 'usot_plan_size',
-    'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
+    'usot_groupdw_multi_f32', 'usot_plan_add_groupdw_multi', 'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
 )
 
 
@@ -93,6 +93,8 @@ def lib():
         L.usot_plan_op_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.usot_conv2d_f32.argtypes = [C.c_void_p, C.c_void_p]
         L.usot_groupdw_f32.argtypes = [C.c_void_p, C.c_void_p]
+        L.usot_groupdw_multi_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.usot_plan_add_groupdw_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_stem_conv_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5
         L.usot_maxpool3x3s2_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6
         L.usot_xcorr_depthwise_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5
