@@ -11,7 +11,7 @@ tiles = hip.tile_table()
 SHAPES = [('b7.ds', 1, 31, 31, 512, 1024, 3, 1, 1, 1), ('conf', 7, 25, 25, 256, 512, 3, 1, 1, 1),
           ('l3.conv2', 1, 31, 31, 256, 256, 3, 1, 2, 2), ('l3.conv1', 1, 31, 31, 1024, 256, 1, 1, 0, 1),
           ('big', 16, 31, 31, 512, 1024, 3, 1, 1, 1)]
-variants = [tuple(int(v) for v in a.split(':')) for a in sys.argv[1:]] or [(1, 1), (11, 1), (12, 1), (4, 1), (13, 1), (14, 1)]
+variants = [tuple(int(v) for v in a.split(':')) for a in sys.argv[1:]] or [(1, 1), (4, 1), (11, 1), (12, 1), (13, 1), (15, 1)]
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for name, N, H, W, Cin, Cout, k, st, pad, dil in SHAPES:
     OH = (H + 2 * pad - dil * (k - 1) - 1) // st + 1

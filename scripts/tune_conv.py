@@ -85,8 +85,8 @@ for key, g in sorted(shapes.items()):
     us, tile, ks = best
     tf = 2.0 * M * Cout * K * groups / us / 1e6
     table['%d,%d,%d,%d' % key] = [tile, ks]
-    print('%-14s M=%6d N=%5d K=%5d g=%d -> tile %dx%d ksplit %d: %7.1f us %6.1f TFLOP/s' % (
-        g['name'], M, Cout, K, groups, tiles[tile][0], tiles[tile][1], ks, us, tf), flush=True)
+    print('%-14s M=%6d N=%5d K=%5d g=%d -> tile %2d (%dx%d) ksplit %d: %7.1f us %6.1f TFLOP/s' % (
+        g['name'], M, Cout, K, groups, tile, tiles[tile][0], tiles[tile][1], ks, us, tf), flush=True)
     if a.verbose:
         for us2, t2, k2 in sorted(rows)[:6]:
             print('      %3dx%-3d ks%-2d %7.1f us' % (tiles[t2][0], tiles[t2][1], k2, us2))

@@ -42,7 +42,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
-@pytest.mark.parametrize('tile', [0, 4, 7, 8])
+@pytest.mark.parametrize('tile', [0, 4, 7, 8, 11, 12, 13, 15, 16, 19, 20])
 def test_conv_igemm(case, tile):
     N, Cin, H, W, Cout, k, stride, pad, dil = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))

@@ -246,6 +246,240 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// v2 main loop: three LDS stages, the barrier in the MIDDLE of a k-tile, fragments
+// prefetched one round ahead (also across the k-tile boundary).
+//
+// At batch 1 most layers run one wavefront per SIMD, so nothing hides a wave's own waits:
+// every cycle it spends on ds_write -> barrier -> ds_read -> first MFMA is a cycle the matrix
+// pipe idles (measured on v1, 64x64 tile, layer3.0 shortcut: MFMA-only 130 TFLOP/s, with
+// staging 58).  Here, per k-tile t:
+//     F1 <- fragments(t, round 1)            issued before round 0's MFMAs
+//     MFMA round 0 (F0)
+//     G (tile t+1, loaded during tile t-1) -> LDS[(t+1)%3];  issue global loads of t+2 -> G
+//     barrier                                 (tile t+1 visible; nobody still reads (t+1)%3,
+//                                              it held tile t-2)
+//     F0 <- fragments(t+1, round 0)          hidden behind round 1's MFMAs
+//     MFMA round 1 (F1)
+// so the global-load latency has a whole k-tile to land, the LDS write is off the critical
+// path, and no MFMA ever waits for a just-issued ds_read.
+template <int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__(256) void conv_igemm_f32_v2(const ConvK p)
+{
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    static_assert(BK == 32 || BK == 64, "k-tile of 32 or 64");
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int LD = BK + 4;
+    constexpr int CPR = BK / 4;                 // 16-byte chunks per row
+    constexpr int RPP = 256 / CPR;              // rows covered per pass of the 256 loaders
+    constexpr int XI = (BM + RPP - 1) / RPP, WI = (BN + RPP - 1) / RPP;
+    constexpr int NR = BK / 16;                 // MFMA rounds per k-tile
+    constexpr int STAGE = (BM + BN) * LD;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int tiles = p.MT * p.NT;
+    const int total = tiles * p.groups * p.ksplit;
+    const int b = xcd_remap(blockIdx.x, total);
+    const int z = b / tiles, t0 = b - z * tiles;
+    const int g = z / p.ksplit, ks = z - g * p.ksplit;
+    const int bn0 = (t0 / p.MT) * BN, bm0 = (t0 % p.MT) * BM;
+    const int KT = p.K / BK;                    // k-tiles of this instantiation
+    const int cch = p.Cin / BK;
+    const int kt0 = (int)((long)KT * ks / p.ksplit);
+    const int kt1 = (int)((long)KT * (ks + 1) / p.ksplit);
+
+    const float *__restrict__ xg = p.x + (long)g * p.x_gs;
+    const float *__restrict__ wg = p.w + (long)g * p.w_gs;
+
+    const int lr = tid / CPR, kc = tid % CPR;
+    int x_ih0[XI], x_iw0[XI];
+    long x_nb[XI];
+    bool x_ok[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = lr + RPP * i;
+        const int m = bm0 + row;
+        x_ok[i] = (row < BM) && (m < p.M);
+        const int mm = x_ok[i] ? m : 0;
+        const int n = mm / p.P, pix = mm - n * p.P;
+        const int oh = pix / p.OW, ow = pix - oh * p.OW;
+        x_ih0[i] = oh * p.stride - p.pad_h;
+        x_iw0[i] = ow * p.stride - p.pad_w;
+        x_nb[i] = (long)n * p.H * p.W * p.Cin + kc * 4;
+    }
+    long w_off[WI];
+    bool w_ok[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = lr + RPP * i;
+        const int co = bn0 + row;
+        w_ok[i] = (row < BN) && (co < p.Cout);
+        w_off[i] = (long)(w_ok[i] ? co : 0) * p.K + kc * 4;
+    }
+
+    // Loader state is incremental: a row's source pointer is recomputed only when the filter
+    // tap changes (every Cin/BK k-tiles, never for a 1x1 conv); inside a tap the next k-tile
+    // is just +BK floats.  Keeps the per-k-tile VALU work (exposed at one wave per SIMD) small.
+    f32x4 xr[XI], wr[WI];
+    const float *xp[XI];
+    bool xin[XI];
+    const float *wp[WI];
+    int cur_tap = kt0 / cch, cur_cc = kt0 - cur_tap * cch;
+    auto set_tap = [&](int tap) {
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int dh = kh * p.dil_h, dw = kw * p.dil_w;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int ih = x_ih0[i] + dh, iw = x_iw0[i] + dw;
+            xin[i] = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            xp[i] = xg + x_nb[i] + ((long)ih * p.W + iw) * p.Cin;
+        }
+    };
+    set_tap(cur_tap);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) wp[i] = wg + w_off[i] + (long)kt0 * BK;
+    auto load_tile = [&](bool advance) {        // loads the NEXT k-tile in sequence
+        const int c0 = cur_cc * BK;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (xin[i]) v = *(const f32x4 *)(xp[i] + c0);
+            xr[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            // rows >= Cout read row 0: they only feed accumulators that are never stored
+            wr[i] = *(const f32x4 *)wp[i];
+            wp[i] += advance ? BK : 0;
+        }
+        if (advance && ++cur_cc == cch) {
+            cur_cc = 0;
+            set_tap(++cur_tap);
+        }
+    };
+    auto store_tile = [&](int st) {
+        float *sX = smem + st * STAGE, *sW = sX + BM * LD;
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            if (BM % RPP == 0 || lr + RPP * i < BM) *(f32x4 *)(sX + (lr + RPP * i) * LD + kc * 4) = xr[i];
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+            if (BN % RPP == 0 || lr + RPP * i < BN) *(f32x4 *)(sW + (lr + RPP * i) * LD + kc * 4) = wr[i];
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int fx_off = (wm * TM * 16 + l15) * LD + quad * 4;
+    const int fw_off = BM * LD + (wn * TN * 16 + l15) * LD + quad * 4;
+    f32x4 fw[2][TN], fx[2][TM];
+    auto read_frags = [&](int st, int r, int slot) {
+        const float *base = smem + st * STAGE + r * 16;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fw[slot][i] = *(const f32x4 *)(base + fw_off + i * 16 * LD);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fx[slot][j] = *(const f32x4 *)(base + fx_off + j * 16 * LD);
+    };
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](int slot) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][i][c], fx[slot][j][c], acc[i][j], 0, 0, 0);
+    };
+
+    const int nt = kt1 - kt0;
+    if (nt > 0) {
+        load_tile(nt > 1);
+        store_tile(0);
+        if (nt > 1) load_tile(nt > 2);
+        __syncthreads();
+        read_frags(0, 0, 0);
+    }
+    int st = 0;                                   // stage holding tile t
+    for (int t = 0; t < nt; ++t) {
+        const int st1 = st == 2 ? 0 : st + 1;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
+            if (r == NR - 1) {                     // mid-tile hand-over sits before the LAST round
+                if (t + 1 < nt) store_tile(st1);
+                if (t + 2 < nt) load_tile(t + 3 < nt);
+                __syncthreads();                  // lowers to lgkmcnt(0) + s_barrier (no vmcnt drain)
+                if (t + 1 < nt) read_frags(st1, 0, 0);
+            }
+            mma(r & 1);
+        }
+        st = st1;
+    }
+
+    // ---- epilogue (same as v1)
+    if (p.ksplit > 1) {
+        float *wsg = p.ws + ((long)(ks * p.groups + g) * p.M) * p.Cout;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = bm0 + (wm * TM + j) * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+                if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
+                    *(f32x4 *)(wsg + (long)m * p.Cout + co) = acc[i][j];
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Cout) wsg[(long)m * p.Cout + co + e] = acc[i][j][e];
+                }
+            }
+        }
+        return;
+    }
+    const float *__restrict__ bg = p.bias ? p.bias + (long)g * p.b_gs : nullptr;
+    const float *__restrict__ rg = p.res ? p.res + (long)g * p.r_gs : nullptr;
+    float *__restrict__ yg = p.y + (long)g * p.y_gs;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = bm0 + (wm * TM + j) * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+            if (co >= p.Cout) continue;
+            f32x4 v = acc[i][j];
+            if (p.vec_store && co + 3 < p.Cout) {
+                if (bg) v += *(const f32x4 *)(bg + co);
+                if (rg) v += *(const f32x4 *)(rg + (long)m * p.res_cstride + p.res_coff + co);
+                const int a = co < p.act_split ? p.act : p.act2;
+                if (a != USOT_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a);
+                }
+                *(f32x4 *)(yg + (long)m * p.y_cstride + p.y_coff + co) = v;
+            } else {
+                const int n = m / p.P, pix = m - n * p.P;
+                for (int e = 0; e < 4; ++e) {
+                    const int c = co + e;
+                    if (c >= p.Cout) break;
+                    float s = v[e];
+                    if (bg) s += bg[c];
+                    if (rg) s += rg[(long)m * p.res_cstride + p.res_coff + c];
+                    s = apply_act(s, c < p.act_split ? p.act : p.act2);
+                    if (p.y_nchw) yg[((long)n * p.Cout + c) * p.P + pix] = s;
+                    else          yg[(long)m * p.y_cstride + p.y_coff + c] = s;
+                }
+            }
+        }
+    }
+}
+
 // split-K second pass: sum the partial slabs, then the same epilogue.
 __global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvK p)
 {
@@ -272,9 +506,10 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvK p)
     }
 }
 
-struct TileCfg { int bm, bn; void (*fn)(const ConvK); };
+struct TileCfg { int bm, bn, bk, stages; void (*fn)(const ConvK); };
 
-#define TILE(bm, bn, wm, wn) { bm, bn, conv_igemm_f32<bm, bn, wm, wn> }
+#define TILE(bm, bn, wm, wn) { bm, bn, 32, 2, conv_igemm_f32<bm, bn, wm, wn> }
+#define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, conv_igemm_f32_v2<bm, bn, wm, wn, bk> }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
     TILE(128, 64, 2, 2),    // 2
@@ -286,10 +521,17 @@ const TileCfg kTiles[] = {
     TILE(16, 64, 1, 4),     // 8: tiny M (template-side encoders)
     TILE(16, 128, 1, 4),    // 9
     TILE(32, 128, 2, 2),    // 10
-    { 128, 128, conv_igemm_f32<128, 128, 2, 2, 1> },   // 11 DBG: no global loads / LDS stores
-    { 128, 128, conv_igemm_f32<128, 128, 2, 2, 2> },   // 12 DBG: MFMA + barrier only
-    { 64, 64, conv_igemm_f32<64, 64, 2, 2, 1> },       // 13
-    { 64, 64, conv_igemm_f32<64, 64, 2, 2, 2> },       // 14
+    TILE2(128, 128, 2, 2, 32),  // 11: v2 (3-stage, mid-tile barrier)
+    TILE2(64, 64, 2, 2, 32),    // 12
+    TILE2(64, 64, 2, 2, 64),    // 13
+    TILE2(32, 64, 2, 2, 32),    // 14
+    TILE2(32, 64, 2, 2, 64),    // 15
+    TILE2(32, 32, 2, 2, 64),    // 16
+    TILE2(64, 128, 2, 2, 32),   // 17
+    TILE2(128, 64, 2, 2, 32),   // 18
+    TILE2(32, 128, 2, 2, 32),   // 19
+    TILE2(16, 64, 1, 4, 64),    // 20
+    TILE2(64, 32, 2, 2, 64),    // 21
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -365,7 +607,6 @@ extern "C" int usot_conv2d_f32(void *stream, const usot_conv_desc *d)
     p.K = d->KH * d->KW * d->Cin;
     p.cchunks = d->Cin / 32;
     p.KT = d->KH * d->KW * p.cchunks;
-    if (ksplit > p.KT) return USOT_EINVAL;
     p.vec_store = !d->y_nchw && (p.y_cstride % 4 == 0) && (p.y_coff % 4 == 0) &&
                   (!d->res || (p.res_cstride % 4 == 0 && p.res_coff % 4 == 0)) &&
                   ((uintptr_t)d->y % 16 == 0) && (!d->res || (uintptr_t)d->res % 16 == 0) &&
@@ -378,11 +619,21 @@ extern "C" int usot_conv2d_f32(void *stream, const usot_conv_desc *d)
     if (tile == 0) tile = pick_tile(d, p.M);
     if (tile < 1 || tile > kNumTiles) return USOT_EINVAL;
     const TileCfg &tc = kTiles[tile - 1];
+    if (d->Cin % tc.bk) return USOT_EINVAL;
+    if (ksplit > p.K / tc.bk) return USOT_EINVAL;
     p.MT = (p.M + tc.bm - 1) / tc.bm;
     p.NT = (d->Cout + tc.bn - 1) / tc.bn;
     const long blocks = (long)p.MT * p.NT * p.groups * ksplit;
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
-    const size_t lds = (size_t)2 * (tc.bm + tc.bn) * LDK * sizeof(float);
+    const size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * (tc.bk + 4) * sizeof(float);
+    if (lds > 64 * 1024) {
+        static bool raised[64] = {false};
+        if (!raised[tile]) {
+            if (hipFuncSetAttribute((const void *)tc.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return USOT_ELAUNCH;
+            raised[tile] = true;
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(tc.fn, dim3((unsigned)blocks), dim3(256), lds, s, p);
     if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
