@@ -11,9 +11,12 @@ ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--size', type=int, default=255)
 ap.add_argument('--mem', type=int, default=7)
 ap.add_argument('--frames', type=int, default=20)
+ap.add_argument('--lanes', type=int, default=0)
+ap.add_argument('--quiet', action='store_true')
 a = ap.parse_args()
 KINDS = ['conv', 'stem', 'maxpool', 'groupdw', 'conf_reduce', 'prroi', 'permute', 'decode', 'fork', 'join']
 m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to('cuda:0')
+m.engine_options['lanes'] = a.lanes
 B = a.batch
 t = lambda x: torch.from_numpy(x).cuda()
 m.pr_pool = False

@@ -22,24 +22,30 @@ dev = torch.device('cuda:0')
 m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to(dev)
 W = Weights(m, dev)
 shapes = {}
+
+
+def collect(bld, B, size):
+    x = bld.buf(B, 3, size, size)
+    xf, hf = bld.backbone(x, B, size)
+    if size == 127:
+        zf = bld.buf(B, 7, 7, 256)
+        bld.encode_kernel(zf, B, 512, 'z')
+    else:
+        zk = [bld.buf(B, hk, wk, 512) for hk, wk in ((5, 5), (3, 5), (5, 3))]
+        mem = bld.buf(B * 7, 7, 7, 256)
+        bld.heads(xf, B, hf, zk, mem, 7)
+        bld.heads(xf, B, hf, zk, None, 0)
+    for g in bld.geoms:
+        oh = (g['H'] + 2 * g['pad'][0] - g['dil'][0] * (g['KH'] - 1) - 1) // g['stride'] + 1
+        ow = (g['W'] + 2 * g['pad'][1] - g['dil'][1] * (g['KW'] - 1) - 1) // g['stride'] + 1
+        key = (g['N'] * oh * ow, g['Cout'], g['KH'] * g['KW'] * g['Cin'], g['groups'])
+        shapes.setdefault(key, g)
+
+
 for B in a.batch:
     for size in a.sizes:
-        bld = Builder(W, {})
-        x = bld.buf(B, 3, size, size)
-        xf, hf = bld.backbone(x, B, size)
-        if size == 127:
-            zf = bld.buf(B, 7, 7, 256)
-            bld.encode_kernel(zf, B, 512, 'z')
-        else:
-            zk = [bld.buf(B, hk, wk, 512) for hk, wk in ((5, 5), (3, 5), (5, 3))]
-            mem = bld.buf(B * 7, 7, 7, 256)
-            bld.heads(xf, B, hf, zk, mem, 7)
-        for g in bld.geoms:
-            key = (g['N'] * ((g['H'] + 2 * g['pad'][0] - g['dil'][0] * (g['KH'] - 1) - 1) // g['stride'] + 1)
-                   * ((g['W'] + 2 * g['pad'][1] - g['dil'][1] * (g['KW'] - 1) - 1) // g['stride'] + 1),
-                   g['Cout'], g['KH'] * g['KW'] * g['Cin'], g['groups'])
-            shapes.setdefault(key, g)
-        del bld
+        for lanes in (0, 2):
+            collect(Builder(W, {}, lanes), B, size)
 tiles = hip.tile_table()
 L = hip.lib()
 table = {}
@@ -72,13 +78,20 @@ for key, g in sorted(shapes.items()):
                               res=res.data_ptr() if res is not None else None, act=1, groups=groups,
                               x_gs=N * H * Wd * Cin, w_gs=Cout * K, b_gs=Cout, y_gs=M * Cout, r_gs=M * Cout,
                               ksplit=ks, tile=tile, ws=ws.data_ptr() if ws is not None else None)
-            for _ in range(2):
-                hip.check(L.usot_conv2d_f32(hip.stream(), C.byref(d)))
-            e0.record()
+            hip.check(L.usot_conv2d_f32(hip.stream(), C.byref(d)))
+            # time through a native plan (C++ launch loop): Python's ~6 us per ctypes call would
+            # otherwise floor every short kernel to the same number
+            plan = C.c_void_p(L.usot_plan_create())
             for _ in range(a.reps):
-                L.usot_conv2d_f32(hip.stream(), C.byref(d))
-            e1.record(); torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / a.reps * 1e3
+                hip.check(L.usot_plan_add_conv(plan, C.byref(d)))
+            best_us = 1e30
+            for _ in range(3):
+                e0.record()
+                hip.check(L.usot_plan_run(plan, hip.stream()))
+                e1.record(); torch.cuda.synchronize()
+                best_us = min(best_us, e0.elapsed_time(e1) / a.reps * 1e3)
+            L.usot_plan_destroy(plan)
+            us = best_us
             rows.append((us, tile, ks))
             if best is None or us < best[0]:
                 best = (us, tile, ks)

@@ -152,11 +152,12 @@ class Plan:
 class Builder:
     """Allocates static buffers and appends ops to a plan."""
 
-    def __init__(self, weights, tuning=None):
+    def __init__(self, weights, tuning=None, lanes=True):
         self.W = weights
         self.dev = weights.device
         self.plan = Plan()
         self.tuning = tuning or {}
+        self.lanes = int(lanes)
         self.log = []           # (name, M, N, K, groups, macs) per conv, for benchmarks
         self.geoms = []         # full geometry per conv, for the tuner
 
@@ -165,8 +166,20 @@ class Builder:
         self.plan.keep.append(t)
         return t
 
+    # lane levels: 1 = memory-kernel side beside the backbone; 2 = + memory head beside the
+    # reg/cls heads; 3 = + shortcut convs, the three search encoders, the prediction convs.
+    # Every fork/join is a cross-queue dependency in the captured graph (several us each on
+    # this stack), so fine-grained lanes cost more than they hide — measured, see DESIGN.md.
+    def fork(self, lane, level=3):
+        if self.lanes >= level:
+            self.plan.fork(lane)
+
+    def join(self, lane, level=3):
+        if self.lanes >= level:
+            self.plan.join(lane)
+
     def conv(self, name, pc, x, n, h, w, *, cout=None, act=ACT_NONE, res=None, y=None, y_cstride=0, y_coff=0,
-             act2=ACT_NONE, act_split=0, y_nchw=False, groups=1, x_gs=0, y_gs=0, w_rows=None):
+             act2=ACT_NONE, act_split=0, y_nchw=False, groups=1, x_gs=0, y_gs=0, w_rows=None, row0=0):
         """x: tensor (NHWC dense, channels == pc.cin).  Returns (y, oh, ow)."""
         cout = cout or pc.cout
         oh, ow = pc.out_hw(h, w)
@@ -180,7 +193,7 @@ class Builder:
         ws = None
         if ksplit > 1:
             ws = self.buf(ksplit * groups * m * cout)
-        d = hip.conv_desc(x.data_ptr(), pc.w.data_ptr(), pc.b.data_ptr(), y.data_ptr(),
+        d = hip.conv_desc(x.data_ptr(), pc.w.data_ptr() + row0 * k * 4, pc.b.data_ptr() + row0 * 4, y.data_ptr(),
                           N=n, H=h, W=w, Cin=pc.cin, OH=oh, OW=ow, Cout=cout, KH=pc.kh, KW=pc.kw,
                           stride=pc.stride, pad=pc.pad, dil=pc.dil,
                           res=res.data_ptr() if res is not None else None, act=act, act2=act2,
@@ -209,12 +222,16 @@ class Builder:
         cur, h = p0, ph
         stages = [s0]
         for bi, (c1, c2, c3, ds) in enumerate(W.blocks):
+            sc = cur
+            if ds is not None:                    # shortcut conv runs beside conv1 -> conv2
+                self.fork(1)
+                sc, hs, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
+                self.fork(0)
             t1, _, _ = self.conv('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU)
             t2, h2, _ = self.conv('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
-            sc = cur
             if ds is not None:
-                sc, hs, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
                 assert hs == h2
+                self.join(1)
             cur, _, _ = self.conv('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc)
             h = h2
             if bi in (2, 6, 12):                      # ends of layer1 / layer2 / layer3
@@ -244,39 +261,71 @@ class Builder:
         hip.check(hip.lib().usot_plan_add_groupdw_multi(self.plan.h, arr, len(descs)), 'plan_add_groupdw_multi')
 
     # ---- a9: heads.  xf NHWC [b,hf,hf,256]; zk: 3 maps [b,hk,wk,512]; mem_nhwc [b*m,7,7,256] or None
-    def heads(self, xf, b, hf, zk, mem_nhwc, m):
+    # `mk` may be passed when the memory-kernel encodes were already issued (on a side lane).
+    def heads(self, xf, b, hf, zk, mem_nhwc, m, mk=None, mem_lane=None):
         W, L = self.W, hip.lib()
-        es = []
-        for g in range(3):
-            y, oh, ow = self.conv('enc_s%d' % g, W.enc_s[g], xf, b, hf, hf, act=ACT_RELU)
-            es.append(y)
+        es = [None] * 3
+        for g, lane in ((1, 1), (2, 3), (0, 0)):          # three encoder geometries side by side
+            self.fork(lane)
+            es[g], _, _ = self.conv('enc_s%d' % g, W.enc_s[g], xf, b, hf, hf, act=ACT_RELU)
+        self.join(1)
+        self.join(3)
         S = hf - 6                                    # response size (25 for 31, 27 for 33)
-        ngroups = 3 if mem_nhwc is not None else 2
+        has_mem = mem_nhwc is not None
+        ngroups = 3 if has_mem else 2
         tin = self.buf(ngroups, b, S, S, 256)         # tower inputs: [reg, cls, (memory)]
         segs = [self.groupdw(es, zk, tin[0], W.reg_wsm, b, 1, S, S, 256, 512),
                 self.groupdw(es, zk, tin[1], W.cls_wsm, b, 1, S, S, 0, 512)]
-        if mem_nhwc is not None:
-            mk = self.encode_kernel(mem_nhwc, b * m, 256, 'mem')
+        if has_mem:
+            if mk is None:
+                mk = self.encode_kernel(mem_nhwc, b * m, 256, 'mem')
+            elif mem_lane is not None:
+                self.join(mem_lane, 1)
             dwm = self.buf(b * m, S, S, 256)
             segs.append(self.groupdw(es, mk, dwm, W.cls_wsm, b * m, m, S, S, 0, 256))
         self.groupdw_flush(segs)
-        if mem_nhwc is not None:
+        gs = b * S * S * 256
+        tout = [self.buf(ngroups, b, S, S, 256) for _ in range(4)]
+        bbox = self.buf(b, 4, S, S)
+        cls2 = self.buf(ngroups - 1, b, 1, S, S)      # [cls, (cls_mem)]
+        if has_mem and self.lanes < 2:
+            # serial schedule: one 3-group launch per tower level (fewest launches)
             cv, _, _ = self.conv('conf_fusion', W.conf, dwm, b * m, S, S, act=ACT_CONF, act2=ACT_RELU, act_split=256)
             hip.check(L.usot_plan_add_conf_reduce(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256),
                       'plan_add_conf_reduce')
+            cur = tin
+            for i in range(4):
+                self.conv('tower%d' % i, W.tower[i], cur, b, S, S, cout=256, act=ACT_RELU, y=tout[i], groups=3,
+                          x_gs=gs, y_gs=gs)
+                cur = tout[i]
+            self.conv('bbox_pred', W.bbox_pred, cur[0], b, S, S, act=ACT_EXP, y=bbox, y_nchw=True)
+            self.conv('cls_preds', W.cls_preds, cur[1], b, S, S, cout=1, y=cls2, y_nchw=True, groups=2,
+                      x_gs=gs, y_gs=b * S * S, w_rows=1)
+            return bbox, cls2, S
+        if has_mem:
+            # lane 1: confidence/value conv -> fusion -> memory tower -> cls_mem;  lane 0: reg + cls
+            self.fork(1, 2)
+            cv, _, _ = self.conv('conf_fusion', W.conf, dwm, b * m, S, S, act=ACT_CONF, act2=ACT_RELU, act_split=256)
+            hip.check(L.usot_plan_add_conf_reduce(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256),
+                      'plan_add_conf_reduce')
+            cur = tin[2]
+            for i in range(4):
+                self.conv('tower%d.mem' % i, W.tower[i], cur, b, S, S, cout=256, act=ACT_RELU, y=tout[i][2], row0=512)
+                cur = tout[i][2]
+            self.conv('cls_mem_pred', W.cls_preds, cur, b, S, S, cout=1, y=cls2[1], y_nchw=True, row0=1)
+            self.fork(0, 2)
         cur = tin
-        gs = b * S * S * 256
         for i in range(4):
-            nxt = self.buf(ngroups, b, S, S, 256)
-            self.conv('tower%d' % i, W.tower[i], cur, b, S, S, cout=256, act=ACT_RELU, y=nxt, groups=ngroups,
+            self.conv('tower%d' % i, W.tower[i], cur, b, S, S, cout=256, act=ACT_RELU, y=tout[i], groups=2,
                       x_gs=gs, y_gs=gs)
-            cur = nxt
-        bbox = self.buf(b, 4, S, S)
+            cur = tout[i]
+        self.fork(3)
         self.conv('bbox_pred', W.bbox_pred, cur[0], b, S, S, act=ACT_EXP, y=bbox, y_nchw=True)
-        ncls = ngroups - 1
-        cls2 = self.buf(ncls, b, 1, S, S)             # [cls, (cls_mem)]
-        self.conv('cls_preds', W.cls_preds, cur[1], b, S, S, cout=1, y=cls2, y_nchw=True, groups=ncls,
-                  x_gs=gs, y_gs=b * S * S, w_rows=1)
+        self.fork(0)
+        self.conv('cls_pred', W.cls_preds, cur[1], b, S, S, cout=1, y=cls2[0], y_nchw=True)
+        self.join(3)
+        if has_mem:
+            self.join(1, 2)
         return bbox, cls2, S
 
 
@@ -302,13 +351,14 @@ def load_tuning(path=None):
 class Engine:
     """Per-model, per-device executor with cached plans.  Stateless w.r.t. tracking."""
 
-    def __init__(self, model, device, graphs=True, tuning=None):
+    def __init__(self, model, device, graphs=True, tuning=None, lanes=0):
         if torch.device(device).type != 'cuda':
             raise hip.HipError('the USOT HIP engine needs a GPU device; got %s (no CPU fallback)' % (device,))
         hip.lib()
         self.device = torch.device(device)
         self.W = Weights(model, self.device)
         self.graphs = graphs
+        self.lanes = int(lanes) if graphs else 0   # lanes only exist as parallel branches of a captured graph
         self.tuning = load_tuning() if tuning is None else tuning
         self._feat = {}       # (n, size) -> dict(x, xf, h, plan)
         self._zenc = {}       # n -> dict(zf, zk, plan)
@@ -319,7 +369,7 @@ class Engine:
     def _feat_plan(self, n, size):
         key = (n, size)
         if key not in self._feat:
-            bld = Builder(self.W, self.tuning)
+            bld = Builder(self.W, self.tuning, self.lanes)
             x = bld.buf(n, 3, size, size)
             xf, h = bld.backbone(x, n, size)
             self._finish(bld.plan)
@@ -348,7 +398,7 @@ class Engine:
         """zf NCHW-shaped [n,256,7,7] (any strides) -> cached merged cls|reg kernel maps."""
         n = zf_nchw.shape[0]
         if n not in self._zenc:
-            bld = Builder(self.W, self.tuning)
+            bld = Builder(self.W, self.tuning, self.lanes)
             zf = bld.buf(n, 7, 7, 256)
             zk = bld.encode_kernel(zf, n, 512, 'z')
             self._finish(bld.plan)
@@ -388,12 +438,17 @@ class Engine:
     def _track_plan(self, b, size, m):
         key = (b, size, m)
         if key not in self._track:
-            bld = Builder(self.W, self.tuning)
+            bld = Builder(self.W, self.tuning, self.lanes)
             x = bld.buf(b, 3, size, size)
+            mem = bld.buf(b * m, 7, 7, 256) if m else None
+            mk = None
+            if m:
+                bld.fork(2, 1)
+                mk = bld.encode_kernel(mem, b * m, 256, 'mem')
+                bld.fork(0, 1)
             xf, hf = bld.backbone(x, b, size)
             zk = self._zenc[b]['zk']
-            mem = bld.buf(b * m, 7, 7, 256) if m else None
-            bbox, cls2, S = bld.heads(xf, b, hf, zk, mem, m)
+            bbox, cls2, S = bld.heads(xf, b, hf, zk, mem, m, mk=mk, mem_lane=2 if m else None)
             self._finish(bld.plan)
             self._track[key] = dict(x=x, xf=xf, hf=hf, mem=mem, bbox=bbox, cls2=cls2, S=S, plan=bld.plan,
                                     log=bld.log)
@@ -475,16 +530,19 @@ class Session:
 
     def _build(self):
         e, L = self.e, hip.lib()
-        bld = Builder(e.W, e.tuning)
+        bld = Builder(e.W, e.tuning, e.lanes)
         pl = bld.plan
         self.x = bld.buf(1, 3, self.size, self.size)
         self.mem_in = bld.buf(7, 7, 7, 256)
         tsz_dev = self.ctl[0:16].view(torch.float64)
         idx_dev = self.ctl[16:48].view(torch.int32)          # 7 gather rows + 1 scatter row
+        bld.fork(2, 1)                               # memory-kernel side runs beside the backbone
         hip.check(L.usot_plan_add_rows_copy(pl.h, hip.ptr(self.bank), hip.ptr(idx_dev), hip.ptr(self.mem_in),
                                             7, Session.ROW, 0), 'plan_add_rows_copy')
+        mk = bld.encode_kernel(self.mem_in, 7, 256, 'mem')
+        bld.fork(0, 1)
         xf, hf = bld.backbone(self.x, 1, self.size)
-        bbox, cls2, S = bld.heads(xf, 1, hf, self.zk, self.mem_in, 7)
+        bbox, cls2, S = bld.heads(xf, 1, hf, self.zk, self.mem_in, 7, mk=mk, mem_lane=2)
         assert S == self.S
         self.roi = bld.buf(5)
         self.feat = bld.buf(1, 7, 7, 256)

@@ -30,7 +30,7 @@ class USOT_(nn.Module):
         self.mem_size = mem_size
         self.pr_pool = pr_pool
         self._engine = None
-        self.engine_options = {'graphs': True, 'tuning': None}
+        self.engine_options = {'graphs': True, 'tuning': None, 'lanes': 0}
         self.grids()
 
     # ------------------------------------------------------------------ engine lifetime
