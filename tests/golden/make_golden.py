@@ -323,20 +323,64 @@ def do_e2e():
     net, _ = build(calibrated=True)
     net.eval()
     out = {}
-    for vid, (seed, nframes, sz) in enumerate(((11, 6, (52.0, 38.0)), (12, 4, (16.0, 12.0)))):
+    # A trajectory is only a meaningful fixture if every frame's argmax is decided by a clear
+    # margin: two fp32 implementations agree to ~1e-4 on the maps, so a frame whose two best
+    # cells are closer than that can legitimately go either way.  Record the margin per frame
+    # and search seeds until every frame of the video has top-1 minus top-2 > MARGIN.
+    MARGIN = 4e-3
+    margins = []
+    orig_track = net.track
+
+    def spy(x, template_mem=None, score_mem=None):
+        res = orig_track(x, template_mem=template_mem, score_mem=score_mem)
+        cls, bbox, cmem, xf = res
+        p = spy.p
+        S = p.score_size
+        sig = lambda a: 1.0 / (1.0 + np.exp(-a.numpy().reshape(S, S).astype(np.float32)))
+        score = p.ratio * sig(cls) + (1 - p.ratio) * sig(cmem)
+        hy = orc.Hyper(p.instance_size)
+        gx, gy, _, _ = orc.grids(hy)
+        b = bbox.numpy()[0]
+        x1, y1, x2, y2 = gx - b[0], gy - b[1], gx + b[2], gy + b[3]
+        t = spy.tsz
+        ch = lambda r: np.maximum(r, 1.0 / r)
+        szf = lambda w, h: np.sqrt((w + (w + h) * 0.5) * (h + (w + h) * 0.5))
+        pen = np.exp(-(ch((t[0] / t[1]) / ((x2 - x1) / (y2 - y1))) * ch(szf(x2 - x1, y2 - y1) / szf(t[0], t[1])) - 1) * p.penalty_k)
+        win = np.outer(np.hanning(S), np.hanning(S))
+        ps = np.sort((pen * score * (1 - p.window_influence) + win * p.window_influence).reshape(-1))
+        margins.append(float(ps[-1] - ps[-2]))
+        return res
+    net.track = spy
+    wanted = [(255, 6, (52.0, 38.0)), (271, 4, (16.0, 12.0))]
+    vid, seed = 0, 10
+    while vid < len(wanted) and seed < 80:
+        seed += 1
+        inst_want, nframes, sz = wanted[vid]
         trk = rt.USOTTracker(_Info())
+        del margins[:]
         with torch.no_grad():
             im, (cx, cy) = synth.frame(seed, t=0)
             state = trk.init(im, np.array([cx, cy]), np.array(sz), net)
+            spy.p = state['p']
             rows = [[cx, cy, sz[0], sz[1], 0.0]]
             for f in range(1, nframes):
                 im, _ = synth.frame(seed, t=f)
+                s_x_scale = state['p'].exemplar_size / np.sqrt(
+                    (state['target_sz'][0] + 0.5 * sum(state['target_sz'])) * (state['target_sz'][1] + 0.5 * sum(state['target_sz'])))
+                spy.tsz = np.asarray(state['target_sz']) * s_x_scale
                 state = trk.track(state, im)
                 rows.append([*state['target_pos'], *state['target_sz'], float(state['cls_score'])])
+        ok = state['p'].instance_size == inst_want and min(margins) > MARGIN
+        print('seed', seed, 'instance', state['p'].instance_size, 'min margin %.2e' % min(margins), 'OK' if ok else 'skip')
+        if not ok:
+            continue
         out['video%d/seed_frames_sz' % vid] = np.array([seed, nframes, *sz])
         out['video%d/track' % vid] = np.array(rows, np.float64)
         out['video%d/instance_size' % vid] = np.array(state['p'].instance_size)
-        print('video', vid, 'instance', state['p'].instance_size, '\n', np.array(rows))
+        out['video%d/margins' % vid] = np.array(margins)
+        print(np.array(rows))
+        vid += 1
+    assert vid == len(wanted), 'no seed with clear margins found'
     np.savez_compressed(os.path.join(GOLD, 'golden_e2e.npz'), **out)
 
 

@@ -64,8 +64,8 @@ def test_trajectory_vs_reference_tracker(net, vid, fused):
 
 
 def test_fused_equals_generic(net):
-    a, _ = run(net, 13, 8, (40.0, 30.0), False)
-    b, sb = run(net, 13, 8, (40.0, 30.0), True)
+    a, _ = run(net, 12, 8, (52.0, 38.0), False)
+    b, sb = run(net, 12, 8, (52.0, 38.0), True)
     np.testing.assert_allclose(a, b, atol=1e-3, rtol=0)
     # the session's bank rows are the memory features the generic path keeps as tensors
     assert sb['session'].n == 8
