@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p)
 //     MFMA round 1 (F1)
 // so the global-load latency has a whole k-tile to land, the LDS write is off the critical
 // path, and no MFMA ever waits for a just-issued ds_read.
-template <int BM, int BN, int WM, int WN, int BK>
-__global__ __launch_bounds__(256) void conv_igemm_f32_v2(const ConvK p)
+template <int BM, int BN, int WM, int WN, int BK, int KSW = 1>
+__global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvK p)
 {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     static_assert(BK == 32 || BK == 64, "k-tile of 32 or 64");
@@ -276,9 +276,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2(const ConvK p)
     constexpr int NR = BK / 16;                 // MFMA rounds per k-tile
     constexpr int STAGE = (BM + BN) * LD;
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // KSW > 1: the workgroup has KSW groups of 4 wavefronts that share ONE output tile and
+    // split its k-tiles round-robin (group g takes kt0+g, kt0+g+KSW, ...), each with its own
+    // LDS stages; partial accumulators meet in LDS at the end.  Two (or four) waves per SIMD
+    // from the same tile hide each other's staging without a cross-workgroup reduction, a
+    // workspace round trip or a second launch (what inter-workgroup split-K costs).
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int grp = KSW > 1 ? (int)(threadIdx.x >> 8) : 0;
+    float *smem = smem_all + grp * 3 * STAGE;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;
     const int tiles = p.MT * p.NT;
     const int total = tiles * p.groups * p.ksplit;
     const int b = xcd_remap(blockIdx.x, total);
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2(const ConvK p)
     const float *xp[XI];
     bool xin[XI];
     const float *wp[WI];
-    int cur_tap = kt0 / cch, cur_cc = kt0 - cur_tap * cch;
+    int cur_tap = (kt0 + grp) / cch, cur_cc = (kt0 + grp) - cur_tap * cch;
     auto set_tap = [&](int tap) {
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         const int dh = kh * p.dil_h, dw = kw * p.dil_w;
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2(const ConvK p)
     };
     set_tap(cur_tap);
 #pragma unroll
-    for (int i = 0; i < WI; ++i) wp[i] = wg + w_off[i] + (long)kt0 * BK;
+    for (int i = 0; i < WI; ++i) wp[i] = wg + w_off[i] + (long)(kt0 + grp) * BK;
     auto load_tile = [&](bool advance) {        // loads the NEXT k-tile in sequence
         const int c0 = cur_cc * BK;
 #pragma unroll
@@ -352,11 +359,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2(const ConvK p)
         for (int i = 0; i < WI; ++i) {
             // rows >= Cout read row 0: they only feed accumulators that are never stored
             wr[i] = *(const f32x4 *)wp[i];
-            wp[i] += advance ? BK : 0;
+            wp[i] += advance ? KSW * BK : 0;
         }
-        if (advance && ++cur_cc == cch) {
-            cur_cc = 0;
-            set_tap(++cur_tap);
+        if (advance) {
+            cur_cc += KSW;
+            if (cur_cc >= cch) {
+                do { cur_cc -= cch; ++cur_tap; } while (cur_cc >= cch);
+                set_tap(cur_tap);
+            }
         }
     };
     auto store_tile = [&](int st) {
@@ -397,7 +407,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2(const ConvK p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][i][c], fx[slot][j][c], acc[i][j], 0, 0, 0);
     };
 
-    const int nt = kt1 - kt0;
+    const int nt_all = kt1 - kt0;
+    const int nt = (nt_all - grp + KSW - 1) / KSW;      // k-tiles of this wave group
+    const int nt_max = (nt_all + KSW - 1) / KSW;        // barriers must match across groups
+    if (KSW > 1 && nt <= 0) __syncthreads();
     if (nt > 0) {
         load_tile(nt > 1);
         store_tile(0);
@@ -406,7 +419,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2(const ConvK p)
         read_frags(0, 0, 0);
     }
     int st = 0;                                   // stage holding tile t
-    for (int t = 0; t < nt; ++t) {
+    for (int t = 0; t < nt_max; ++t) {
+        if (KSW > 1 && t >= nt) {                 // this group is out of k-tiles: keep the barrier count
+            __syncthreads();
+            continue;
+        }
         const int st1 = st == 2 ? 0 : st + 1;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -422,6 +439,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2(const ConvK p)
         st = st1;
     }
 
+    if (KSW > 1) {
+        // meet in LDS: thread (lane, wave) of every group holds the same (channel, pixel) slots
+        __syncthreads();
+        f32x4 *red = (f32x4 *)smem_all;
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) red[(((grp - 1) * TN + i) * TM + j) * 256 + tid] = acc[i][j];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g2 = 1; g2 < KSW; ++g2)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] += red[(((g2 - 1) * TN + i) * TM + j) * 256 + tid];
+    }
     // ---- epilogue (same as v1)
     if (p.ksplit > 1) {
         float *wsg = p.ws + ((long)(ks * p.groups + g) * p.M) * p.Cout;
@@ -506,10 +542,11 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvK p)
     }
 }
 
-struct TileCfg { int bm, bn, bk, stages; void (*fn)(const ConvK); };
+struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvK); };
 
-#define TILE(bm, bn, wm, wn) { bm, bn, 32, 2, conv_igemm_f32<bm, bn, wm, wn> }
-#define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, conv_igemm_f32_v2<bm, bn, wm, wn, bk> }
+#define TILE(bm, bn, wm, wn) { bm, bn, 32, 2, 1, conv_igemm_f32<bm, bn, wm, wn> }
+#define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v2<bm, bn, wm, wn, bk> }
+#define TILE3(bm, bn, wm, wn, bk, ksw) { bm, bn, bk, 3, ksw, conv_igemm_f32_v2<bm, bn, wm, wn, bk, ksw> }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
     TILE(128, 64, 2, 2),    // 2
@@ -532,6 +569,13 @@ const TileCfg kTiles[] = {
     TILE2(32, 128, 2, 2, 32),   // 19
     TILE2(16, 64, 1, 4, 64),    // 20
     TILE2(64, 32, 2, 2, 64),    // 21
+    TILE3(32, 64, 2, 2, 64, 2), // 22: in-workgroup k-split, 8 waves
+    TILE3(32, 32, 2, 2, 64, 2), // 23
+    TILE3(32, 32, 2, 2, 32, 4), // 24: 16 waves
+    TILE3(64, 64, 2, 2, 32, 2), // 25
+    TILE3(16, 64, 1, 4, 64, 2), // 26
+    TILE3(32, 64, 2, 2, 32, 2), // 27
+    TILE3(16, 64, 1, 4, 32, 4), // 28
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -625,7 +669,7 @@ extern "C" int usot_conv2d_f32(void *stream, const usot_conv_desc *d)
     p.NT = (d->Cout + tc.bn - 1) / tc.bn;
     const long blocks = (long)p.MT * p.NT * p.groups * ksplit;
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
-    const size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * (tc.bk + 4) * sizeof(float);
+    const size_t lds = (size_t)tc.ksw * tc.stages * (tc.bm + tc.bn) * (tc.bk + 4) * sizeof(float);
     if (lds > 64 * 1024) {
         static bool raised[64] = {false};
         if (!raised[tile]) {
@@ -635,7 +679,7 @@ extern "C" int usot_conv2d_f32(void *stream, const usot_conv_desc *d)
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(tc.fn, dim3((unsigned)blocks), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(tc.fn, dim3((unsigned)blocks), dim3(256 * tc.ksw), lds, s, p);
     if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
     if (ksplit > 1) {
         const long total = (long)p.M * p.Cout * p.groups;

@@ -47,30 +47,35 @@ struct GdwK {
     int total;         // samples over all segments
 };
 
-template <int RS, int CW>
-__global__ __launch_bounds__(256) void groupdw_nhwc_kernel(const GdwK p)
+template <int RS, int CW, int WPS>
+__global__ __launch_bounds__(256, WPS) void groupdw_nhwc_kernel(const GdwK p)
 {
     // Work unit = (sample, patch); channel group = 64 lanes.  With C = 256 the 1-D grid is
-    // laid out so that XCD x (= block id % 8, observed dispatch order; speed only) always
-    // works on channel group x % 4: each XCD's L2 then holds one quarter of the search maps
-    // instead of every XCD pulling all of them across the fabric.
+    // laid out so that XCD x (= block id % 8, observed dispatch order; speed only) works on
+    // channel group x % 4 of the samples with parity x / 4: all 25 patches of one
+    // (sample, channel group) meet in ONE XCD's L2, so the 3.2x halo re-reads between
+    // neighbouring patches are L2 hits and HBM sees each search element once.
     const int ntile = p.nty * p.ntx;
-    const int units = p.total * ntile;
     const int wave = threadIdx.x >> 6;
-    int cgi, unit;
+    int cgi, s, tile;
     if (p.C == 256) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int half = xcd >> 2;
         cgi = xcd & 3;
-        unit = (slot * 4 + wave) * 2 + (xcd >> 2);
+        const int v = slot * 4 + wave;
+        const int sl = v / ntile;
+        tile = v - sl * ntile;
+        s = sl * 2 + half;
     } else {
         const int ncg = p.C >> 6;
         cgi = blockIdx.x % ncg;
-        unit = (blockIdx.x / ncg) * 4 + wave;
+        const int v = (blockIdx.x / ncg) * 4 + wave;
+        s = v / ntile;
+        tile = v - s * ntile;
     }
-    if (unit >= units) return;
+    if (s >= p.total) return;
     const int c = cgi * 64 + (threadIdx.x & 63);
-    int s = unit / ntile, sg = 0;
-    const int tile = unit - s * ntile;
+    int sg = 0;
     while (sg + 1 < p.nseg && s >= p.seg[sg].S) { s -= p.seg[sg].S; ++sg; }
     const GdwSeg &g = p.seg[sg];
     const int i0 = (tile / p.ntx) * RS, j0 = (tile % p.ntx) * CW;
@@ -168,6 +173,228 @@ __global__ __launch_bounds__(256) void groupdw_nhwc_kernel(const GdwK p)
 #pragma unroll
         for (int j = 0; j < CW; ++j)
             if (i0 + i < p.OH && j0 + j < p.OW) o[((long)(i0 + i) * p.OW + j0 + j) * p.C] = acc[i][j];
+}
+
+// Column-thread variant: a thread owns one channel and ONE output column j (all OH rows,
+// OH <= 32).  For each of the template's columns v it loads search column j+v once (a run of
+// independent loads), then for each template row u streams 25 FMAs against one tap register.
+// ~80 VGPRs -> 6 waves per SIMD: latency is hidden by occupancy instead of by a huge
+// unrolled register window (the patch variant needs 256 VGPRs and runs 1 wave per SIMD).
+template <int HK, int WK>
+__device__ __forceinline__ void gdw_col_branch(float (&acc)[32], const float *__restrict__ x, int H, int W, int cs,
+                                               const float *__restrict__ z, int zcs, float wsm, int j, int OH)
+{
+#pragma unroll 1          // one search column live at a time: keeps the kernel at ~80 VGPRs
+    for (int v = 0; v < WK; ++v) {
+        float col[36];
+        const int cidx = min(j + v, W - 1);
+#pragma unroll
+        for (int r = 0; r < 36; ++r)
+            if (r < H) col[r] = x[((long)r * W + cidx) * cs];
+#pragma unroll
+        for (int u = 0; u < HK; ++u) {
+            const float k = wsm * z[(u * WK + v) * zcs];
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (i < OH) acc[i] = fmaf(col[i + u], k, acc[i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void groupdw_nhwc_col_kernel(const GdwK p)
+{
+    // blocks: 4 adjacent columns x 64 channels; XCD x%8 -> channel group x%4, sample parity x/4
+    const int wave = threadIdx.x >> 6;
+    const int ncolg = (p.OW + 3) / 4;
+    int cgi, s, colg;
+    if (p.C == 256) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        cgi = xcd & 3;
+        const int sl = slot / ncolg;
+        colg = slot - sl * ncolg;
+        s = sl * 2 + (xcd >> 2);
+    } else {
+        const int ncg = p.C >> 6;
+        cgi = blockIdx.x % ncg;
+        const int v = blockIdx.x / ncg;
+        s = v / ncolg;
+        colg = v - s * ncolg;
+    }
+    const int j = colg * 4 + wave;
+    if (s >= p.total || j >= p.OW) return;
+    const int c = cgi * 64 + (threadIdx.x & 63);
+    int sg = 0;
+    while (sg + 1 < p.nseg && s >= p.seg[sg].S) { s -= p.seg[sg].S; ++sg; }
+    const GdwSeg &g = p.seg[sg];
+    const int xs = s / g.x_rep;
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    {
+        const int H = p.OH + 4, W = p.OW + 4;
+        gdw_col_branch<5, 5>(acc, g.x[0] + (long)xs * H * W * g.x_cs[0] + g.x_co[0] + c, H, W, g.x_cs[0],
+                             g.z[0] + (long)s * 25 * g.z_cs[0] + g.z_co[0] + c, g.z_cs[0], g.wsm[0], j, p.OH);
+    }
+    {
+        const int H = p.OH + 2, W = p.OW + 4;
+        gdw_col_branch<3, 5>(acc, g.x[1] + (long)xs * H * W * g.x_cs[1] + g.x_co[1] + c, H, W, g.x_cs[1],
+                             g.z[1] + (long)s * 15 * g.z_cs[1] + g.z_co[1] + c, g.z_cs[1], g.wsm[1], j, p.OH);
+    }
+    {
+        const int H = p.OH + 4, W = p.OW + 2;
+        gdw_col_branch<5, 3>(acc, g.x[2] + (long)xs * H * W * g.x_cs[2] + g.x_co[2] + c, H, W, g.x_cs[2],
+                             g.z[2] + (long)s * 15 * g.z_cs[2] + g.z_co[2] + c, g.z_cs[2], g.wsm[2], j, p.OH);
+    }
+    float *o = g.out + ((long)s * p.OH * p.OW + j) * p.C + c;
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        if (i < p.OH) o[(long)i * p.OW * p.C] = acc[i];
+}
+
+// Streaming variant for the bandwidth regime (many samples): one workgroup owns a whole
+// (sample, 64-channel group) and walks its search maps top to bottom exactly once.  Row r of
+// the three maps is fetched with 16-byte coalesced loads into registers while row r-1 is
+// being consumed, parked in a double-buffered LDS row-set, and read back by the compute
+// role: wave w owns output columns 5w..5w+4, lane = channel, a 5x5 ring of accumulators holds
+// the five output rows a search row contributes to.  Every search element crosses HBM once and
+// LDS once per strip that needs it; nothing depends on L1/L2 luck.
+template <int NSTRIP>
+__global__ __launch_bounds__(64 * NSTRIP) void groupdw_nhwc_stream_kernel(const GdwK p)
+{
+    constexpr int NT = 64 * NSTRIP;
+    extern __shared__ __attribute__((aligned(16))) float rows[];     // [2][npx][64]
+    const int W0 = p.OW + 4, W2 = p.OW + 2;
+    const int npx = 2 * W0 + W2;                  // pixels of one row-set: x0 | x1 | x2
+    int cgi, s;
+    if (p.C == 256) {
+        const int xcd = blockIdx.x & 7;
+        cgi = xcd & 3;
+        s = (blockIdx.x >> 3) * 2 + (xcd >> 2);
+    } else {
+        const int ncg = p.C >> 6;
+        cgi = blockIdx.x % ncg;
+        s = blockIdx.x / ncg;
+    }
+    if (s >= p.total) return;
+    int sg = 0;
+    while (sg + 1 < p.nseg && s >= p.seg[sg].S) { s -= p.seg[sg].S; ++sg; }
+    const GdwSeg &g = p.seg[sg];
+    const int xs = s / g.x_rep;
+    const int tid = threadIdx.x, lane = tid & 63, strip = tid >> 6;
+    const int c = cgi * 64 + lane;
+    const int j0 = strip * 5;
+    const int H0 = p.OH + 4, H1 = p.OH + 2;
+    const float *xb0 = g.x[0] + (long)xs * H0 * W0 * g.x_cs[0] + g.x_co[0] + cgi * 64;
+    const float *xb1 = g.x[1] + (long)xs * H1 * W0 * g.x_cs[1] + g.x_co[1] + cgi * 64;
+    const float *xb2 = g.x[2] + (long)xs * H0 * W2 * g.x_cs[2] + g.x_co[2] + cgi * 64;
+
+    // loader role: chunk q = (pixel, 4-channel group); MAXQ chunks per thread per row-set
+    constexpr int MAXQ = 6;                       // (3*27+10)*16 / 320 < 6
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 pre[MAXQ];
+    auto fetch = [&](int r) {
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) {
+            const int q = tid + k * NT;
+            const int px = q >> 4, c4 = (q & 15) * 4;
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (px < npx) {
+                if (px < W0)            v = *(const f4 *)(xb0 + ((long)r * W0 + px) * g.x_cs[0] + c4);
+                else if (px < 2 * W0) { if (r < H1) v = *(const f4 *)(xb1 + ((long)r * W0 + px - W0) * g.x_cs[1] + c4); }
+                else                    v = *(const f4 *)(xb2 + ((long)r * W2 + px - 2 * W0) * g.x_cs[2] + c4);
+            }
+            pre[k] = v;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) {
+            const int q = tid + k * NT;
+            const int px = q >> 4, c4 = (q & 15) * 4;
+            if (px < npx) *(f4 *)(rows + ((long)buf * npx + px) * 64 + c4) = pre[k];
+        }
+    };
+
+    float k0[5][5], k1[3][5], k2[5][3];
+    {
+        const float *z0 = g.z[0] + (long)s * 25 * g.z_cs[0] + g.z_co[0] + c;
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+            for (int v = 0; v < 5; ++v) k0[u][v] = g.wsm[0] * z0[(u * 5 + v) * g.z_cs[0]];
+        const float *z1 = g.z[1] + (long)s * 15 * g.z_cs[1] + g.z_co[1] + c;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int v = 0; v < 5; ++v) k1[u][v] = g.wsm[1] * z1[(u * 5 + v) * g.z_cs[1]];
+        const float *z2 = g.z[2] + (long)s * 15 * g.z_cs[2] + g.z_co[2] + c;
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) k2[u][v] = g.wsm[2] * z2[(u * 3 + v) * g.z_cs[2]];
+    }
+    float A[5][5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) A[u][j] = 0.f;
+
+    fetch(0);
+    park(0);
+    __syncthreads();
+    float *o = g.out + ((long)s * p.OH * p.OW) * p.C + c;
+    for (int r = 0; r < H0; ++r) {
+        const int buf = r & 1;
+        if (r + 1 < H0) fetch(r + 1);
+        const float *rs = rows + (long)buf * npx * 64 + lane;
+        {
+            float xv[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) xv[q] = rs[min(j0 + q, W0 - 1) * 64];
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) A[u][j] = fmaf(xv[j + v], k0[u][v], A[u][j]);
+        }
+        if (r < H1) {
+            float xv[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) xv[q] = rs[(W0 + min(j0 + q, W0 - 1)) * 64];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) A[u][j] = fmaf(xv[j + v], k1[u][v], A[u][j]);
+        }
+        {
+            float xv[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) xv[q] = rs[(2 * W0 + min(j0 + q, W2 - 1)) * 64];
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) A[u][j] = fmaf(xv[j + v], k2[u][v], A[u][j]);
+        }
+        const int done = r - 4;
+        if (done >= 0) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                if (j0 + j < p.OW) o[((long)done * p.OW + j0 + j) * p.C] = A[4][j];
+        }
+#pragma unroll
+        for (int u = 4; u > 0; --u)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) A[u][j] = A[u - 1][j];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) A[0][j] = 0.f;
+        if (r + 1 < H0) park(buf ^ 1);
+        __syncthreads();
+    }
 }
 
 // -------------------------------------------------------------------------------------
@@ -304,17 +531,45 @@ extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, 
         g.out = q.out; g.S = q.S; g.x_rep = q.x_rep;
         total += q.S;
     }
-    const int mode = d[0].cols_per_thread;      // 0/5: 5x5 patches; 1: 5x1 strips (more waves)
+    // variant: 0 -> default (5x1 strips: best measured at 9 and at 128+ samples);
+    // 1 strips, 5/50/52 5x5 patches (register budgets), 2 column threads, 3 LDS row streaming
+    const int mode = d[0].cols_per_thread == 0 ? 1 : d[0].cols_per_thread;
     hipStream_t s = (hipStream_t)stream;
-    if (mode != 0 && mode != 1 && mode != 5) return USOT_EINVAL;
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 5 && mode != 50 && mode != 52) return USOT_EINVAL;
+    if (mode == 3) {            // streaming: one workgroup per (sample, 64-channel group)
+        const int nstrip = (p.OW + 4) / 5;
+        if (nstrip != 5 && nstrip != 6) return USOT_EINVAL;
+        p.total = total;
+        p.nty = p.ntx = 1;
+        const long nb = p.C == 256 ? 8L * ((total + 1) / 2) : (long)(p.C / 64) * total;
+        const size_t lds = (size_t)2 * (3 * p.OW + 10) * 64 * sizeof(float);
+        if (nstrip == 5) hipLaunchKernelGGL(groupdw_nhwc_stream_kernel<5>, dim3((unsigned)nb), dim3(320), lds, (hipStream_t)stream, p);
+        else             hipLaunchKernelGGL(groupdw_nhwc_stream_kernel<6>, dim3((unsigned)nb), dim3(384), lds, (hipStream_t)stream, p);
+        USOT_CHECK_LAUNCH();
+        return USOT_OK;
+    }
+    if (mode == 2) {
+        if (p.OH > 32) return USOT_EINVAL;
+        p.total = total;
+        p.nty = p.ntx = 1;
+        const long ncolg = (p.OW + 3) / 4;
+        const long nb = p.C == 256 ? 8 * (((total + 1) / 2) * ncolg) : (long)(p.C / 64) * total * ncolg;
+        hipLaunchKernelGGL(groupdw_nhwc_col_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+        USOT_CHECK_LAUNCH();
+        return USOT_OK;
+    }
     p.total = total;
     p.nty = (p.OH + 4) / 5;
-    p.ntx = mode == 1 ? p.OW : (p.OW + 4) / 5;
-    const long units = (long)total * p.nty * p.ntx;
-    const long blocks = p.C == 256 ? 8 * (((units + 1) / 2 + 3) / 4) : (long)(p.C / 64) * ((units + 3) / 4);
+    p.ntx = mode == 1 ? p.OW : (p.OW + 4) / 5;   // every other mode: 5x5 patches
+    const long ntile = (long)p.nty * p.ntx;
+    const long blocks = p.C == 256 ? 8 * ((((total + 1) / 2) * ntile + 3) / 4)
+                                   : (long)(p.C / 64) * ((total * ntile + 3) / 4);
     if (blocks > 0x7fffffffL) return USOT_EINVAL;
-    if (mode == 1) hipLaunchKernelGGL((groupdw_nhwc_kernel<5, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else           hipLaunchKernelGGL((groupdw_nhwc_kernel<5, 5>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    // 5 -> 5x5 patches capped at 128 VGPRs (4 waves/SIMD; spills); 50 -> uncapped; 52 -> 2 waves
+    if (mode == 1)       hipLaunchKernelGGL((groupdw_nhwc_kernel<5, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (mode == 50) hipLaunchKernelGGL((groupdw_nhwc_kernel<5, 5, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (mode == 52) hipLaunchKernelGGL((groupdw_nhwc_kernel<5, 5, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else                 hipLaunchKernelGGL((groupdw_nhwc_kernel<5, 5, 4>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }
