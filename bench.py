@@ -167,6 +167,54 @@ def cpu_baseline(budget_s=12.0):
             'sample': '%d frames of the same workload (1 crop 255x255, N_q=7, fp32) in %.1f s, torch-CPU oracle' % (n, dt)}
 
 
+BF16_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF is 2:1 sparse)
+BACKBONE_GFLOP = 28.192642        # one 255^2 crop through stem..layer3
+
+
+def backbone_bf16(a, device):
+    """BASELINE configs[2]: batch-64 bf16 backbone (+neck), the MFMA-roofline run.  Separate
+    workload, separate JSON line; the default invocation stays configs[1]."""
+    model, _ = build_model(0, 1, device)
+    e = model.engine
+    x = torch.from_numpy(synth.crop(3000, a.batch, a.size)).to(device)
+    for _ in range(max(2, a.warmup)):
+        e.features_bf16(x)
+    p = e._feat[('bf16', a.batch, a.size)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        p['plan'].run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = p['plan'].profile(frames=3, reps=1)
+    convs = iter(p['log'])
+    ms_conv = fl_conv = 0.0
+    rows = []
+    for kind, tile, ks, groups, ms in prof:
+        if kind == 11:                                   # K_CONVB
+            name, M, N, K, g, macs = next(convs)
+            ms_conv += ms
+            fl_conv += 2.0 * macs
+            rows.append((ms, name, M, N, K, 2.0 * macs / ms / 1e9))
+    top = sorted(rows, reverse=True)[:5]
+    ach = fl_conv / (ms_conv * 1e-3) / 1e12
+    line = {
+        'metric': 'backbone crops/s (255x255, ResNet-50 layer3 + neck, bf16, batch %d)' % a.batch,
+        'value': round(a.batch * a.steps / dt, 1), 'unit': 'crops/s', 'n_gpus': 1, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'configs[2]: batch=%d search crops bf16, backbone + neck convs on '
+                               'v_mfma_f32_16x16x32_bf16, fp32 accumulate' % a.batch, 'search': a.size, 'hipgraph': True},
+        'roofline': {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(ach / BF16_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': 'conv_igemm_bf16 (all 45 launches)',
+                     'algorithmic_gflop_per_step': round(fl_conv / 1e9, 1), 'conv_ms_per_step': round(ms_conv, 3),
+                     'end_to_end_tflops': round(a.batch * (BACKBONE_GFLOP + 0.504) * a.steps / dt / 1e3, 1),
+                     'slowest': [{'op': n, 'M': M, 'N': N, 'K': K, 'ms': round(ms, 3), 'tflops': round(tf, 1)}
+                                 for ms, n, M, N, K, tf in top]},
+    }
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -175,6 +223,8 @@ def main():
     ap.add_argument('--size', type=int, default=255)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-xcorr', action='store_true')
+    ap.add_argument('--workload', default='track', choices=['track', 'backbone_bf16'])
+    ap.add_argument('--batch', type=int, default=64)
     a = ap.parse_args()
 
     rank, local, world = streams.init()
@@ -186,6 +236,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
+    if a.workload == 'backbone_bf16':
+        if rank == 0:
+            backbone_bf16(a, device)
+        return
 
     model, wbytes = build_model(rank, world, device)
     sess, crops, p = open_stream(model, device, seed=rank, size=a.size)

@@ -71,6 +71,15 @@ int usot_conv_tile_count(void);
 int usot_conv_tile_info(int tile, int *bm, int *bn);           /* tile ids are 1..count */
 int64_t usot_conv_ws_floats(const usot_conv_desc *d);          /* workspace need for ksplit */
 
+/* ---- bf16 variant for the batched backbone (BASELINE config 3): x / w / res / y are bf16
+ * NHWC (uint16 storage), bias fp32, accumulate fp32 on v_mfma_f32_16x16x32_bf16.  Uses
+ * N..dil_w, act (NONE | RELU), res, tile of the descriptor; dense output; Cin % 64 == 0,
+ * Cout % 4 == 0.                                                                         */
+int usot_conv2d_bf16(void *stream, const usot_conv_desc *d);
+int usot_conv_bf16_tile_count(void);
+int usot_cvt_f32_to_bf16(void *stream, const float *src, void *dst, int64_t n);
+int usot_maxpool3x3s2_bf16(void *stream, const void *x, void *y, int N, int H, int W, int C, int OH, int OW);
+
 /* ---- stem: 7x7 / stride 2 / pad 0 conv, 3 -> 64 channels, + folded BN + ReLU ---------
  * modules.py:70-72,138-140.  x NCHW [N][3][H][W] (the API-edge crop, BGR 0..255),
  * w packed [147][64] with row = (ci*7 + kh)*7 + kw, y NHWC [N][OH][OW][64].            */
@@ -172,6 +181,9 @@ void *usot_plan_create(void);
 void usot_plan_destroy(void *plan);
 int usot_plan_size(void *plan);
 int usot_plan_add_conv(void *plan, const usot_conv_desc *d);
+int usot_plan_add_conv_bf16(void *plan, const usot_conv_desc *d);
+int usot_plan_add_cvt_bf16(void *plan, const float *src, void *dst, int64_t n);
+int usot_plan_add_maxpool_bf16(void *plan, const void *x, void *y, int N, int H, int W, int C, int OH, int OW);
 int usot_plan_add_groupdw(void *plan, const usot_groupdw_desc *d);
 int usot_plan_add_groupdw_multi(void *plan, const usot_groupdw_desc *d, int nseg);
 int usot_plan_add_stem(void *plan, const float *x, const float *w, const float *bias, float *y,

@@ -217,3 +217,30 @@ def test_decode_matches_oracle(gold_host):
             assert int(out[0]) == rc[0] * S + rc[1]
             assert abs(out[1] - score) < 1e-6
             np.testing.assert_allclose(out[3:7], box, rtol=1e-9)
+
+
+BF16_CASES = [(2, 64, 17, 19, 64, 1, 1, (0, 0), (1, 1)), (1, 128, 15, 15, 128, 3, 2, (0, 0), (1, 1)),
+              (2, 256, 13, 13, 256, 3, 1, (2, 2), (2, 2)), (1, 512, 9, 9, 1024, 3, 1, (1, 1), (1, 1)),
+              (4, 1024, 31, 31, 256, 1, 1, (0, 0), (1, 1))]
+
+
+@pytest.mark.parametrize('case', BF16_CASES)
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5])
+def test_conv_bf16(case, tile):
+    """bf16 MFMA conv vs an fp32 conv on the SAME bf16-rounded operands: the only differences
+    are fp32 summation order and the final bf16 rounding (2^-8 relative)."""
+    N, Cin, H, W, Cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)).bfloat16()
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.float(), w.float(), b, stride, pad, dil)
+    res = torch.randn_like(ref).bfloat16()
+    ref_r = F.relu(ref + res.float())
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV)
+    y = hip.conv2d_bf16(xd, wd, b.to(DEV), KH=k, KW=k, stride=stride, pad=pad, dil=dil, tile=tile)
+    assert rel_err(y.float().permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 6e-3
+    rd = res.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = hip.conv2d_bf16(xd, wd, b.to(DEV), KH=k, KW=k, stride=stride, pad=pad, dil=dil, res=rd, act=hip.ACT_RELU, tile=tile)
+    assert rel_err(y.float().permute(0, 3, 1, 2).cpu().numpy(), ref_r.numpy()) < 6e-3

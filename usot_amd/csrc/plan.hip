@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -92,6 +92,11 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
             rc = usot_decode_dev_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2],
                                      (const double *)op.p[3], (double *)op.p[4], op.i[0], op.i[1], op.i[2],
                                      op.f[0], op.d[0], op.d[1], (const double *)op.p[5], (float *)op.l[0]);
+            break;
+        case K_CONVB: rc = usot_conv2d_bf16(s, &op.conv); break;
+        case K_CVTB:  rc = usot_cvt_f32_to_bf16(s, (const float *)op.p[0], (void *)op.p[1], op.l[0]); break;
+        case K_POOLB:
+            rc = usot_maxpool3x3s2_bf16(s, op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5]);
             break;
         case K_ROWS:
             rc = usot_rows_copy_f32(s, (const float *)op.p[0], (const int32_t *)op.p[1], (float *)op.p[2],
@@ -175,6 +180,32 @@ extern "C" int usot_plan_add_conv(void *plan, const usot_conv_desc *d)
     Op *op = push(plan, K_CONV);
     if (!op) return USOT_ESTATE;
     op->conv = *d;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_conv_bf16(void *plan, const usot_conv_desc *d)
+{
+    if (!d) return USOT_EINVAL;
+    Op *op = push(plan, K_CONVB);
+    if (!op) return USOT_ESTATE;
+    op->conv = *d;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_cvt_bf16(void *plan, const float *src, void *dst, int64_t n)
+{
+    Op *op = push(plan, K_CVTB);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = src; op->p[1] = dst; op->l[0] = n;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_maxpool_bf16(void *plan, const void *x, void *y, int N, int H, int W, int C, int OH, int OW)
+{
+    Op *op = push(plan, K_POOLB);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = x; op->p[1] = y;
+    op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = C; op->i[4] = OH; op->i[5] = OW;
     return USOT_OK;
 }
 
@@ -371,6 +402,7 @@ extern "C" int usot_plan_op_info(void *plan, int i, int *info)
     if (!pl || !info || i < 0 || i >= (int)pl->ops.size()) return USOT_EINVAL;
     const Op &op = pl->ops[i];
     info[0] = (int)op.kind; info[1] = 0; info[2] = 1; info[3] = 1;
+    if (op.kind == K_CONVB) { info[1] = op.conv.tile; }
     if (op.kind == K_CONV) {
         info[1] = usot_conv_resolve_tile(&op.conv);
         info[2] = op.conv.ksplit > 1 ? op.conv.ksplit : 1;
