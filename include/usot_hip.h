@@ -67,6 +67,10 @@ typedef struct usot_conv_desc {
 } usot_conv_desc;
 
 int usot_conv2d_f32(void *stream, const usot_conv_desc *d);
+/* up to 4 convolutions of different geometry side by side in ONE launch (same tile shape =
+ * d[0].tile, own ksplit each): shortcut conv + conv1 of a bottleneck, the three dilated
+ * encoders of one input, the prediction heads. */
+int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int n);
 int usot_conv_tile_count(void);
 int usot_conv_tile_info(int tile, int *bm, int *bn);           /* tile ids are 1..count */
 int64_t usot_conv_ws_floats(const usot_conv_desc *d);          /* workspace need for ksplit */
@@ -181,6 +185,7 @@ void *usot_plan_create(void);
 void usot_plan_destroy(void *plan);
 int usot_plan_size(void *plan);
 int usot_plan_add_conv(void *plan, const usot_conv_desc *d);
+int usot_plan_add_conv_batch(void *plan, const usot_conv_desc *d, int n);
 int usot_plan_add_conv_bf16(void *plan, const usot_conv_desc *d);
 int usot_plan_add_cvt_bf16(void *plan, const float *src, void *dst, int64_t n);
 int usot_plan_add_maxpool_bf16(void *plan, const void *x, void *y, int N, int H, int W, int C, int OH, int OW);

@@ -16,6 +16,7 @@ ap.add_argument('--sizes', type=int, nargs='+', default=[255, 127, 271])
 ap.add_argument('--reps', type=int, default=12)
 ap.add_argument('--out', default=os.path.join(ROOT, 'usot_amd', 'data', 'tuning_gfx950.json'))
 ap.add_argument('--verbose', action='store_true')
+ap.add_argument('--split-margin', type=float, default=0.10)
 a = ap.parse_args()
 
 dev = torch.device('cuda:0')
@@ -95,6 +96,12 @@ for key, g in sorted(shapes.items()):
             rows.append((us, tile, ks))
             if best is None or us < best[0]:
                 best = (us, tile, ks)
+    # a split-K candidate costs a second (cold) launch and a workspace round trip inside the
+    # frame that this warm, back-to-back timing under-prices: prefer the best unsplit candidate
+    # unless splitting wins by more than --split-margin
+    unsplit = min((r for r in rows if r[2] == 1), default=None)
+    if unsplit is not None and best[2] > 1 and unsplit[0] <= best[0] * (1.0 + a.split_margin):
+        best = unsplit
     us, tile, ks = best
     tf = 2.0 * M * Cout * K * groups / us / 1e6
     table['%d,%d,%d,%d' % key] = [tile, ks]

@@ -43,6 +43,16 @@ struct ConvK {
     int vec_store;
 };
 
+// Up to four convolutions of DIFFERENT geometry in one launch (same tile shape): the shortcut
+// conv beside conv1 of a bottleneck, the three dilated encoders of one input, the two
+// prediction heads.  At batch 1 each of these alone leaves most of the chip idle and pays a
+// full launch; side by side they share one.  Workgroup ranges are [start[i], start[i+1]).
+struct ConvBatch {
+    ConvK p[4];
+    int n;
+    int start[5];
+};
+
 __device__ __forceinline__ float apply_act(float v, int a)
 {
     switch (a) {
@@ -66,8 +76,14 @@ __device__ __forceinline__ int xcd_remap(int b, int total)
 constexpr int LDK = 36;   // padded k-extent of an LDS row (floats)
 
 template <int BM, int BN, int WM, int WN, int DBG = 0>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p)
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvBatch bt)
 {
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < bt.n && (int)blockIdx.x >= bt.start[q]) pi = q;
+    const ConvK &p = bt.p[pi];
+    const int bid0 = (int)blockIdx.x - bt.start[pi];
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     static_assert(TM >= 1 && TN >= 1, "wave tile at least 16x16");
@@ -80,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p)
     const int tid = threadIdx.x;
     const int tiles = p.MT * p.NT;
     const int total = tiles * p.groups * p.ksplit;
-    const int b = xcd_remap(blockIdx.x, total);
+    const int b = xcd_remap(bid0, total);
     const int z = b / tiles, t = b - z * tiles;
     const int g = z / p.ksplit, ks = z - g * p.ksplit;
     const int bn0 = (t / p.MT) * BN, bm0 = (t % p.MT) * BM;
@@ -264,8 +280,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p)
 // so the global-load latency has a whole k-tile to land, the LDS write is off the critical
 // path, and no MFMA ever waits for a just-issued ds_read.
 template <int BM, int BN, int WM, int WN, int BK, int KSW = 1>
-__global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvK p)
+__global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch bt)
 {
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < bt.n && (int)blockIdx.x >= bt.start[q]) pi = q;
+    const ConvK &p = bt.p[pi];
+    const int bid0 = (int)blockIdx.x - bt.start[pi];
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     static_assert(BK == 32 || BK == 64, "k-tile of 32 or 64");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvK p)
     const int tid = threadIdx.x & 255;
     const int tiles = p.MT * p.NT;
     const int total = tiles * p.groups * p.ksplit;
-    const int b = xcd_remap(blockIdx.x, total);
+    const int b = xcd_remap(bid0, total);
     const int z = b / tiles, t0 = b - z * tiles;
     const int g = z / p.ksplit, ks = z - g * p.ksplit;
     const int bn0 = (t0 / p.MT) * BN, bm0 = (t0 % p.MT) * BM;
@@ -516,6 +538,233 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvK p)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// v3: producer / consumer wavefronts.  512 threads: waves 0-3 only feed the matrix pipe
+// (ds_read fragments -> MFMA), waves 4-7 only move data (global -> registers -> LDS).
+// Each SIMD hosts one of each, so the loader's address math, VMEM issue and LDS writes run in
+// the shadow of the other wave's MFMAs instead of inside the MFMA wave's own instruction
+// stream — the overlap a one-wave-per-SIMD launch (batch 1) cannot get from occupancy.
+// Three LDS stages, one barrier per k-tile; the producers stay two tiles ahead, so at tile t a
+// consumer may read tile t and prefetch the first fragments of tile t+1 without waiting:
+//     producers, tile t : G (tile t+2) -> stage (t+2)%3 ; issue loads of tile t+3 ; barrier
+//     consumers, tile t : rounds of {prefetch next fragments ; MFMAs} ;             barrier
+// stage (t+2)%3 held tile t-1, which every consumer finished before barrier(t-1).
+template <int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__(512) void conv_igemm_f32_v3(const ConvBatch bt)
+{
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < bt.n && (int)blockIdx.x >= bt.start[q]) pi = q;
+    const ConvK &p = bt.p[pi];
+    const int bid0 = (int)blockIdx.x - bt.start[pi];
+    static_assert(WM * WN == 4, "4 consumer wavefronts");
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int LD = BK + 4;
+    constexpr int CPR = BK / 4;
+    constexpr int RPP = 256 / CPR;
+    constexpr int XI = (BM + RPP - 1) / RPP, WI = (BN + RPP - 1) / RPP;
+    constexpr int NR = BK / 16;
+    constexpr int STAGE = (BM + BN) * LD;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const bool producer = threadIdx.x >= 256;
+    const int tid = threadIdx.x & 255;
+    const int tiles = p.MT * p.NT;
+    const int total = tiles * p.groups * p.ksplit;
+    const int b = xcd_remap(bid0, total);
+    const int z = b / tiles, t0 = b - z * tiles;
+    const int g = z / p.ksplit, ks = z - g * p.ksplit;
+    const int bn0 = (t0 / p.MT) * BN, bm0 = (t0 % p.MT) * BM;
+    const int KT = p.K / BK;
+    const int cch = p.Cin / BK;
+    const int kt0 = (int)((long)KT * ks / p.ksplit);
+    const int kt1 = (int)((long)KT * (ks + 1) / p.ksplit);
+    const int nt = kt1 - kt0;
+
+    if (producer) {
+        const float *__restrict__ xg = p.x + (long)g * p.x_gs;
+        const float *__restrict__ wg = p.w + (long)g * p.w_gs;
+        const int lr = tid / CPR, kc = tid % CPR;
+        int x_ih0[XI], x_iw0[XI];
+        long x_nb[XI];
+        bool x_ok[XI];
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int row = lr + RPP * i;
+            const int m = bm0 + row;
+            x_ok[i] = (row < BM) && (m < p.M);
+            const int mm = x_ok[i] ? m : 0;
+            const int n = mm / p.P, pix = mm - n * p.P;
+            const int oh = pix / p.OW, ow = pix - oh * p.OW;
+            x_ih0[i] = oh * p.stride - p.pad_h;
+            x_iw0[i] = ow * p.stride - p.pad_w;
+            x_nb[i] = (long)n * p.H * p.W * p.Cin + kc * 4;
+        }
+        const float *wp[WI];
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int row = lr + RPP * i;
+            const int co = bn0 + row;
+            wp[i] = wg + (long)((row < BN && co < p.Cout) ? co : 0) * p.K + kc * 4 + (long)kt0 * BK;
+        }
+        f32x4 xr[XI], wr[WI];
+        const float *xp[XI];
+        bool xin[XI];
+        int cur_tap = kt0 / cch, cur_cc = kt0 - cur_tap * cch;
+        auto set_tap = [&](int tap) {
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const int dh = kh * p.dil_h, dw = kw * p.dil_w;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int ih = x_ih0[i] + dh, iw = x_iw0[i] + dw;
+                xin[i] = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                xp[i] = xg + x_nb[i] + ((long)ih * p.W + iw) * p.Cin;
+            }
+        };
+        set_tap(cur_tap);
+        auto load_tile = [&](bool advance) {
+            const int c0 = cur_cc * BK;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (xin[i]) v = *(const f32x4 *)(xp[i] + c0);
+                xr[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < WI; ++i) {
+                wr[i] = *(const f32x4 *)wp[i];
+                wp[i] += advance ? BK : 0;
+            }
+            if (advance && ++cur_cc == cch) {
+                cur_cc = 0;
+                set_tap(++cur_tap);
+            }
+        };
+        auto store_tile = [&](int st) {
+            float *sX = smem + st * STAGE, *sW = sX + BM * LD;
+#pragma unroll
+            for (int i = 0; i < XI; ++i)
+                if (BM % RPP == 0 || lr + RPP * i < BM) *(f32x4 *)(sX + (lr + RPP * i) * LD + kc * 4) = xr[i];
+#pragma unroll
+            for (int i = 0; i < WI; ++i)
+                if (BN % RPP == 0 || lr + RPP * i < BN) *(f32x4 *)(sW + (lr + RPP * i) * LD + kc * 4) = wr[i];
+        };
+        // tiles 0 and 1 before the first barrier, tile 2 in flight
+        if (nt > 0) { load_tile(nt > 1); store_tile(0); }
+        if (nt > 1) { load_tile(nt > 2); store_tile(1); }
+        if (nt > 2) load_tile(nt > 3);
+        __syncthreads();
+        int st2 = 2;                                  // stage that receives tile t+2
+        for (int t = 0; t < nt; ++t) {
+            if (t + 2 < nt) store_tile(st2);
+            if (t + 3 < nt) load_tile(t + 4 < nt);
+            st2 = st2 == 2 ? 0 : st2 + 1;
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------- consumers
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int fx_off = (wm * TM * 16 + l15) * LD + quad * 4;
+    const int fw_off = BM * LD + (wn * TN * 16 + l15) * LD + quad * 4;
+    f32x4 fw[2][TN], fx[2][TM];
+    auto read_frags = [&](int st, int r, int slot) {
+        const float *base = smem + st * STAGE + r * 16;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fw[slot][i] = *(const f32x4 *)(base + fw_off + i * 16 * LD);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fx[slot][j] = *(const f32x4 *)(base + fx_off + j * 16 * LD);
+    };
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](int slot) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][i][c], fx[slot][j][c], acc[i][j], 0, 0, 0);
+    };
+    __syncthreads();
+    if (nt > 0) read_frags(0, 0, 0);
+    int st = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int st1 = st == 2 ? 0 : st + 1;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
+            else if (t + 1 < nt) read_frags(st1, 0, 0);
+            mma(r & 1);
+        }
+        st = st1;
+        __syncthreads();
+    }
+
+    if (p.ksplit > 1) {
+        float *wsg = p.ws + ((long)(ks * p.groups + g) * p.M) * p.Cout;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = bm0 + (wm * TM + j) * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+                if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
+                    *(f32x4 *)(wsg + (long)m * p.Cout + co) = acc[i][j];
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Cout) wsg[(long)m * p.Cout + co + e] = acc[i][j][e];
+                }
+            }
+        }
+        return;
+    }
+    const float *__restrict__ bg = p.bias ? p.bias + (long)g * p.b_gs : nullptr;
+    const float *__restrict__ rg = p.res ? p.res + (long)g * p.r_gs : nullptr;
+    float *__restrict__ yg = p.y + (long)g * p.y_gs;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = bm0 + (wm * TM + j) * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+            if (co >= p.Cout) continue;
+            f32x4 v = acc[i][j];
+            if (p.vec_store && co + 3 < p.Cout) {
+                if (bg) v += *(const f32x4 *)(bg + co);
+                if (rg) v += *(const f32x4 *)(rg + (long)m * p.res_cstride + p.res_coff + co);
+                const int a = co < p.act_split ? p.act : p.act2;
+                if (a != USOT_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a);
+                }
+                *(f32x4 *)(yg + (long)m * p.y_cstride + p.y_coff + co) = v;
+            } else {
+                const int n = m / p.P, pix = m - n * p.P;
+                for (int e = 0; e < 4; ++e) {
+                    const int c = co + e;
+                    if (c >= p.Cout) break;
+                    float s = v[e];
+                    if (bg) s += bg[c];
+                    if (rg) s += rg[(long)m * p.res_cstride + p.res_coff + c];
+                    s = apply_act(s, c < p.act_split ? p.act : p.act2);
+                    if (p.y_nchw) yg[((long)n * p.Cout + c) * p.P + pix] = s;
+                    else          yg[(long)m * p.y_cstride + p.y_coff + c] = s;
+                }
+            }
+        }
+    }
+}
+
 // split-K second pass: sum the partial slabs, then the same epilogue.
 __global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvK p)
 {
@@ -542,11 +791,12 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvK p)
     }
 }
 
-struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvK); };
+struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int threads; };
 
-#define TILE(bm, bn, wm, wn) { bm, bn, 32, 2, 1, conv_igemm_f32<bm, bn, wm, wn> }
-#define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v2<bm, bn, wm, wn, bk> }
-#define TILE3(bm, bn, wm, wn, bk, ksw) { bm, bn, bk, 3, ksw, conv_igemm_f32_v2<bm, bn, wm, wn, bk, ksw> }
+#define TILE(bm, bn, wm, wn) { bm, bn, 32, 2, 1, conv_igemm_f32<bm, bn, wm, wn>, 256 }
+#define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v2<bm, bn, wm, wn, bk>, 256 }
+#define TILE3(bm, bn, wm, wn, bk, ksw) { bm, bn, bk, 3, ksw, conv_igemm_f32_v2<bm, bn, wm, wn, bk, ksw>, 256 * ksw }
+#define TILE4(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk>, 512 }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
     TILE(128, 64, 2, 2),    // 2
@@ -576,6 +826,14 @@ const TileCfg kTiles[] = {
     TILE3(16, 64, 1, 4, 64, 2), // 26
     TILE3(32, 64, 2, 2, 32, 2), // 27
     TILE3(16, 64, 1, 4, 32, 4), // 28
+    TILE4(64, 64, 2, 2, 32),    // 29: v3 producer/consumer waves
+    TILE4(64, 64, 2, 2, 64),    // 30
+    TILE4(32, 64, 2, 2, 64),    // 31
+    TILE4(128, 128, 2, 2, 32),  // 32
+    TILE4(32, 32, 2, 2, 64),    // 33
+    TILE4(64, 128, 2, 2, 32),   // 34
+    TILE4(128, 64, 2, 2, 32),   // 35
+    TILE4(32, 128, 2, 2, 64),   // 36
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -620,7 +878,10 @@ extern "C" int64_t usot_conv_ws_floats(const usot_conv_desc *d)
     return (int64_t)d->ksplit * d->groups * d->N * d->OH * d->OW * d->Cout;
 }
 
-extern "C" int usot_conv2d_f32(void *stream, const usot_conv_desc *d)
+namespace {
+
+// validates one descriptor and fills the kernel-side parameter block (tile-independent part)
+int fill_params(const usot_conv_desc *d, ConvK &p)
 {
     if (!d || !d->x || !d->w || !d->y) return USOT_EINVAL;
     if (d->Cin <= 0 || (d->Cin & 31) || d->Cout <= 0 || d->N <= 0) return USOT_EINVAL;
@@ -630,8 +891,6 @@ extern "C" int usot_conv2d_f32(void *stream, const usot_conv_desc *d)
     if (oh != d->OH || ow != d->OW || oh <= 0 || ow <= 0) return USOT_EINVAL;
     const int ksplit = d->ksplit > 1 ? d->ksplit : 1;
     if (ksplit > 1 && !d->ws) return USOT_EINVAL;
-
-    ConvK p;
     p.x = d->x; p.w = d->w; p.bias = d->bias; p.res = d->res; p.y = d->y; p.ws = d->ws;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
@@ -658,16 +917,39 @@ extern "C" int usot_conv2d_f32(void *stream, const usot_conv_desc *d)
                   (d->y_gs % 4 == 0) && (d->r_gs % 4 == 0) && (d->b_gs % 4 == 0);
     if (((uintptr_t)d->x % 16) || ((uintptr_t)d->w % 16) || (d->x_gs % 4) || (d->w_gs % 4))
         return USOT_EINVAL;
+    return USOT_OK;
+}
 
-    int tile = d->tile;
-    if (tile == 0) tile = pick_tile(d, p.M);
+}  // namespace
+
+extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int n)
+{
+    if (!d || n < 1 || n > 4) return USOT_EINVAL;
+    ConvBatch bt;
+    bt.n = n;
+    int rc;
+    for (int i = 0; i < n; ++i)
+        if ((rc = fill_params(&d[i], bt.p[i])) != USOT_OK) return rc;
+    int tile = d[0].tile;
+    if (tile == 0) {                       // heuristic on the largest problem
+        int big = 0;
+        for (int i = 1; i < n; ++i)
+            if ((long)bt.p[i].M * bt.p[i].Cout * bt.p[i].K > (long)bt.p[big].M * bt.p[big].Cout * bt.p[big].K) big = i;
+        tile = pick_tile(&d[big], bt.p[big].M);
+    }
     if (tile < 1 || tile > kNumTiles) return USOT_EINVAL;
     const TileCfg &tc = kTiles[tile - 1];
-    if (d->Cin % tc.bk) return USOT_EINVAL;
-    if (ksplit > p.K / tc.bk) return USOT_EINVAL;
-    p.MT = (p.M + tc.bm - 1) / tc.bm;
-    p.NT = (d->Cout + tc.bn - 1) / tc.bn;
-    const long blocks = (long)p.MT * p.NT * p.groups * ksplit;
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        ConvK &p = bt.p[i];
+        if (d[i].Cin % tc.bk) return USOT_EINVAL;
+        if (p.ksplit > p.K / tc.bk) return USOT_EINVAL;
+        p.MT = (p.M + tc.bm - 1) / tc.bm;
+        p.NT = (d[i].Cout + tc.bn - 1) / tc.bn;
+        bt.start[i] = (int)blocks;
+        blocks += (long)p.MT * p.NT * p.groups * p.ksplit;
+    }
+    for (int i = n; i < 5; ++i) bt.start[i] = (int)blocks;
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
     const size_t lds = (size_t)tc.ksw * tc.stages * (tc.bm + tc.bn) * (tc.bk + 4) * sizeof(float);
     if (lds > 64 * 1024) {
@@ -679,13 +961,21 @@ extern "C" int usot_conv2d_f32(void *stream, const usot_conv_desc *d)
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(tc.fn, dim3((unsigned)blocks), dim3(256 * tc.ksw), lds, s, p);
+    hipLaunchKernelGGL(tc.fn, dim3((unsigned)blocks), dim3(tc.threads), lds, s, bt);
     if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
-    if (ksplit > 1) {
-        const long total = (long)p.M * p.Cout * p.groups;
-        const int gb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-        hipLaunchKernelGGL(conv_splitk_epilogue, dim3(gb), dim3(256), 0, s, p);
-        if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
+    for (int i = 0; i < n; ++i) {
+        const ConvK &p = bt.p[i];
+        if (p.ksplit > 1) {
+            const long total = (long)p.M * p.Cout * p.groups;
+            const int gb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+            hipLaunchKernelGGL(conv_splitk_epilogue, dim3(gb), dim3(256), 0, s, p);
+            if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
+        }
     }
     return USOT_OK;
+}
+
+extern "C" int usot_conv2d_f32(void *stream, const usot_conv_desc *d)
+{
+    return usot_conv2d_batch_f32(stream, d, 1);
 }

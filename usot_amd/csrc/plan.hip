@@ -31,7 +31,9 @@ constexpr int kLanes = 4;     // lane 0 is the caller's stream
 struct Op {
     Kind kind;
     int lane;
-    usot_conv_desc conv;
+    usot_conv_desc conv;          // first (or only) problem
+    usot_conv_desc more[3];       // further problems of a batched launch
+    int nconv;
     usot_groupdw_desc gdw[3];
     int ngdw;
     const void *p[6];
@@ -65,7 +67,15 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
         ++opi;
         for (int rep = 0; rep < reps && rc == USOT_OK; ++rep)
         switch (op.kind) {
-        case K_CONV: rc = usot_conv2d_f32(s, &op.conv); break;
+        case K_CONV:
+            if (op.nconv <= 1) rc = usot_conv2d_f32(s, &op.conv);
+            else {
+                usot_conv_desc tmp[4];
+                tmp[0] = op.conv;
+                for (int q = 1; q < op.nconv; ++q) tmp[q] = op.more[q - 1];
+                rc = usot_conv2d_batch_f32(s, tmp, op.nconv);
+            }
+            break;
         case K_GDW:  rc = usot_groupdw_multi_f32(s, op.gdw, op.ngdw); break;
         case K_STEM:
             rc = usot_stem_conv_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2],
@@ -177,9 +187,17 @@ extern "C" int usot_plan_size(void *plan) { return plan ? (int)((Plan *)plan)->o
 extern "C" int usot_plan_add_conv(void *plan, const usot_conv_desc *d)
 {
     if (!d) return USOT_EINVAL;
+    return usot_plan_add_conv_batch(plan, d, 1);
+}
+
+extern "C" int usot_plan_add_conv_batch(void *plan, const usot_conv_desc *d, int n)
+{
+    if (!d || n < 1 || n > 4) return USOT_EINVAL;
     Op *op = push(plan, K_CONV);
     if (!op) return USOT_ESTATE;
-    op->conv = *d;
+    op->conv = d[0];
+    for (int q = 1; q < n; ++q) op->more[q - 1] = d[q];
+    op->nconv = n;
     return USOT_OK;
 }
 

@@ -164,6 +164,8 @@ class Builder:
         self.plan = Plan()
         self.tuning = tuning or {}
         self.lanes = int(lanes)
+        self.batch = True                 # heterogeneous conv batching (one launch for sibling convs)
+        self.default_batch_tile = 15      # v2 32x64 BK64 when the lead shape has no tuned entry
         self.log = []           # (name, M, N, K, groups, macs) per conv, for benchmarks
         self.geoms = []         # full geometry per conv, for the tuner
 
@@ -184,9 +186,10 @@ class Builder:
         if self.lanes >= level:
             self.plan.join(lane)
 
-    def conv(self, name, pc, x, n, h, w, *, cout=None, act=ACT_NONE, res=None, y=None, y_cstride=0, y_coff=0,
-             act2=ACT_NONE, act_split=0, y_nchw=False, groups=1, x_gs=0, y_gs=0, w_rows=None, row0=0):
-        """x: tensor (NHWC dense, channels == pc.cin).  Returns (y, oh, ow)."""
+    def conv_desc(self, name, pc, x, n, h, w, *, cout=None, act=ACT_NONE, res=None, y=None, y_cstride=0, y_coff=0,
+                  act2=ACT_NONE, act_split=0, y_nchw=False, groups=1, x_gs=0, y_gs=0, w_rows=None, row0=0, tile=None):
+        """Descriptor of one convolution (nothing is added to the plan yet).
+        x: tensor (NHWC dense, channels == pc.cin).  Returns (desc, y, oh, ow, log, geom)."""
         cout = cout or pc.cout
         oh, ow = pc.out_hw(h, w)
         if y is None:
@@ -195,7 +198,10 @@ class Builder:
                 y = y[0]
         k = pc.kh * pc.kw * pc.cin
         m = n * oh * ow
-        tile, ksplit = self.tuning.get((m, cout, k, groups), (0, 1))
+        ttile, ksplit = self.tuning.get((m, cout, k, groups), (0, 1))
+        if tile is not None:                       # batched launch: tile imposed by the lead problem
+            ksplit = 1 if tile != ttile else ksplit
+            ttile = tile
         ws = None
         if ksplit > 1:
             ws = self.buf(ksplit * groups * m * cout)
@@ -206,13 +212,44 @@ class Builder:
                           act_split=act_split, y_cstride=y_cstride, y_coff=y_coff, y_nchw=int(y_nchw),
                           groups=groups, x_gs=x_gs, w_gs=(w_rows or cout) * k, b_gs=(w_rows or cout),
                           y_gs=y_gs if y_gs else n * oh * ow * cout, r_gs=0,
-                          ksplit=ksplit, tile=tile, ws=ws.data_ptr() if ws is not None else None)
-        hip.check(hip.lib().usot_plan_add_conv(self.plan.h, C.byref(d)), 'plan_add_conv ' + name)
+                          ksplit=ksplit, tile=ttile, ws=ws.data_ptr() if ws is not None else None)
         self.plan.keep += [x, pc.w, pc.b]
-        self.log.append((name, m, cout, k, groups, m * cout * k * groups))
-        self.geoms.append(dict(name=name, N=n, H=h, W=w, Cin=pc.cin, Cout=cout, KH=pc.kh, KW=pc.kw, stride=pc.stride,
-                               pad=list(pc.pad), dil=list(pc.dil), groups=groups, has_res=res is not None))
+        log = (name, m, cout, k, groups, m * cout * k * groups)
+        geom = dict(name=name, N=n, H=h, W=w, Cin=pc.cin, Cout=cout, KH=pc.kh, KW=pc.kw, stride=pc.stride,
+                    pad=list(pc.pad), dil=list(pc.dil), groups=groups, has_res=res is not None)
+        return d, y, oh, ow, log, geom
+
+    def conv(self, name, pc, x, n, h, w, **kw):
+        """One convolution = one launch.  Returns (y, oh, ow)."""
+        d, y, oh, ow, log, geom = self.conv_desc(name, pc, x, n, h, w, **kw)
+        hip.check(hip.lib().usot_plan_add_conv(self.plan.h, C.byref(d)), 'plan_add_conv ' + name)
+        self.log.append(log)
+        self.geoms.append(geom)
         return y, oh, ow
+
+    def conv_batch(self, items):
+        """Several convolutions of different geometry in ONE launch (usot_conv2d_batch_f32).
+        items: [(name, pc, x, n, h, w, kwargs)], the first one leads (its tuned tile is used).
+        Falls back to separate launches when batching is disabled.  Returns [(y, oh, ow)]."""
+        if not self.batch or len(items) == 1:
+            return [self.conv(nm, pc, x, n, h, w, **kw) for nm, pc, x, n, h, w, kw in items]
+        descs, outs, macs = [], [], 0
+        lead_tile = None
+        for nm, pc, x, n, h, w, kw in items:
+            d, y, oh, ow, log, geom = self.conv_desc(nm, pc, x, n, h, w, tile=lead_tile, **kw)
+            if lead_tile is None:
+                lead_tile = d.tile if d.tile else self.default_batch_tile
+                d.tile = lead_tile
+            descs.append(d)
+            outs.append((y, oh, ow))
+            macs += log[5]
+            self.geoms.append(geom)
+        arr = (hip.ConvDesc * len(descs))(*descs)
+        hip.check(hip.lib().usot_plan_add_conv_batch(self.plan.h, arr, len(descs)), 'plan_add_conv_batch')
+        first = items[0]
+        self.log.append(('+'.join(i[0] for i in items), descs[0].N * descs[0].OH * descs[0].OW, descs[0].Cout,
+                         descs[0].KH * descs[0].KW * descs[0].Cin, len(descs), macs))
+        return outs
 
     # ---- a1-a4: backbone + neck: x NCHW [n,3,s,s] -> xf NHWC [n,hf,wf,256]
     def backbone(self, x, n, size):
@@ -229,15 +266,21 @@ class Builder:
         stages = [s0]
         for bi, (c1, c2, c3, ds) in enumerate(W.blocks):
             sc = cur
-            if ds is not None:                    # shortcut conv runs beside conv1 -> conv2
-                self.fork(1)
-                sc, hs, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
-                self.fork(0)
-            t1, _, _ = self.conv('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU)
-            t2, h2, _ = self.conv('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
-            if ds is not None:
+            if ds is not None and self.lanes < 3:   # shortcut conv shares conv1's launch
+                (sc, hs, _), (t1, _, _) = self.conv_batch([('b%d.ds' % bi, ds, cur, n, h, h, {}),
+                                                           ('b%d.conv1' % bi, c1, cur, n, h, h, dict(act=ACT_RELU))])
+                t2, h2, _ = self.conv('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
                 assert hs == h2
-                self.join(1)
+            else:
+                if ds is not None:                # shortcut conv on its own lane beside conv1 -> conv2
+                    self.fork(1)
+                    sc, hs, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
+                    self.fork(0)
+                t1, _, _ = self.conv('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU)
+                t2, h2, _ = self.conv('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
+                if ds is not None:
+                    assert hs == h2
+                    self.join(1)
             cur, _, _ = self.conv('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc)
             h = h2
             if bi in (2, 6, 12):                      # ends of layer1 / layer2 / layer3
@@ -290,12 +333,11 @@ class Builder:
 
     # ---- a5 template side: zf NHWC [n,7,7,256] -> 3 maps NHWC [n,hk,wk,cout]
     def encode_kernel(self, zf, n, cout, tag):
-        out = []
-        for g in range(3):
-            y, oh, ow = self.conv('enc_k%d.%s' % (g, tag), self.W.enc_k[g], zf, n, 7, 7, cout=cout, act=ACT_RELU)
+        res = self.conv_batch([('enc_k%d.%s' % (g, tag), self.W.enc_k[g], zf, n, 7, 7, dict(cout=cout, act=ACT_RELU))
+                               for g in range(3)])
+        for g, (y, oh, ow) in enumerate(res):
             assert (oh, ow) == KGEO[g]
-            out.append(y)
-        return out
+        return [r[0] for r in res]
 
     def groupdw(self, xs, zs, out, wsm, S, x_rep, oh, ow, x_co, z_cs):
         d = hip.groupdw_desc([t.data_ptr() for t in xs], [t.data_ptr() for t in zs], out.data_ptr(), wsm,
@@ -313,11 +355,15 @@ class Builder:
     def heads(self, xf, b, hf, zk, mem_nhwc, m, mk=None, mem_lane=None):
         W, L = self.W, hip.lib()
         es = [None] * 3
-        for g, lane in ((1, 1), (2, 3), (0, 0)):          # three encoder geometries side by side
-            self.fork(lane)
-            es[g], _, _ = self.conv('enc_s%d' % g, W.enc_s[g], xf, b, hf, hf, act=ACT_RELU)
-        self.join(1)
-        self.join(3)
+        if self.lanes < 3:                                # three encoder geometries in one launch
+            res = self.conv_batch([('enc_s%d' % g, W.enc_s[g], xf, b, hf, hf, dict(act=ACT_RELU)) for g in range(3)])
+            es = [r[0] for r in res]
+        else:
+            for g, lane in ((1, 1), (2, 3), (0, 0)):
+                self.fork(lane)
+                es[g], _, _ = self.conv('enc_s%d' % g, W.enc_s[g], xf, b, hf, hf, act=ACT_RELU)
+            self.join(1)
+            self.join(3)
         S = hf - 6                                    # response size (25 for 31, 27 for 33)
         has_mem = mem_nhwc is not None
         ngroups = 3 if has_mem else 2
@@ -346,9 +392,9 @@ class Builder:
                 self.conv('tower%d' % i, W.tower[i], cur, b, S, S, cout=256, act=ACT_RELU, y=tout[i], groups=3,
                           x_gs=gs, y_gs=gs)
                 cur = tout[i]
-            self.conv('bbox_pred', W.bbox_pred, cur[0], b, S, S, act=ACT_EXP, y=bbox, y_nchw=True)
-            self.conv('cls_preds', W.cls_preds, cur[1], b, S, S, cout=1, y=cls2, y_nchw=True, groups=2,
-                      x_gs=gs, y_gs=b * S * S, w_rows=1)
+            self.conv_batch([('bbox_pred', W.bbox_pred, cur[0], b, S, S, dict(act=ACT_EXP, y=bbox, y_nchw=True)),
+                             ('cls_preds', W.cls_preds, cur[1], b, S, S, dict(cout=1, y=cls2, y_nchw=True, groups=2,
+                                                                              x_gs=gs, y_gs=b * S * S, w_rows=1))])
             return bbox, cls2, S
         if has_mem:
             # lane 1: confidence/value conv -> fusion -> memory tower -> cls_mem;  lane 0: reg + cls

@@ -22,7 +22,7 @@ EXPORTS = (
     'usot_plan_add_maxpool', 'usot_plan_add_groupdw', 'usot_plan_add_conf_reduce',
     'usot_plan_add_prroi', 'usot_plan_add_permute', 'usot_plan_add_decode', 'usot_plan_run',
     'usot_plan_fork', 'usot_plan_join', 'usot_plan_capture', 'usot_plan_size',
-    'usot_groupdw_multi_f32', 'usot_plan_add_groupdw_multi', 'usot_conv2d_bf16', 'usot_conv_bf16_tile_count', 'usot_cvt_f32_to_bf16', 'usot_maxpool3x3s2_bf16',
+    'usot_groupdw_multi_f32', 'usot_plan_add_groupdw_multi', 'usot_conv2d_batch_f32', 'usot_plan_add_conv_batch', 'usot_conv2d_bf16', 'usot_conv_bf16_tile_count', 'usot_cvt_f32_to_bf16', 'usot_maxpool3x3s2_bf16',
     'usot_plan_add_conv_bf16', 'usot_plan_add_cvt_bf16', 'usot_plan_add_maxpool_bf16',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
 )
@@ -100,6 +100,8 @@ def lib():
         L.usot_plan_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.usot_plan_op_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.usot_conv2d_f32.argtypes = [C.c_void_p, C.c_void_p]
+        L.usot_conv2d_batch_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.usot_plan_add_conv_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_groupdw_f32.argtypes = [C.c_void_p, C.c_void_p]
         L.usot_groupdw_multi_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_plan_add_groupdw_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
