@@ -92,7 +92,7 @@ def roofline(sess, frames):
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
-        'kernel': 'conv_igemm_f32<%d,%d>' % tiles[tile], 'launches_per_frame': n,
+        'kernel': hip.tile_name(tile), 'launches_per_frame': n,
         'avg_launch_us': round(ms / n * 1e3, 2), 'algorithmic_gflop_per_frame': round(fl / 1e9, 3),
         'all_convs': {'gflop_per_frame': round(conv_flops / 1e9, 3), 'us_per_frame': round(conv_ms * 1e3, 1),
                       'tflops': round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),

@@ -73,6 +73,7 @@ int usot_conv2d_f32(void *stream, const usot_conv_desc *d);
 int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int n);
 int usot_conv_tile_count(void);
 int usot_conv_tile_info(int tile, int *bm, int *bn);           /* tile ids are 1..count */
+int usot_conv_tile_name(int tile, char *buf, int len);         /* kernel symbol of the tile */
 int64_t usot_conv_ws_floats(const usot_conv_desc *d);          /* workspace need for ksplit */
 
 /* ---- bf16 variant for the batched backbone (BASELINE config 3): x / w / res / y are bf16
@@ -161,7 +162,9 @@ int usot_decode_f32(void *stream, const float *cls, const float *cls_mem, const 
 /* same, with the target size read from device memory (double[2]) and, if roi_out != NULL,
  * the PrRoIPool box of the winning cell (usot_tracker.py:196, 329-350) written to
  * roi_out[5] = (0, x1, y1, x2, y2) in feature coordinates: no host round trip between
- * decode and memory-feature pooling.                                                    */
+ * decode and memory-feature pooling.  tsz_dev[6] is a caller-chosen frame tag that is copied
+ * to out[8] AFTER the results (system-scope fence in between), so `out` needs 9 doubles and a
+ * host may poll out[8] in pinned memory instead of synchronising the stream.             */
 int usot_decode_dev_f32(void *stream, const float *cls, const float *cls_mem, const float *bbox,
                         const double *window, double *out, int S, int instance_size, int stride,
                         float ratio, double penalty_k, double window_influence,

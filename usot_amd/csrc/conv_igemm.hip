@@ -22,6 +22,7 @@
 // by padding up to a big tile — see DESIGN.md "filling 1024 SIMDs at M = 961".
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include "usot_hip.h"
 #include "common.h"
 
@@ -862,6 +863,19 @@ extern "C" int usot_conv_tile_info(int tile, int *bm, int *bn)
     if (tile < 1 || tile > kNumTiles) return USOT_EINVAL;
     if (bm) *bm = kTiles[tile - 1].bm;
     if (bn) *bn = kTiles[tile - 1].bn;
+    return USOT_OK;
+}
+
+/* kernel symbol of a tile id as rocprofv3 prints it (for matching bench.py's roofline object
+ * with profiles/) */
+extern "C" int usot_conv_tile_name(int tile, char *buf, int len)
+{
+    if (tile < 1 || tile > kNumTiles || !buf || len < 8) return USOT_EINVAL;
+    const TileCfg &t = kTiles[tile - 1];
+    const char *fam = t.threads == 512 && t.ksw == 1 ? "conv_igemm_f32_v3" : (t.stages == 3 ? "conv_igemm_f32_v2" : "conv_igemm_f32");
+    if (t.stages == 3 && t.ksw > 1) snprintf(buf, len, "%s<%d,%d,%d,%d> ksw=%d", fam, t.bm, t.bn, t.bk, t.ksw, t.ksw);
+    else if (t.stages == 3)         snprintf(buf, len, "%s<%d,%d,BK=%d>", fam, t.bm, t.bn, t.bk);
+    else                            snprintf(buf, len, "%s<%d,%d>", fam, t.bm, t.bn);
     return USOT_OK;
 }
 

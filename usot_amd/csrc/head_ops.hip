@@ -225,6 +225,12 @@ __global__ __launch_bounds__(256) void decode_kernel(
                 roi_out[1 + e] = (float)((v - lo) * slope);
             }
         }
+        if (tsz_dev) {
+            // completion tag for a host that polls the (pinned, coherent) result block instead of
+            // waiting for the whole stream: results first, system-scope fence, then the tag
+            __threadfence_system();
+            out[8] = tsz_dev[6];
+        }
     }
 }
 

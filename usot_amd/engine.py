@@ -636,7 +636,7 @@ class Session:
         # kernels address directly: the 64-byte per-frame upload/download needs no copy
         # kernels at all — the host writes ctl, launches the graph, synchronises, reads out.
         self.ctl = torch.zeros(64, dtype=torch.uint8).pin_memory()
-        self.out8 = torch.zeros(8, dtype=torch.float64).pin_memory()
+        self.out8 = torch.zeros(16, dtype=torch.float64).pin_memory()   # 8 results + completion tag
         self.x_host = torch.zeros(1, 3, self.size, self.size).pin_memory()
         self._build()
 
@@ -646,7 +646,7 @@ class Session:
         pl = bld.plan
         self.x = bld.buf(1, 3, self.size, self.size)
         self.mem_in = bld.buf(7, 7, 7, 256)
-        tsz_dev = self.ctl[0:16].view(torch.float64)
+        tsz_dev = self.ctl[0:56].view(torch.float64)          # [0:2] target size, [6] frame tag
         idx_dev = self.ctl[16:48].view(torch.int32)          # 7 gather rows + 1 scatter row
         self._ctl_f64 = tsz_dev.numpy()
         self._ctl_i32 = idx_dev.numpy()
@@ -676,7 +676,9 @@ class Session:
         self.xf, self.cls2, self.bbox, self.plan, self.log = xf, cls2, bbox, pl, bld.log
         # warm-up must not leave a stray row in the bank: point the scatter at a scratch row
         self._set_ctl([0, 1, 2, 2, 2, 2, 2], self.cap - 1, (64.0, 64.0))
+        self._ctl_f64[6] = -1.0
         e._finish(pl)
+        torch.cuda.current_stream().synchronize()
 
     def _set_ctl(self, rows, slot, tsz):
         self._ctl_f64[0] = float(tsz[0])
@@ -702,10 +704,20 @@ class Session:
                 self.x_host.copy_(x_crop.reshape(self.x.shape))
                 self.x.copy_(self.x_host, non_blocking=True)
         self._set_ctl([0, 1] + [2 + int(i) for i in picks], 2 + self.n, tsz_scaled)
+        tag = float(self.n)
+        self._ctl_f64[6] = tag
         self.plan.run()
-        torch.cuda.current_stream().synchronize()
+        # the decode kernel publishes the result block and then the tag: poll it rather than
+        # sleeping in hipStreamSynchronize (the PrRoIPool + bank append behind it are ordered
+        # before the next frame by the stream)
+        out = self._out_np
+        for _ in range(200000):
+            if out[8] == tag:
+                break
+        else:
+            torch.cuda.current_stream().synchronize()
         self.n += 1
-        return self._out_np.copy()
+        return out[:8].copy()
 
     def memory_feature(self, i):
         """Memory feature i as an NCHW-shaped view [1,256,7,7] of its bank row."""

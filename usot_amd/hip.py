@@ -15,7 +15,7 @@ ACT_NONE, ACT_RELU, ACT_EXP, ACT_CONF = 0, 1, 2, 3
 
 EXPORTS = (
     'usot_abi_version', 'usot_strerror', 'usot_conv2d_f32', 'usot_conv_tile_count',
-    'usot_conv_tile_info', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
+    'usot_conv_tile_info', 'usot_conv_tile_name', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
     'usot_xcorr_depthwise_f32', 'usot_groupdw_f32', 'usot_conf_fusion_reduce_f32',
     'usot_prroi_pool_forward_f32', 'usot_permute4_f32', 'usot_decode_f32',
     'usot_plan_create', 'usot_plan_destroy', 'usot_plan_add_conv', 'usot_plan_add_stem',
@@ -138,6 +138,12 @@ def _dev(t, dtype=torch.float32):
 
 def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def tile_name(tile):
+    buf = C.create_string_buffer(96)
+    check(lib().usot_conv_tile_name(int(tile), buf, 96), 'usot_conv_tile_name')
+    return buf.value.decode()
 
 
 def tile_table():
