@@ -170,6 +170,13 @@ int usot_decode_dev_f32(void *stream, const float *cls, const float *cls_mem, co
                         float ratio, double penalty_k, double window_influence,
                         const double *tsz_dev, float *roi_out);
 
+/* ---- SiamFC crop on the device (lib/utils/track_utils.py:30-119, get_subwindow_tracking):
+ * window [x0, x0+win) x [y0, y0+win) of an HWC uint8 BGR frame (coordinates may leave the
+ * image: mean-colour fill, values already truncated to uint8 like numpy's assignment),
+ * OpenCV-style fixed-point bilinear resize to S x S when win != S, CHW float32 output.     */
+int usot_crop_resize_u8_f32(void *stream, const unsigned char *im, float *out, int H, int W,
+                            int x0, int y0, int win, int S, int fill_b, int fill_g, int fill_r);
+
 /* ---- row gather (scatter = 0: dst[i] = src[idx[i]]) / scatter (dst[idx[i]] = src[i]) of
  * `n_rows` rows of `row_len` floats with indices read from DEVICE memory: selects the
  * memory-queue kernels of a frame (usot_tracker.py:222-256) and appends the new one

@@ -244,3 +244,18 @@ def test_conv_bf16(case, tile):
     rd = res.permute(0, 2, 3, 1).contiguous().to(DEV)
     y = hip.conv2d_bf16(xd, wd, b.to(DEV), KH=k, KW=k, stride=stride, pad=pad, dil=dil, res=rd, act=hip.ACT_RELU, tile=tile)
     assert rel_err(y.float().permute(0, 3, 1, 2).cpu().numpy(), ref_r.numpy()) < 6e-3
+
+
+@pytest.mark.parametrize('pos,win', [((240.3, 180.7), 255), ((10.2, 8.9), 255), ((470.0, 350.0), 301), ((200.5, 100.5), 188),
+                                     ((5.0, 355.0), 127), ((240.0, 180.0), 271), ((100.0, 100.0), 612)])
+def test_device_crop_matches_host_crop(pos, win):
+    """crop + mean pad + fixed-point bilinear + HWC->CHW on the device == hostutils, bit for bit."""
+    from usot_amd import hostutils, synth
+    im, _ = synth.frame(5, t=3)
+    avg = np.mean(im, axis=(0, 1))
+    size = 255
+    want, _ = hostutils.get_subwindow_tracking(im, np.array(pos), size, win, avg)
+    (cx0, _, cy0, _), (top, _, left, _) = hostutils.crop_geometry(im.shape, pos, win)
+    out = torch.empty(3, size, size, device=DEV)
+    hip.crop_resize(torch.from_numpy(np.ascontiguousarray(im)).to(DEV), out, int(cx0) - left, int(cy0) - top, win, avg.astype(np.uint8))
+    assert torch.equal(out.cpu(), want)

@@ -138,6 +138,63 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(
     }
 }
 
+// ---- SiamFC crop on the device (lib/utils/track_utils.py:30-119): window extraction with
+// mean-colour padding, OpenCV-style fixed-point bilinear resize (the arithmetic restated in
+// usot_amd/hostutils.py::resize_bilinear_u8) and HWC uint8 -> CHW float32, one thread per
+// output pixel.  Replaces ~1 ms of numpy per frame with one small kernel.
+struct CropK {
+    const unsigned char *im;      // [H][W][3]
+    float *out;                   // [3][S][S]
+    int H, W, S, win;
+    int x0, y0;                   // window origin in image coordinates (may be negative)
+    int fill[3];
+};
+
+__device__ __forceinline__ void crop_axis(int d, int n_src, int n_dst, int &s0, int &s1, int &w0, int &w1)
+{
+    const double scale = (double)n_src / (double)n_dst;
+    double f = ((double)d + 0.5) * scale - 0.5;
+    long s = (long)floor(f);
+    f -= (double)s;
+    if (s < 0) { f = 0.0; s = 0; }
+    if (s >= n_src - 1) { f = 0.0; s = n_src - 1; }
+    const float ff = (float)f;
+    w1 = (int)rintf(ff * 2048.0f);
+    w0 = (int)rintf((1.0f - ff) * 2048.0f);
+    s0 = (int)s;
+    s1 = min((int)s + 1, n_src - 1);
+}
+
+__device__ __forceinline__ int crop_px(const CropK &p, int wx, int wy, int c)
+{
+    const int ix = p.x0 + wx, iy = p.y0 + wy;
+    if ((unsigned)ix >= (unsigned)p.W || (unsigned)iy >= (unsigned)p.H) return p.fill[c];
+    return p.im[((long)iy * p.W + ix) * 3 + c];
+}
+
+__global__ __launch_bounds__(256) void crop_resize_kernel(const CropK p)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.S * p.S) return;
+    const int dy = idx / p.S, dx = idx - dy * p.S;
+    if (p.win == p.S) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p.out[((long)c * p.S + dy) * p.S + dx] = (float)crop_px(p, dx, dy, c);
+        return;
+    }
+    int xa, xb, wxa, wxb, ya, yb, wya, wyb;
+    crop_axis(dx, p.win, p.S, xa, xb, wxa, wxb);
+    crop_axis(dy, p.win, p.S, ya, yb, wya, wyb);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const long top = (long)crop_px(p, xa, ya, c) * wxa + (long)crop_px(p, xb, ya, c) * wxb;
+        const long bot = (long)crop_px(p, xa, yb, c) * wxa + (long)crop_px(p, xb, yb, c) * wxb;
+        long v = ((((long)wya * (top >> 4)) >> 16) + (((long)wyb * (bot >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        p.out[((long)c * p.S + dy) * p.S + dx] = (float)v;
+    }
+}
+
 // ---- decode (usot_tracker.py:138-163): one workgroup, double precision like the numpy
 // reference (its grids are float64, so everything after the float32 sigmoid promotes) -------
 __global__ __launch_bounds__(256) void decode_kernel(
@@ -302,6 +359,16 @@ extern "C" int usot_decode_dev_f32(void *stream, const float *cls, const float *
     hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cls, cls_mem, bbox,
                        window, out, S, instance_size, stride, ratio, penalty_k, window_influence, 1.0, 1.0,
                        tsz_dev, roi_out);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+extern "C" int usot_crop_resize_u8_f32(void *stream, const unsigned char *im, float *out, int H, int W,
+                                       int x0, int y0, int win, int S, int fill_b, int fill_g, int fill_r)
+{
+    if (!im || !out || H <= 0 || W <= 0 || win <= 0 || S <= 0) return USOT_EINVAL;
+    CropK p{im, out, H, W, S, win, x0, y0, {fill_b, fill_g, fill_r}};
+    hipLaunchKernelGGL(crop_resize_kernel, dim3((S * S + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }

@@ -719,6 +719,22 @@ class Session:
         self.n += 1
         return out[:8].copy()
 
+    def frame_from_image(self, im, pos, win, avg_chans, picks, tsz_scaled):
+        """Whole frame from the raw image: upload the uint8 frame, crop/pad/resize on the
+        device straight into the plan's input buffer (hostutils.get_subwindow_tracking's
+        arithmetic), then `frame`.  `win` = python2round(s_x)."""
+        from .hostutils import crop_geometry
+        h, w, _ = im.shape
+        if getattr(self, '_im_dev', None) is None or tuple(self._im_dev.shape) != (h, w, 3):
+            self._im_dev = torch.empty((h, w, 3), dtype=torch.uint8, device=self.e.device)
+            self._im_host = torch.empty((h, w, 3), dtype=torch.uint8).pin_memory()
+        self._im_host.copy_(torch.from_numpy(np.ascontiguousarray(im)))
+        self._im_dev.copy_(self._im_host, non_blocking=True)
+        (cx0, _, cy0, _), (top, _, left, _) = crop_geometry(im.shape, pos, win)
+        fill = np.asarray(avg_chans).astype(np.uint8)         # numpy's float -> uint8 assignment truncates
+        hip.crop_resize(self._im_dev, self.x[0], int(cx0) - left, int(cy0) - top, int(win), fill)
+        return self.frame(None, picks, tsz_scaled, resident=True)
+
     def memory_feature(self, i):
         """Memory feature i as an NCHW-shaped view [1,256,7,7] of its bank row."""
         return self.bank[2 + i:3 + i].permute(0, 3, 1, 2)

@@ -24,7 +24,7 @@ EXPORTS = (
     'usot_plan_fork', 'usot_plan_join', 'usot_plan_capture', 'usot_plan_size',
     'usot_groupdw_multi_f32', 'usot_plan_add_groupdw_multi', 'usot_conv2d_batch_f32', 'usot_plan_add_conv_batch', 'usot_conv2d_bf16', 'usot_conv_bf16_tile_count', 'usot_cvt_f32_to_bf16', 'usot_maxpool3x3s2_bf16',
     'usot_plan_add_conv_bf16', 'usot_plan_add_cvt_bf16', 'usot_plan_add_maxpool_bf16',
-    'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
+    'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
 )
 
 
@@ -86,6 +86,7 @@ def lib():
                                            + [C.c_double] * 2 + [C.c_void_p] * 2)
         L.usot_plan_add_rows_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int] * 3
         L.usot_rows_copy_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
+        L.usot_crop_resize_u8_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 9
         L.usot_plan_add_conv_bf16.argtypes = [C.c_void_p, C.c_void_p]
         L.usot_plan_add_cvt_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.usot_plan_add_maxpool_bf16.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 6
@@ -335,3 +336,15 @@ def conv2d_bf16(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=Non
                   res=res.data_ptr() if res is not None else None, act=act, tile=tile)
     check(lib().usot_conv2d_bf16(stream(), C.byref(d)), 'usot_conv2d_bf16')
     return y
+
+
+def crop_resize(frame_u8, out, x0, y0, win, fill):
+    """frame_u8: device uint8 [H,W,3]; out: device float32 [3,S,S] (written in place)."""
+    _dev(frame_u8, torch.uint8), _dev(out)
+    if not frame_u8.is_contiguous() or not out.is_contiguous():
+        raise HipError('crop_resize needs a dense HWC uint8 frame and a dense CHW output')
+    H, W_, _ = frame_u8.shape
+    S = out.shape[-1]
+    check(lib().usot_crop_resize_u8_f32(stream(), ptr(frame_u8), ptr(out), H, W_, int(x0), int(y0), int(win), S,
+                                        int(fill[0]), int(fill[1]), int(fill[2])), 'usot_crop_resize_u8_f32')
+    return out

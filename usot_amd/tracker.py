@@ -84,6 +84,7 @@ def select_memory(conf, n_q):
 
 class USOTTracker(object):
     fused = True      # use the device-resident frame plan when the model supports it
+    device_crop = True   # crop / pad / resize the search window on the device (fused path only)
 
     def __init__(self, info):
         self.info = info
@@ -225,13 +226,18 @@ class USOTTracker(object):
         p, net = state['p'], state['net']
         target_pos, target_sz = state['target_pos'], state['target_sz']
         s_x, scale_z = search_scale(target_sz, p)
-        x_crop, _ = get_subwindow_tracking(im, target_pos, p.instance_size, python2round(s_x), state['avg_chans'])
         conf = state['memory_confidences']
         picks = select_memory(conf, p.mem_queue_size)
 
         sess = state.get('session')
+        if sess is None or not self.device_crop:
+            x_crop, _ = get_subwindow_tracking(im, target_pos, p.instance_size, python2round(s_x), state['avg_chans'])
         if sess is not None:
-            out = sess.frame(x_crop, picks, target_sz * scale_z)
+            if self.device_crop:
+                out = sess.frame_from_image(im, target_pos, python2round(s_x), state['avg_chans'], picks,
+                                            target_sz * scale_z)
+            else:
+                out = sess.frame(x_crop, picks, target_sz * scale_z)
             pos, sz = self._apply_box(p, out[3:7], out[2], out[1], target_pos, target_sz * scale_z, scale_z)
             score = np.float32(out[1])
             state['memory_features'].append(None)          # the feature lives in the session's bank
