@@ -124,6 +124,29 @@ def xcorr_bandwidth(device, samples=128, iters=20):
             'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}
 
 
+def video_loop(model, device, frames=200):
+    """PCIe-inclusive rate of the real API: USOTTracker.track on host uint8 frames (upload,
+    device crop, frame graph, result poll, host state update).  Not `value`."""
+    from usot_amd.tracker import USOTTracker
+
+    class Info:
+        arch = 'USOT'
+    trk = USOTTracker(Info())
+    ims = [synth.frame(77, t=t)[0] for t in range(16)]
+    im0, (cx, cy) = synth.frame(77, t=0)
+    state = trk.init(im0, np.array([cx, cy]), np.array([52.0, 38.0]), model)
+    for i in range(10):
+        state = trk.track(state, ims[i % 16])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(frames):
+        state = trk.track(state, ims[i % 16])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'value': round(frames / dt, 1), 'unit': 'frames/s', 'frames': frames, 'frame_hw': list(ims[0].shape[:2]),
+            'what': 'USOTTracker.track(state, uint8 frame): H2D upload + device crop + frame graph + poll + host update'}
+
+
 def host_threads(cap=32):
     """Threads for the CPU leg: the cores this process may actually use (affinity mask and
     cgroup quota), capped — torch-CPU on every hardware thread of a 2-socket host thrashes."""
@@ -234,6 +257,7 @@ def main():
                              '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (a.gpus, a.gpus, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
+    torch.set_num_threads(host_threads())        # the box shows 256 hardware threads under a 16-CPU quota
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     if a.workload == 'backbone_bf16':
@@ -268,6 +292,8 @@ def main():
         line['roofline'] = roofline(sess, frames=10)
         if not a.no_xcorr:
             line['xcorr_hbm'] = xcorr_bandwidth(device)
+        if world == 1:
+            line['video_loop_pcie_inclusive'] = video_loop(model, device)
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line))
