@@ -117,8 +117,9 @@ typedef struct usot_groupdw_desc {
     int32_t x_cs[3], x_co[3], z_cs[3], z_co[3];
     float wsm[3];
     int32_t S, x_rep, OH, OW, C;
-    int32_t cols_per_thread;     /* kernel variant: 0 default (= 1: 5x1 output strips per thread);
-                                  * 50: 5x5 patches; 2: column threads; 3: LDS row streaming */
+    int32_t cols_per_thread;     /* kernel variant: 0 auto (strips for a frame, ring for >= 64 samples);
+                                  * 1: 5x1 strips; 50: 5x5 patches; 2: column threads;
+                                  * 3: LDS row streaming; 4: ring (taps in LDS, rows streamed once) */
 } usot_groupdw_desc;
 int usot_groupdw_f32(void *stream, const usot_groupdw_desc *d);
 /* up to three segments of identical geometry (the cls, reg and memory GroupDWs of a frame)

@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from usot_amd import hip
 dev = 'cuda:0'
 B = 3161088
-for S, cols in ((9, 1), (9, 3), (128, 1), (128, 3), (512, 3), (2048, 3)):
+for S, cols in ((9, 1), (9, 4), (128, 1), (128, 4), (512, 1), (512, 4), (2048, 4)):
     g = torch.Generator().manual_seed(1)
     geo = ((5, 5), (3, 5), (5, 3))
     xs = [torch.randn(S, 25 + hk - 1, 25 + wk - 1, 256, generator=g).to(dev) for hk, wk in geo]

@@ -138,7 +138,7 @@ def test_xcorr_golden(gold_model):
 
 
 @pytest.mark.parametrize('S,x_rep,OW,cols', [(1, 1, 25, 1), (7, 7, 25, 1), (14, 7, 25, 5), (3, 1, 27, 1),
-                                             (2, 1, 25, 5), (4, 2, 27, 5), (9, 1, 25, 2), (7, 7, 27, 2), (3, 1, 25, 50), (9, 1, 25, 3), (14, 7, 27, 3), (5, 1, 25, 3)])
+                                             (2, 1, 25, 5), (4, 2, 27, 5), (9, 1, 25, 2), (7, 7, 27, 2), (3, 1, 25, 50), (9, 1, 25, 3), (14, 7, 27, 3), (5, 1, 25, 3), (9, 1, 25, 4), (14, 7, 27, 4), (5, 1, 25, 4)])
 def test_groupdw_fused(S, x_rep, OW, cols):
     g = torch.Generator().manual_seed(S * 31 + OW)
     XS = S // x_rep

@@ -397,6 +397,121 @@ __global__ __launch_bounds__(64 * NSTRIP) void groupdw_nhwc_stream_kernel(const 
     }
 }
 
+// Ring variant for the bandwidth regime: workgroup = one (sample, 64-channel group), wave w =
+// output columns 5w..5w+4, lane = channel.  The 55 taps live in LDS ([tap][64], read
+// conflict-free one row of 64 lanes at a time) instead of 55 registers per lane; a thread keeps
+// only the 5x5 ring of partial output rows and two search rows (current + prefetched), ~90
+// VGPRs, so 5+ waves per SIMD hide HBM latency.  Rows stream top to bottom exactly once.
+template <int NSTRIP>
+__global__ __launch_bounds__(64 * NSTRIP) void groupdw_nhwc_ring_kernel(const GdwK p)
+{
+    __shared__ float taps[55 * 64];
+    int cgi, s;
+    if (p.C == 256) {
+        const int xcd = blockIdx.x & 7;
+        cgi = xcd & 3;
+        s = (blockIdx.x >> 3) * 2 + (xcd >> 2);
+    } else {
+        const int ncg = p.C >> 6;
+        cgi = blockIdx.x % ncg;
+        s = blockIdx.x / ncg;
+    }
+    if (s >= p.total) return;
+    int sg = 0;
+    while (sg + 1 < p.nseg && s >= p.seg[sg].S) { s -= p.seg[sg].S; ++sg; }
+    const GdwSeg &g = p.seg[sg];
+    const int xs = s / g.x_rep;
+    const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
+    const int c = cgi * 64 + lane;
+    const int j0 = strip * 5;
+    const int W0 = p.OW + 4, W2 = p.OW + 2, H0 = p.OH + 4, H1 = p.OH + 2;
+    for (int t = threadIdx.x; t < 55 * 64; t += 64 * NSTRIP) {
+        const int tap = t >> 6, l = t & 63;
+        float v;
+        if (tap < 25)      v = g.wsm[0] * g.z[0][((long)s * 25 + tap) * g.z_cs[0] + g.z_co[0] + cgi * 64 + l];
+        else if (tap < 40) v = g.wsm[1] * g.z[1][((long)s * 15 + tap - 25) * g.z_cs[1] + g.z_co[1] + cgi * 64 + l];
+        else               v = g.wsm[2] * g.z[2][((long)s * 15 + tap - 40) * g.z_cs[2] + g.z_co[2] + cgi * 64 + l];
+        taps[t] = v;
+    }
+    __syncthreads();
+    const float *x0 = g.x[0] + (long)xs * H0 * W0 * g.x_cs[0] + g.x_co[0] + c;
+    const float *x1 = g.x[1] + (long)xs * H1 * W0 * g.x_cs[1] + g.x_co[1] + c;
+    const float *x2 = g.x[2] + (long)xs * H0 * W2 * g.x_cs[2] + g.x_co[2] + c;
+    // column offsets of this strip (clamped at the map edge; clamped columns feed only
+    // outputs that are never stored)
+    int o0[9], o2[7];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) o0[q] = min(j0 + q, W0 - 1);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) o2[q] = min(j0 + q, W2 - 1);
+    float a[9], b[9], d[7], an[9], bn[9], dn[7];
+    auto fetch = [&](int r, float (&fa)[9], float (&fb)[9], float (&fd)[7]) {
+        const int r1 = min(r, H1 - 1);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) fa[q] = x0[((long)r * W0 + o0[q]) * g.x_cs[0]];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) fb[q] = x1[((long)r1 * W0 + o0[q]) * g.x_cs[1]];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) fd[q] = x2[((long)r * W2 + o2[q]) * g.x_cs[2]];
+    };
+    float A[5][5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) A[u][j] = 0.f;
+    float *o = g.out + ((long)s * p.OH * p.OW) * p.C + c;
+    // (hipcc hoists these loop-invariant LDS reads back into registers — 238 VGPRs; forcing them
+    // to stay in LDS with volatile or a register cap made the schedule worse / spilled)
+    const float *tp = taps + lane;
+    fetch(0, a, b, d);
+#pragma unroll 1
+    for (int r = 0; r < H0; ++r) {
+        fetch(min(r + 1, H0 - 1), an, bn, dn);
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                const float k = tp[(u * 5 + v) * 64];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) A[u][j] = fmaf(a[j + v], k, A[u][j]);
+            }
+        if (r < H1) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 5; ++v) {
+                    const float k = tp[(25 + u * 5 + v) * 64];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) A[u][j] = fmaf(b[j + v], k, A[u][j]);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const float k = tp[(40 + u * 3 + v) * 64];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) A[u][j] = fmaf(d[j + v], k, A[u][j]);
+            }
+        const int done = r - 4;
+        if (done >= 0) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                if (j0 + j < p.OW) o[((long)done * p.OW + j0 + j) * p.C] = A[4][j];
+        }
+#pragma unroll
+        for (int u = 4; u > 0; --u)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) A[u][j] = A[u - 1][j];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) A[0][j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { a[q] = an[q]; b[q] = bn[q]; }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) d[q] = dn[q];
+    }
+}
+
 // -------------------------------------------------------------------------------------
 // (2) per-plane xcorr on NCHW
 // -------------------------------------------------------------------------------------
@@ -531,11 +646,24 @@ extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, 
         g.out = q.out; g.S = q.S; g.x_rep = q.x_rep;
         total += q.S;
     }
-    // variant: 0 -> default (5x1 strips: best measured at 9 and at 128+ samples);
-    // 1 strips, 5/50/52 5x5 patches (register budgets), 2 column threads, 3 LDS row streaming
-    const int mode = d[0].cols_per_thread == 0 ? 1 : d[0].cols_per_thread;
+    // variant: 0 -> auto (5x1 strips for a frame's 9 samples, ring for >= 64 samples);
+    // 1 strips, 5/50/52 5x5 patches (register budgets), 2 column threads, 3 LDS row streaming, 4 ring
+    const int nstrip0 = (p.OW + 4) / 5;
+    const int mode = d[0].cols_per_thread != 0 ? d[0].cols_per_thread
+                   : ((total >= 64 && (nstrip0 == 5 || nstrip0 == 6)) ? 4 : 1);
     hipStream_t s = (hipStream_t)stream;
-    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 5 && mode != 50 && mode != 52) return USOT_EINVAL;
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 50 && mode != 52) return USOT_EINVAL;
+    if (mode == 4) {            // ring: workgroup per (sample, 64-channel group), taps in LDS
+        const int nstrip = (p.OW + 4) / 5;
+        if (nstrip != 5 && nstrip != 6) return USOT_EINVAL;
+        p.total = total;
+        p.nty = p.ntx = 1;
+        const long nb = p.C == 256 ? 8L * ((total + 1) / 2) : (long)(p.C / 64) * total;
+        if (nstrip == 5) hipLaunchKernelGGL(groupdw_nhwc_ring_kernel<5>, dim3((unsigned)nb), dim3(320), 0, (hipStream_t)stream, p);
+        else             hipLaunchKernelGGL(groupdw_nhwc_ring_kernel<6>, dim3((unsigned)nb), dim3(384), 0, (hipStream_t)stream, p);
+        USOT_CHECK_LAUNCH();
+        return USOT_OK;
+    }
     if (mode == 3) {            // streaming: one workgroup per (sample, 64-channel group)
         const int nstrip = (p.OW + 4) / 5;
         if (nstrip != 5 && nstrip != 6) return USOT_EINVAL;
