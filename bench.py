@@ -89,9 +89,15 @@ def roofline(sess, frames):
         conv_flops += 2.0 * macs
     tile, (n, ms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
     ach = fl / (ms * 1e-3) / 1e12
+    traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes (if this kernel was profiled)
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            traffic = json.load(f).get(hip.tile_name(tile), {}).get('hbm_bytes_per_launch')
+    except Exception:
+        pass
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+        'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
         'kernel': hip.tile_name(tile), 'launches_per_frame': n,
         'avg_launch_us': round(ms / n * 1e3, 2), 'algorithmic_gflop_per_frame': round(fl / 1e9, 3),
         'all_convs': {'gflop_per_frame': round(conv_flops / 1e9, 3), 'us_per_frame': round(conv_ms * 1e3, 1),
