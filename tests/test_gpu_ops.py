@@ -259,3 +259,107 @@ def test_device_crop_matches_host_crop(pos, win):
     out = torch.empty(3, size, size, device=DEV)
     hip.crop_resize(torch.from_numpy(np.ascontiguousarray(im)).to(DEV), out, int(cx0) - left, int(cy0) - top, win, avg.astype(np.uint8))
     assert torch.equal(out.cpu(), want)
+
+
+def test_conv_batch_heterogeneous():
+    """Three convolutions of different geometry (the dilated encoder triple) and a split-K one
+    in a single launch == the same convolutions launched one by one."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 256, 31, 31, generator=g)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    geos = [((1, 1), 29, 29), ((2, 1), 27, 29), ((1, 2), 29, 27)]
+    descs, outs, refs, keep = [], [], [], []
+    for i, (dil, oh, ow) in enumerate(geos):
+        w = torch.randn(128, 256, 3, 3, generator=g) / 48
+        b = torch.randn(128, generator=g)
+        refs.append(F.relu(F.conv2d(x, w, b, 1, 0, dil)))
+        wd, bd = pack_w(w).to(DEV), b.to(DEV)
+        y = torch.empty(1, oh, ow, 128, device=DEV)
+        ks = 3 if i == 1 else 1
+        ws = torch.empty(ks * oh * ow * 128, device=DEV) if ks > 1 else None
+        descs.append(hip.conv_desc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), N=1, H=31, W=31, Cin=256,
+                                   OH=oh, OW=ow, Cout=128, KH=3, KW=3, dil=dil, act=hip.ACT_RELU, tile=31 if i == 0 else 0,
+                                   ksplit=ks, ws=ws.data_ptr() if ws is not None else None))
+        outs.append(y)
+        keep += [wd, bd, ws]
+    arr = (hip.ConvDesc * 3)(*descs)
+    hip.check(hip.lib().usot_conv2d_batch_f32(hip.stream(), arr, 3), 'batch')
+    for y, ref in zip(outs, refs):
+        assert rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 2e-5
+
+
+def test_rows_copy_gather_scatter():
+    bank = torch.randn(16, 64, device=DEV)
+    idx = torch.tensor([3, 0, 15, 7], dtype=torch.int32, device=DEV)
+    out = torch.zeros(4, 64, device=DEV)
+    hip.check(hip.lib().usot_rows_copy_f32(hip.stream(), hip.ptr(bank), hip.ptr(idx), hip.ptr(out), 4, 64, 0), 'gather')
+    assert torch.equal(out, bank[idx.long()])
+    dst = torch.zeros(16, 64, device=DEV)
+    hip.check(hip.lib().usot_rows_copy_f32(hip.stream(), hip.ptr(out), hip.ptr(idx), hip.ptr(dst), 4, 64, 1), 'scatter')
+    assert torch.equal(dst[idx.long()], out) and float(dst.abs().sum()) == float(out.abs().sum())
+
+
+def test_plan_run_capture_and_lanes():
+    """A plan replays natively, as a captured hipGraph, and with forked lanes — same results."""
+    import ctypes as C
+    L = hip.lib()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 64, 20, 20, generator=g)
+    w1, w2 = torch.randn(64, 64, 3, 3, generator=g) / 24, torch.randn(64, 64, 1, 1, generator=g) / 8
+    ref = F.relu(F.conv2d(x, w1, None, 1, 1)) + F.conv2d(x, w2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w1d, w2d = pack_w(w1).to(DEV), pack_w(w2).to(DEV)
+    for lanes in (False, True):
+        y1 = torch.zeros(1, 20, 20, 64, device=DEV)
+        y2 = torch.zeros(1, 20, 20, 64, device=DEV)
+        plan = C.c_void_p(L.usot_plan_create())
+        d1 = hip.conv_desc(xd.data_ptr(), w1d.data_ptr(), None, y1.data_ptr(), N=1, H=20, W=20, Cin=64, OH=20, OW=20,
+                           Cout=64, KH=3, KW=3, pad=(1, 1), act=hip.ACT_RELU)
+        # second conv adds the first one's output as residual -> depends on it across lanes
+        d2 = hip.conv_desc(xd.data_ptr(), w2d.data_ptr(), None, y2.data_ptr(), N=1, H=20, W=20, Cin=64, OH=20, OW=20,
+                           Cout=64, KH=1, KW=1, res=y1.data_ptr())
+        if lanes:
+            hip.check(L.usot_plan_fork(plan, 1))
+        hip.check(L.usot_plan_add_conv(plan, C.byref(d1)))
+        if lanes:
+            hip.check(L.usot_plan_join(plan, 1))
+        hip.check(L.usot_plan_add_conv(plan, C.byref(d2)))
+        assert L.usot_plan_size(plan) == (4 if lanes else 2)
+        hip.check(L.usot_plan_run(plan, hip.stream()))
+        torch.cuda.synchronize()
+        assert rel_err(y2.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 2e-5
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            y1.zero_(); y2.zero_()
+            s.synchronize()
+            hip.check(L.usot_plan_capture(plan, hip.stream()))
+            hip.check(L.usot_plan_run(plan, hip.stream()))
+            s.synchronize()
+        assert rel_err(y2.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 2e-5
+        assert L.usot_plan_add_conv(plan, C.byref(d1)) == -4          # USOT_ESTATE: captured plans are frozen
+        ms = (C.c_float * L.usot_plan_size(plan))()
+        L.usot_plan_destroy(plan)
+
+
+def test_decode_dev_writes_roi_and_tag(gold_host):
+    import ctypes as C
+    p = orc.Hyper(255)
+    S = p.score_size
+    c = 'i255/decode1'
+    cls, cm, bbox = gold_host[c + '/cls'], gold_host[c + '/cls_mem'], gold_host[c + '/bbox']
+    tsz, sz = gold_host[c + '/tsz'], float(gold_host[c + '/scale_z'])
+    window = torch.from_numpy(np.outer(np.hanning(S), np.hanning(S))).reshape(-1).to(DEV)
+    ctl = torch.zeros(8, dtype=torch.float64, device=DEV)
+    ctl[0], ctl[1], ctl[6] = tsz[0] * sz, tsz[1] * sz, 42.0
+    out = torch.zeros(9, dtype=torch.float64, device=DEV)
+    roi = torch.zeros(5, device=DEV)
+    dcls, dcm, dbox = torch.from_numpy(cls).to(DEV), torch.from_numpy(cm).to(DEV), torch.from_numpy(bbox).to(DEV)
+    hip.check(hip.lib().usot_decode_dev_f32(hip.stream(), hip.ptr(dcls), hip.ptr(dcm),
+                                            hip.ptr(dbox), hip.ptr(window), hip.ptr(out), S, 255, 8,
+                                            C.c_float(p.ratio), C.c_double(p.penalty_k), C.c_double(p.window_influence),
+                                            hip.ptr(ctl), hip.ptr(roi)), 'decode_dev')
+    o = out.cpu().numpy()
+    assert o[8] == 42.0
+    np.testing.assert_array_equal(roi.cpu().numpy()[1:], gold_host[c + '/out_poolbox'][0])
+    assert roi.cpu().numpy()[0] == 0.0

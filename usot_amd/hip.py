@@ -115,6 +115,8 @@ def lib():
         L.usot_permute4_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_int64] * 4
         L.usot_decode_f32.argtypes = ([C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_float]
                                       + [C.c_double] * 4)
+        L.usot_decode_dev_f32.argtypes = ([C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_float] + [C.c_double] * 2
+                                          + [C.c_void_p] * 2)
         L.usot_conv_tile_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
     return _lib
