@@ -69,3 +69,35 @@ def test_fused_equals_generic(net):
     np.testing.assert_allclose(a, b, atol=1e-3, rtol=0)
     # the session's bank rows are the memory features the generic path keeps as tensors
     assert sb['session'].n == 8
+
+
+def test_session_bank_growth(net):
+    """The memory bank doubles (and the frame plan is rebuilt) when a video outgrows it."""
+    a, _ = run(net, 12, 14, (52.0, 38.0), False)
+    net.engine.session_capacity = 8
+    try:
+        b, sb = run(net, 12, 14, (52.0, 38.0), True)
+    finally:
+        net.engine.session_capacity = 1024
+    assert sb['session'].cap >= 16 and sb['session'].n == 14
+    np.testing.assert_allclose(a, b, atol=1e-3, rtol=0)
+
+
+def test_two_sessions_share_one_engine(net):
+    """Two videos interleaved on one model: each session owns its template encodes and bank."""
+    ref0, _ = run(net, 12, 5, (52.0, 38.0), True)
+    ref1, _ = run(net, 17, 4, (16.0, 12.0), True)
+    trk0, trk1 = USOTTracker(Info()), USOTTracker(Info())
+    im0, (cx0, cy0) = synth.frame(12, t=0)
+    im1, (cx1, cy1) = synth.frame(17, t=0)
+    s0 = trk0.init(im0, np.array([cx0, cy0]), np.array([52.0, 38.0]), net)
+    s1 = trk1.init(im1, np.array([cx1, cy1]), np.array([16.0, 12.0]), net)
+    rows0, rows1 = [], []
+    for f in range(1, 5):
+        s0 = trk0.track(s0, synth.frame(12, t=f)[0])
+        rows0.append([*s0['target_pos'], *s0['target_sz'], float(s0['cls_score'])])
+        if f < 4:
+            s1 = trk1.track(s1, synth.frame(17, t=f)[0])
+            rows1.append([*s1['target_pos'], *s1['target_sz'], float(s1['cls_score'])])
+    np.testing.assert_allclose(np.array(rows0), ref0[1:], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(np.array(rows1), ref1[1:], atol=1e-3, rtol=0)

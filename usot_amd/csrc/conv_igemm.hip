@@ -420,14 +420,25 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // A wave with a single 16x16 block would chain every MFMA on one accumulator (40-cycle
+    // dependent latency vs 32-cycle issue: an 80 % cap); it alternates two accumulators instead
+    // (even / odd k-slots) and adds them at the end.
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
     auto mma = [&](int slot) {
+        if constexpr (TM * TN == 1) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][0], fx[slot][0][0], acc[0][0], 0, 0, 0);
+            acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][1], fx[slot][0][1], acc2, 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][2], fx[slot][0][2], acc[0][0], 0, 0, 0);
+            acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][3], fx[slot][0][3], acc2, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][i][c], fx[slot][j][c], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][i][c], fx[slot][j][c], acc[i][j], 0, 0, 0);
+        }
     };
 
     const int nt_all = kt1 - kt0;
@@ -461,6 +472,7 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
         }
         st = st1;
     }
+    if constexpr (TM * TN == 1) acc[0][0] += acc2;
 
     if (KSW > 1) {
         // meet in LDS: thread (lane, wave) of every group holds the same (channel, pixel) slots
@@ -685,14 +697,25 @@ __global__ __launch_bounds__(512) void conv_igemm_f32_v3(const ConvBatch bt)
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // A wave with a single 16x16 block would chain every MFMA on one accumulator (40-cycle
+    // dependent latency vs 32-cycle issue: an 80 % cap); it alternates two accumulators instead
+    // (even / odd k-slots) and adds them at the end.
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
     auto mma = [&](int slot) {
+        if constexpr (TM * TN == 1) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][0], fx[slot][0][0], acc[0][0], 0, 0, 0);
+            acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][1], fx[slot][0][1], acc2, 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][2], fx[slot][0][2], acc[0][0], 0, 0, 0);
+            acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][3], fx[slot][0][3], acc2, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][i][c], fx[slot][j][c], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][i][c], fx[slot][j][c], acc[i][j], 0, 0, 0);
+        }
     };
     __syncthreads();
     if (nt > 0) read_frags(0, 0, 0);
@@ -708,6 +731,7 @@ __global__ __launch_bounds__(512) void conv_igemm_f32_v3(const ConvBatch bt)
         st = st1;
         __syncthreads();
     }
+    if constexpr (TM * TN == 1) acc[0][0] += acc2;
 
     if (p.ksplit > 1) {
         float *wsg = p.ws + ((long)(ks * p.groups + g) * p.M) * p.Cout;

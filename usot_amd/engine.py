@@ -604,7 +604,7 @@ class Engine:
     def open_session(self, p, window, init_feats):
         """Device-resident tracking state for one video (see Session).  Must be called
         right after template(): it snapshots the current template encodes."""
-        return Session(self, p, window, init_feats)
+        return Session(self, p, window, init_feats, capacity=getattr(self, 'session_capacity', 1024))
 
 
 class Session:
@@ -686,6 +686,12 @@ class Session:
         self._ctl_f64[1] = float(tsz[1])
         self._ctl_i32[:] = list(rows) + [slot]
 
+    def _ensure_capacity(self):
+        """Grow BEFORE anything is written into the plan's input buffer: growing rebuilds the
+        plan and its workspace."""
+        if 2 + self.n >= self.cap - 1:
+            self._grow()
+
     def _grow(self):
         bank = torch.zeros(self.cap * 2, 7, 7, 256, device=self.e.device)
         bank[:self.cap].copy_(self.bank)
@@ -696,8 +702,7 @@ class Session:
         """Run one frame.  x_crop: CHW float tensor (host or device); picks: memory indices
         of the N_q-2 sampled slots; tsz_scaled: target size * scale_z.
         Returns float64[8] = (argmax, score, penalty, x1, y1, x2, y2, pscore)."""
-        if 2 + self.n >= self.cap - 1:
-            self._grow()
+        self._ensure_capacity()
         if not resident:
             if x_crop.is_cuda:
                 self.x.copy_(x_crop.reshape(self.x.shape))
@@ -725,6 +730,7 @@ class Session:
         device straight into the plan's input buffer (hostutils.get_subwindow_tracking's
         arithmetic), then `frame`.  `win` = python2round(s_x)."""
         from .hostutils import crop_geometry
+        self._ensure_capacity()
         h, w, _ = im.shape
         if getattr(self, '_im_dev', None) is None or tuple(self._im_dev.shape) != (h, w, 3):
             self._im_dev = torch.empty((h, w, 3), dtype=torch.uint8, device=self.e.device)
