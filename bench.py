@@ -244,6 +244,41 @@ def backbone_bf16(a, device):
     print(json.dumps(line))
 
 
+def track_mixed(a, rank, world, device):
+    """BASELINE configs[4]: fp16 backbone + fp32 xcorr/heads, `--batch` independent streams per GPU
+    (32 per GPU = 256 on 8 GPUs), N_q = 7.  One step = one batched frame on every rank."""
+    model, wbytes = build_model(rank, world, device)
+    e = model.engine
+    b = a.batch
+    t = lambda arr: torch.from_numpy(arr).to(device)
+    model.pr_pool = False
+    model.template(t(synth.crop(5000 + rank, b, 127)))
+    x = t(synth.crop(6000 + rank, b, a.size))
+    mem = t(synth.memory_kernels(7000 + rank, 7 * b))
+    sm = torch.ones(b, 7, device=device)
+    dt_ = torch.float16 if a.lp == 'fp16' else torch.bfloat16
+    for _ in range(max(2, a.warmup)):
+        e.track_mixed(x, model.zf, mem, sm, dtype=dt_)
+    p = e._track[('mixed', b, a.size, 7, dt_)]
+    streams.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        p['plan'].run()
+    torch.cuda.synchronize()
+    streams.barrier()
+    dt = streams.max_over_ranks(time.perf_counter() - t0, device=device)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'tracker FPS (255x255 search, ResNet-50), %s backbone + fp32 xcorr/heads, batch %d per GPU' % (a.lp, b),
+            'value': round(world * b * a.steps / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': a.lp + '+f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[4]: %s backbone + fp32 xcorr mixed precision, batch=%d per GPU x %d GPUs, N_q=7'
+                                   % (a.lp, b, world), 'search': a.size, 'hipgraph': True}}))
+    streams.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -252,7 +287,8 @@ def main():
     ap.add_argument('--size', type=int, default=255)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-xcorr', action='store_true')
-    ap.add_argument('--workload', default='track', choices=['track', 'backbone_bf16'])
+    ap.add_argument('--workload', default='track', choices=['track', 'backbone_bf16', 'track_mixed'])
+    ap.add_argument('--lp', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--batch', type=int, default=64)
     a = ap.parse_args()
 
@@ -269,6 +305,9 @@ def main():
     if a.workload == 'backbone_bf16':
         if rank == 0:
             backbone_bf16(a, device)
+        return
+    if a.workload == 'track_mixed':
+        track_mixed(a, rank, world, device)
         return
 
     model, wbytes = build_model(rank, world, device)

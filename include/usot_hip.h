@@ -81,6 +81,11 @@ int64_t usot_conv_ws_floats(const usot_conv_desc *d);          /* workspace need
  * N..dil_w, act (NONE | RELU), res, tile of the descriptor; dense output; Cin % 64 == 0,
  * Cout % 4 == 0.                                                                         */
 int usot_conv2d_bf16(void *stream, const usot_conv_desc *d);
+/* general low-precision form: dtype 0 = bf16, 1 = fp16 (v_mfma_f32_16x16x32_f16); out_f32 != 0
+ * stores the result as fp32 (the neck output feeding the fp32 xcorr/heads, BASELINE config 5) */
+int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, int out_f32);
+int usot_cvt_f32_to_lp(void *stream, const float *src, void *dst, int64_t n, int dtype);
+int usot_maxpool3x3s2_lp(void *stream, const void *x, void *y, int N, int H, int W, int C, int OH, int OW, int dtype);
 int usot_conv_bf16_tile_count(void);
 int usot_cvt_f32_to_bf16(void *stream, const float *src, void *dst, int64_t n);
 int usot_maxpool3x3s2_bf16(void *stream, const void *x, void *y, int N, int H, int W, int C, int OH, int OW);
@@ -198,6 +203,9 @@ int usot_plan_size(void *plan);
 int usot_plan_add_conv(void *plan, const usot_conv_desc *d);
 int usot_plan_add_conv_batch(void *plan, const usot_conv_desc *d, int n);
 int usot_plan_add_conv_bf16(void *plan, const usot_conv_desc *d);
+int usot_plan_add_conv_lp(void *plan, const usot_conv_desc *d, int dtype, int out_f32);
+int usot_plan_add_cvt_lp(void *plan, const float *src, void *dst, int64_t n, int dtype);
+int usot_plan_add_maxpool_lp(void *plan, const void *x, void *y, int N, int H, int W, int C, int OH, int OW, int dtype);
 int usot_plan_add_cvt_bf16(void *plan, const float *src, void *dst, int64_t n);
 int usot_plan_add_maxpool_bf16(void *plan, const void *x, void *y, int N, int H, int W, int C, int OH, int OW);
 int usot_plan_add_groupdw(void *plan, const usot_groupdw_desc *d);

@@ -122,3 +122,23 @@ def test_backbone_bf16_tracks_fp32(net, oracle_sd):
     scale = np.abs(ref).mean()
     assert err.mean() / scale < 6e-2, err.mean() / scale      # measured 3-4e-2
     assert np.corrcoef(got.reshape(-1), ref.reshape(-1))[0, 1] > 0.999
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['fp16', 'bf16'])
+def test_track_mixed_precision(net, oracle_sd, dtype):
+    """config 5 path: low-precision MFMA backbone, fp32 xcorr + heads, batch of 2 streams."""
+    z, x = t(synth.crop(60, 2, 127)), t(synth.crop(61, 2, 255))
+    mem = t(synth.memory_kernels(62, 14))
+    with torch.no_grad():
+        zf = orc.template(oracle_sd, z, pr_pool=False)
+        cls, bbox, cm, xf = orc.track(oracle_sd, x, zf, mem, torch.ones(2, 7))
+    net.pr_pool = False
+    net.template(z.to(DEV))
+    net.pr_pool = True
+    gcls, gbbox, gcm, gxf = net.engine.track_mixed(x.to(DEV), net.zf, mem.to(DEV), torch.ones(2, 7, device=DEV), dtype=dtype)
+    tol = 3e-2 if dtype == torch.float16 else 1.5e-1           # fp16: 11 mantissa bits, bf16: 8
+    for got, ref in ((gxf, xf), (gcls, cls), (gcm, cm)):
+        g_, r_ = npy(got.float()), ref.numpy()
+        assert np.abs(g_ - r_).mean() / np.abs(r_).mean() < tol
+    lb = np.abs(np.log(npy(gbbox)) - np.log(bbox.numpy())).mean()
+    assert lb < tol

@@ -224,6 +224,24 @@ BF16_CASES = [(2, 64, 17, 19, 64, 1, 1, (0, 0), (1, 1)), (1, 128, 15, 15, 128, 3
               (4, 1024, 31, 31, 256, 1, 1, (0, 0), (1, 1))]
 
 
+@pytest.mark.parametrize('case', BF16_CASES[:3])
+def test_conv_fp16_and_f32_out(case):
+    N, Cin, H, W, Cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 1)
+    x = torch.randn(N, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)).half()
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x.float(), w.float(), b, stride, pad, dil))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV)
+    y = hip.conv2d_bf16(xd, wd, b.to(DEV), KH=k, KW=k, stride=stride, pad=pad, dil=dil, act=hip.ACT_RELU)
+    assert y.dtype == torch.float16
+    assert rel_err(y.float().permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 1e-3
+    y32 = hip.conv2d_bf16(xd, wd, b.to(DEV), KH=k, KW=k, stride=stride, pad=pad, dil=dil, act=hip.ACT_RELU, out_f32=True)
+    assert y32.dtype == torch.float32
+    assert rel_err(y32.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 2e-5
+
+
 @pytest.mark.parametrize('case', BF16_CASES)
 @pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5])
 def test_conv_bf16(case, tile):

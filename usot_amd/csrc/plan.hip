@@ -103,10 +103,10 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
                                      (const double *)op.p[3], (double *)op.p[4], op.i[0], op.i[1], op.i[2],
                                      op.f[0], op.d[0], op.d[1], (const double *)op.p[5], (float *)op.l[0]);
             break;
-        case K_CONVB: rc = usot_conv2d_bf16(s, &op.conv); break;
-        case K_CVTB:  rc = usot_cvt_f32_to_bf16(s, (const float *)op.p[0], (void *)op.p[1], op.l[0]); break;
+        case K_CONVB: rc = usot_conv2d_lp(s, &op.conv, op.i[6], op.i[7]); break;
+        case K_CVTB:  rc = usot_cvt_f32_to_lp(s, (const float *)op.p[0], (void *)op.p[1], op.l[0], op.i[6]); break;
         case K_POOLB:
-            rc = usot_maxpool3x3s2_bf16(s, op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5]);
+            rc = usot_maxpool3x3s2_lp(s, op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6]);
             break;
         case K_ROWS:
             rc = usot_rows_copy_f32(s, (const float *)op.p[0], (const int32_t *)op.p[1], (float *)op.p[2],
@@ -201,30 +201,40 @@ extern "C" int usot_plan_add_conv_batch(void *plan, const usot_conv_desc *d, int
     return USOT_OK;
 }
 
-extern "C" int usot_plan_add_conv_bf16(void *plan, const usot_conv_desc *d)
+extern "C" int usot_plan_add_conv_lp(void *plan, const usot_conv_desc *d, int dtype, int out_f32)
 {
     if (!d) return USOT_EINVAL;
     Op *op = push(plan, K_CONVB);
     if (!op) return USOT_ESTATE;
     op->conv = *d;
+    op->i[6] = dtype; op->i[7] = out_f32;
     return USOT_OK;
 }
 
-extern "C" int usot_plan_add_cvt_bf16(void *plan, const float *src, void *dst, int64_t n)
+extern "C" int usot_plan_add_conv_bf16(void *plan, const usot_conv_desc *d) { return usot_plan_add_conv_lp(plan, d, 0, 0); }
+
+extern "C" int usot_plan_add_cvt_lp(void *plan, const float *src, void *dst, int64_t n, int dtype)
 {
     Op *op = push(plan, K_CVTB);
     if (!op) return USOT_ESTATE;
-    op->p[0] = src; op->p[1] = dst; op->l[0] = n;
+    op->p[0] = src; op->p[1] = dst; op->l[0] = n; op->i[6] = dtype;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_cvt_bf16(void *plan, const float *src, void *dst, int64_t n) { return usot_plan_add_cvt_lp(plan, src, dst, n, 0); }
+
+extern "C" int usot_plan_add_maxpool_lp(void *plan, const void *x, void *y, int N, int H, int W, int C, int OH, int OW, int dtype)
+{
+    Op *op = push(plan, K_POOLB);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = x; op->p[1] = y;
+    op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = C; op->i[4] = OH; op->i[5] = OW; op->i[6] = dtype;
     return USOT_OK;
 }
 
 extern "C" int usot_plan_add_maxpool_bf16(void *plan, const void *x, void *y, int N, int H, int W, int C, int OH, int OW)
 {
-    Op *op = push(plan, K_POOLB);
-    if (!op) return USOT_ESTATE;
-    op->p[0] = x; op->p[1] = y;
-    op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = C; op->i[4] = OH; op->i[5] = OW;
-    return USOT_OK;
+    return usot_plan_add_maxpool_lp(plan, x, y, N, H, W, C, OH, OW, 0);
 }
 
 extern "C" int usot_plan_add_groupdw(void *plan, const usot_groupdw_desc *d)

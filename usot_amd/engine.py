@@ -59,11 +59,12 @@ class PackedConv:
         ow = (w + 2 * self.pad[1] - self.dil[1] * (self.kw - 1) - 1) // self.stride + 1
         return oh, ow
 
-    def w_bf16(self):
-        """bf16 copy of the folded filter bank (made on first use; fp32 stays the master)."""
-        if getattr(self, '_wb', None) is None:
-            self._wb = self.w.to(torch.bfloat16).contiguous()
-        return self._wb
+    def w_lp(self, dtype=torch.bfloat16):
+        """bf16 / fp16 copy of the folded filter bank (made on first use; fp32 stays the master)."""
+        cache = self.__dict__.setdefault('_wlp', {})
+        if dtype not in cache:
+            cache[dtype] = self.w.to(dtype).contiguous()
+        return cache[dtype]
 
 
 def pack(device, pairs, scale=None, shift=None):
@@ -290,45 +291,48 @@ class Builder:
         return xf, h
 
     # ---- bf16 backbone for the batched MFMA-roofline configuration (BASELINE config 3)
-    def conv_bf16(self, name, pc, x, n, h, w, *, act=ACT_NONE, res=None, tile=0):
+    def conv_bf16(self, name, pc, x, n, h, w, *, act=ACT_NONE, res=None, tile=0, dtype=torch.bfloat16, out_f32=False):
         oh, ow = pc.out_hw(h, w)
-        y = self.buf(n, oh, ow, pc.cout, dtype=torch.bfloat16)
-        wb = pc.w_bf16()
+        y = self.buf(n, oh, ow, pc.cout, dtype=torch.float32 if out_f32 else dtype)
+        wb = pc.w_lp(dtype)
         d = hip.conv_desc(x.data_ptr(), wb.data_ptr(), pc.b.data_ptr(), y.data_ptr(), N=n, H=h, W=w, Cin=pc.cin,
                           OH=oh, OW=ow, Cout=pc.cout, KH=pc.kh, KW=pc.kw, stride=pc.stride, pad=pc.pad, dil=pc.dil,
                           res=res.data_ptr() if res is not None else None, act=act, tile=tile)
-        hip.check(hip.lib().usot_plan_add_conv_bf16(self.plan.h, C.byref(d)), 'plan_add_conv_bf16 ' + name)
+        hip.check(hip.lib().usot_plan_add_conv_lp(self.plan.h, C.byref(d), 1 if dtype == torch.float16 else 0, int(out_f32)),
+                  'plan_add_conv_lp ' + name)
         self.plan.keep += [x, wb, pc.b]
         k = pc.kh * pc.kw * pc.cin
         self.log.append((name, n * oh * ow, pc.cout, k, 1, n * oh * ow * pc.cout * k))
         return y, oh, ow
 
-    def backbone_bf16(self, x, n, size):
-        """x NCHW fp32 [n,3,s,s] -> neck output NHWC bf16 [n,hf,hf,256].  The stem stays the
-        fp32 VALU kernel (K = 147); its output is packed to bf16 once."""
+    def backbone_bf16(self, x, n, size, dtype=torch.bfloat16, neck_f32=False):
+        """x NCHW fp32 [n,3,s,s] -> neck output NHWC bf16|fp16 (or fp32 with neck_f32)
+        [n,hf,hf,256].  The stem stays the fp32 VALU kernel (K = 147); its output is packed to
+        the low-precision type once."""
         W, L = self.W, hip.lib()
+        dt = 1 if dtype == torch.float16 else 0
         oh = (size - 7) // 2 + 1
         s0 = self.buf(n, oh, oh, 64)
         hip.check(L.usot_plan_add_stem(self.plan.h, hip.ptr(x), hip.ptr(W.stem_w), hip.ptr(W.stem_b), hip.ptr(s0),
                                        n, size, size, oh, oh), 'plan_add_stem')
-        s0b = self.buf(n, oh, oh, 64, dtype=torch.bfloat16)
-        hip.check(L.usot_plan_add_cvt_bf16(self.plan.h, hip.ptr(s0), hip.ptr(s0b), s0.numel()), 'plan_add_cvt_bf16')
+        s0b = self.buf(n, oh, oh, 64, dtype=dtype)
+        hip.check(L.usot_plan_add_cvt_lp(self.plan.h, hip.ptr(s0), hip.ptr(s0b), s0.numel(), dt), 'plan_add_cvt_lp')
         ph = (oh - 1) // 2 + 1
-        p0 = self.buf(n, ph, ph, 64, dtype=torch.bfloat16)
-        hip.check(L.usot_plan_add_maxpool_bf16(self.plan.h, hip.ptr(s0b), hip.ptr(p0), n, oh, oh, 64, ph, ph),
-                  'plan_add_maxpool_bf16')
+        p0 = self.buf(n, ph, ph, 64, dtype=dtype)
+        hip.check(L.usot_plan_add_maxpool_lp(self.plan.h, hip.ptr(s0b), hip.ptr(p0), n, oh, oh, 64, ph, ph, dt),
+                  'plan_add_maxpool_lp')
         self.plan.keep += [x]
         cur, h = p0, ph
         for bi, (c1, c2, c3, ds) in enumerate(W.blocks):
             sc = cur
             if ds is not None:
-                sc, _, _ = self.conv_bf16('b%d.ds' % bi, ds, cur, n, h, h)
-            t1, _, _ = self.conv_bf16('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU)
-            t2, h2, _ = self.conv_bf16('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
-            cur, _, _ = self.conv_bf16('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc)
+                sc, _, _ = self.conv_bf16('b%d.ds' % bi, ds, cur, n, h, h, dtype=dtype)
+            t1, _, _ = self.conv_bf16('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU, dtype=dtype)
+            t2, h2, _ = self.conv_bf16('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU, dtype=dtype)
+            cur, _, _ = self.conv_bf16('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc, dtype=dtype)
             h = h2
         self.p3 = cur
-        xf, _, _ = self.conv_bf16('neck', W.neck, cur, n, h, h)
+        xf, _, _ = self.conv_bf16('neck', W.neck, cur, n, h, h, dtype=dtype, out_f32=neck_f32)
         return xf, h
 
     # ---- a5 template side: zf NHWC [n,7,7,256] -> 3 maps NHWC [n,hk,wk,cout]
@@ -487,16 +491,16 @@ class Engine:
         p['plan'].run()
         return p['xf'].permute(0, 3, 1, 2)
 
-    def features_bf16(self, x):
-        """Batched bf16 backbone + neck (config 3): x NCHW fp32 [n,3,s,s] -> NCHW-shaped bf16 view
-        [n,256,hf,hf] of the NHWC result.  Workspace view: valid until the next call."""
+    def features_bf16(self, x, dtype=torch.bfloat16):
+        """Batched low-precision backbone + neck (config 3): x NCHW fp32 [n,3,s,s] -> NCHW-shaped
+        bf16|fp16 view [n,256,hf,hf] of the NHWC result.  Workspace view: valid until the next call."""
         x = _as_dev_f32(x, self.device)
         n, _, s, _ = x.shape
-        key = ('bf16', n, s)
+        key = ('bf16' if dtype == torch.bfloat16 else 'f16', n, s)
         if key not in self._feat:
             bld = Builder(self.W, self.tuning, 0)
             xin = bld.buf(n, 3, s, s)
-            xf, h = bld.backbone_bf16(xin, n, s)
+            xf, h = bld.backbone_bf16(xin, n, s, dtype=dtype)
             self._finish(bld.plan)
             self._feat[key] = dict(x=xin, xf=xf, h=h, plan=bld.plan, log=bld.log, p3=bld.p3)
         p = self._feat[key]
@@ -594,6 +598,29 @@ class Engine:
             return cls, bbox, None, None
         cls_mem = p['cls2'][1].clone() if clone else p['cls2'][1]
         return cls, bbox, cls_mem, p['xf'].permute(0, 3, 1, 2)
+
+    def track_mixed(self, x, zf, template_mem, score_mem, dtype=torch.float16):
+        """BASELINE config 5: low-precision (fp16 | bf16) backbone + neck on MFMA, fp32 encoders /
+        xcorr / heads.  Same returns as track(); batch = independent streams."""
+        x = _as_dev_f32(x, self.device)
+        b, _, size, _ = x.shape
+        if self._zk_key != (zf.data_ptr(), zf._version, tuple(zf.shape)) or b not in self._zenc:
+            self.set_template(zf)
+        m = int(score_mem.shape[1])
+        key = ('mixed', b, size, m, dtype)
+        if key not in self._track:
+            bld = Builder(self.W, self.tuning, 0)
+            xin = bld.buf(b, 3, size, size)
+            mem = bld.buf(b * m, 7, 7, 256)
+            xf, hf = bld.backbone_bf16(xin, b, size, dtype=dtype, neck_f32=True)
+            bbox, cls2, S = bld.heads(xf, b, hf, self._zenc[b]['zk'], mem, m)
+            self._finish(bld.plan)
+            self._track[key] = dict(x=xin, xf=xf, hf=hf, mem=mem, bbox=bbox, cls2=cls2, S=S, plan=bld.plan, log=bld.log)
+        p = self._track[key]
+        p['x'].copy_(x)
+        p['mem'].copy_(hip.to_nhwc(_as_dev_f32(template_mem, self.device)))
+        p['plan'].run()
+        return p['cls2'][0].clone(), p['bbox'].clone(), p['cls2'][1].clone(), p['xf'].permute(0, 3, 1, 2)
 
     def pool(self, xf, boxes):
         """models.py:164-171: PrRoIPool 7x7, scale 1, batch index prepended -> NCHW dense."""

@@ -24,6 +24,8 @@ EXPORTS = (
     'usot_plan_fork', 'usot_plan_join', 'usot_plan_capture', 'usot_plan_size',
     'usot_groupdw_multi_f32', 'usot_plan_add_groupdw_multi', 'usot_conv2d_batch_f32', 'usot_plan_add_conv_batch', 'usot_conv2d_bf16', 'usot_conv_bf16_tile_count', 'usot_cvt_f32_to_bf16', 'usot_maxpool3x3s2_bf16',
     'usot_plan_add_conv_bf16', 'usot_plan_add_cvt_bf16', 'usot_plan_add_maxpool_bf16',
+    'usot_conv2d_lp', 'usot_cvt_f32_to_lp', 'usot_maxpool3x3s2_lp', 'usot_plan_add_conv_lp', 'usot_plan_add_cvt_lp',
+    'usot_plan_add_maxpool_lp',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
 )
 
@@ -88,6 +90,10 @@ def lib():
         L.usot_rows_copy_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
         L.usot_crop_resize_u8_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 9
         L.usot_plan_add_conv_bf16.argtypes = [C.c_void_p, C.c_void_p]
+        L.usot_plan_add_conv_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.usot_plan_add_cvt_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        L.usot_plan_add_maxpool_lp.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 7
+        L.usot_conv2d_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.usot_plan_add_cvt_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.usot_plan_add_maxpool_bf16.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 6
         L.usot_conv2d_bf16.argtypes = [C.c_void_p, C.c_void_p]
@@ -325,18 +331,22 @@ def decode(cls, cls_mem, bbox, window, S, instance_size, stride, ratio, penalty_
     return out
 
 
-def conv2d_bf16(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, act=ACT_NONE, tile=0):
-    """x NHWC bf16 [N,H,W,Cin], w packed bf16 [Cout, KH*KW*Cin], bias fp32 -> y NHWC bf16."""
-    _dev(x, torch.bfloat16), _dev(w, torch.bfloat16)
+def conv2d_bf16(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, act=ACT_NONE, tile=0, out_f32=False):
+    """x NHWC bf16|fp16 [N,H,W,Cin], w packed same dtype [Cout, KH*KW*Cin], bias fp32 -> y NHWC
+    (same dtype, or fp32 with out_f32)."""
+    lp = x.dtype
+    if lp not in (torch.bfloat16, torch.float16):
+        raise HipError('conv2d_bf16 takes bf16 or fp16 tensors')
+    _dev(x, lp), _dev(w, lp)
     N, H, W_, Cin = x.shape
     Cout = w.shape[0]
     OH = (H + 2 * pad[0] - dil[0] * (KH - 1) - 1) // stride + 1
     OW = (W_ + 2 * pad[1] - dil[1] * (KW - 1) - 1) // stride + 1
-    y = torch.empty((N, OH, OW, Cout), device=x.device, dtype=torch.bfloat16)
+    y = torch.empty((N, OH, OW, Cout), device=x.device, dtype=torch.float32 if out_f32 else lp)
     d = conv_desc(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                   N=N, H=H, W=W_, Cin=Cin, OH=OH, OW=OW, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil,
                   res=res.data_ptr() if res is not None else None, act=act, tile=tile)
-    check(lib().usot_conv2d_bf16(stream(), C.byref(d)), 'usot_conv2d_bf16')
+    check(lib().usot_conv2d_lp(stream(), C.byref(d), 1 if lp == torch.float16 else 0, int(out_f32)), 'usot_conv2d_lp')
     return y
 
 
