@@ -24,10 +24,14 @@ for name, N, H, W, Cin, Cout, k, st, pad, dil in SHAPES:
                           KH=k, KW=k, stride=st, pad=(pad, pad), dil=(dil, dil), act=1, ksplit=ks, tile=tile,
                           ws=ws.data_ptr() if ws is not None else None)
         for _ in range(3): hip.check(L.usot_conv2d_f32(hip.stream(), C.byref(d)))
-        e0.record()
-        for _ in range(20): L.usot_conv2d_f32(hip.stream(), C.byref(d))
-        e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 20 * 1e3
+        # native launch loop: a ctypes call per launch (~7 us) would floor every short kernel
+        plan = C.c_void_p(L.usot_plan_create())
+        for _ in range(20): hip.check(L.usot_plan_add_conv(plan, C.byref(d)))
+        us = 1e30
+        for _ in range(3):
+            e0.record(); hip.check(L.usot_plan_run(plan, hip.stream())); e1.record(); torch.cuda.synchronize()
+            us = min(us, e0.elapsed_time(e1) / 20 * 1e3)
+        L.usot_plan_destroy(plan)
         bm, bn = tiles[tile]
         blocks = -(-M // bm) * -(-Cout // bn) * ks
         print('%-9s M=%5d N=%4d K=%4d tile %2d (%3dx%-3d) ks %2d blocks %4d: %8.1f us %6.1f TFLOP/s' % (

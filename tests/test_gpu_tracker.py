@@ -101,3 +101,41 @@ def test_two_sessions_share_one_engine(net):
             rows1.append([*s1['target_pos'], *s1['target_sz'], float(s1['cls_score'])])
     np.testing.assert_allclose(np.array(rows0), ref0[1:], atol=1e-3, rtol=0)
     np.testing.assert_allclose(np.array(rows1), ref1[1:], atol=1e-3, rtol=0)
+
+
+def _open(net, seed):
+    from usot_amd.tracker import USOTConfig
+    p = USOTConfig()
+    p.renew()
+    p.sf_size = p.score_size
+    t = lambda a: torch.from_numpy(a).cuda()
+    net.pr_pool = True
+    net.template(t(synth.crop(1000 + seed, 1, 127)), template_bbox=torch.tensor([[3.5, 3.5, 10.5, 10.5]]).cuda())
+    crops = t(synth.crop(2000 + seed, 4, 255))
+    roi = torch.tensor([[9.0, 9.0, 16.0, 16.0]]).cuda()
+    feats = [net.extract_memory_feature(ori_x=crops[0:1], search_bbox=roi),
+             net.extract_memory_feature(ori_x=crops[0:1].flip(3), search_bbox=roi)]
+    window = np.outer(np.hanning(p.score_size), np.hanning(p.score_size))
+    return net.engine.open_session(p, window, feats), crops
+
+
+def test_sessions_on_separate_streams_overlap_safely(net):
+    """submit()/collect(): two videos in flight at once on two HIP streams give bit-identical
+    results to running each video alone with frame()."""
+    picks = [[0, 0, 0, 0, 0], [0, 1, 0, 1, 0], [2, 1, 0, 2, 1]]
+    want = []
+    for seed in (3, 4):
+        sess, crops = _open(net, seed)
+        want.append([sess.frame(crops[i], picks[i], (63.5, 63.5)) for i in range(3)])
+    group = [_open(net, seed) + (torch.cuda.Stream(),) for seed in (3, 4)]
+    torch.cuda.synchronize()
+    got = [[], []]
+    for i in range(3):
+        for sess, crops, st in group:
+            with torch.cuda.stream(st):
+                sess.submit(crops[i], picks[i], (63.5, 63.5))
+        for k, (sess, crops, st) in enumerate(group):
+            got[k].append(sess.collect())
+    torch.cuda.synchronize()
+    for k in range(2):
+        np.testing.assert_array_equal(np.array(got[k]), np.array(want[k]))

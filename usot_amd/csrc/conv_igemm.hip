@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 #include "usot_hip.h"
 #include "common.h"
 
@@ -562,7 +563,11 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
 //     producers, tile t : G (tile t+2) -> stage (t+2)%3 ; issue loads of tile t+3 ; barrier
 //     consumers, tile t : rounds of {prefetch next fragments ; MFMAs} ;             barrier
 // stage (t+2)%3 held tile t-1, which every consumer finished before barrier(t-1).
-template <int BM, int BN, int WM, int WN, int BK>
+// D = k-tiles of global loads a producer keeps in flight in registers: with D = 1 the loads of
+// tile t+3 are issued only after those of tile t+2 have landed, so a k-step can never be shorter
+// than one L2/HBM round trip (measured: 32x32x64 steps took ~600 ns with the MFMAs removed);
+// D = 2/3 rotate that many register buffers so a step only waits for loads issued D steps ago.
+template <int BM, int BN, int WM, int WN, int BK, int D = 1>
 __global__ __launch_bounds__(512) void conv_igemm_f32_v3(const ConvBatch bt)
 {
     int pi = 0;
@@ -621,7 +626,8 @@ __global__ __launch_bounds__(512) void conv_igemm_f32_v3(const ConvBatch bt)
             const int co = bn0 + row;
             wp[i] = wg + (long)((row < BN && co < p.Cout) ? co : 0) * p.K + kc * 4 + (long)kt0 * BK;
         }
-        f32x4 xr[XI], wr[WI];
+        f32x4 xr[D][XI], wr[D][WI];
+        bool xz[D][XI];
         const float *xp[XI];
         bool xin[XI];
         int cur_tap = kt0 / cch, cur_cc = kt0 - cur_tap * cch;
@@ -636,17 +642,20 @@ __global__ __launch_bounds__(512) void conv_igemm_f32_v3(const ConvBatch bt)
             }
         };
         set_tap(cur_tap);
-        auto load_tile = [&](bool advance) {
+        auto load_tile = [&](auto dc, bool advance) {
+            constexpr int d = decltype(dc)::value;
             const int c0 = cur_cc * BK;
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (xin[i]) v = *(const f32x4 *)(xp[i] + c0);
-                xr[i] = v;
+                // unconditional load (padding taps read pixel 0 of the tensor and are zeroed at the
+                // LDS store): a branch around the load makes the compiler's vmcnt bookkeeping
+                // conservative and every buffer's last store then drains ALL loads in flight
+                xr[d][i] = *(const f32x4 *)(xin[i] ? xp[i] + c0 : xg + kc * 4);
+                xz[d][i] = xin[i];
             }
 #pragma unroll
             for (int i = 0; i < WI; ++i) {
-                wr[i] = *(const f32x4 *)wp[i];
+                wr[d][i] = *(const f32x4 *)wp[i];
                 wp[i] += advance ? BK : 0;
             }
             if (advance && ++cur_cc == cch) {
@@ -654,27 +663,55 @@ __global__ __launch_bounds__(512) void conv_igemm_f32_v3(const ConvBatch bt)
                 set_tap(++cur_tap);
             }
         };
-        auto store_tile = [&](int st) {
+        auto store_tile = [&](auto dc, int st) {
+            constexpr int d = decltype(dc)::value;
             float *sX = smem + st * STAGE, *sW = sX + BM * LD;
 #pragma unroll
             for (int i = 0; i < XI; ++i)
-                if (BM % RPP == 0 || lr + RPP * i < BM) *(f32x4 *)(sX + (lr + RPP * i) * LD + kc * 4) = xr[i];
+                if (BM % RPP == 0 || lr + RPP * i < BM)
+                    *(f32x4 *)(sX + (lr + RPP * i) * LD + kc * 4) = xz[d][i] ? xr[d][i] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < WI; ++i)
-                if (BN % RPP == 0 || lr + RPP * i < BN) *(f32x4 *)(sW + (lr + RPP * i) * LD + kc * 4) = wr[i];
+                if (BN % RPP == 0 || lr + RPP * i < BN) *(f32x4 *)(sW + (lr + RPP * i) * LD + kc * 4) = wr[d][i];
         };
-        // tiles 0 and 1 before the first barrier, tile 2 in flight
-        if (nt > 0) { load_tile(nt > 1); store_tile(0); }
-        if (nt > 1) { load_tile(nt > 2); store_tile(1); }
-        if (nt > 2) load_tile(nt > 3);
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, D >= 2 ? 1 : 0>;
+        using I2 = std::integral_constant<int, D >= 3 ? 2 : 0>;
+        // Every load below is unconditional (past the last tile the pointers stop advancing and the
+        // last tile is simply fetched again, never stored): the compiler can then count exactly
+        // how many younger loads are in flight and waits with vmcnt(N > 0) instead of draining.
+        // tiles 0 and 1 go to stages 0 and 1 before the first barrier; tiles 2 .. D+1 stay in
+        // flight in register buffers 0 .. D-1 (tile t+2 lives in buffer t % D)
+        int lt = 0;                                   // next tile to fetch
+        auto load_next = [&](auto dc) { load_tile(dc, lt + 1 < nt); ++lt; };
+        if constexpr (D == 1) {
+            load_next(I0{}); store_tile(I0{}, 0);
+            load_next(I0{}); if (nt > 1) store_tile(I0{}, 1);
+        } else {
+            load_next(I0{});
+            load_next(I1{});
+            store_tile(I0{}, 0);
+            if (nt > 1) store_tile(I1{}, 1);
+        }
+        load_next(I0{});
+        if constexpr (D >= 2) load_next(I1{});
+        if constexpr (D >= 3) load_next(I2{});
         __syncthreads();
         int st2 = 2;                                  // stage that receives tile t+2
-        for (int t = 0; t < nt; ++t) {
-            if (t + 2 < nt) store_tile(st2);
-            if (t + 3 < nt) load_tile(t + 4 < nt);
+        auto step = [&](auto dc, int t) {
+            if (t + 2 < nt) store_tile(dc, st2);
+            load_next(dc);
             st2 = st2 == 2 ? 0 : st2 + 1;
             __syncthreads();
+        };
+        int t = 0;
+        for (; t + D <= nt; t += D) {
+            step(I0{}, t);
+            if constexpr (D >= 2) step(I1{}, t + 1);
+            if constexpr (D >= 3) step(I2{}, t + 2);
         }
+        if constexpr (D >= 2) { if (t < nt) { step(I0{}, t); ++t; } }
+        if constexpr (D >= 3) { if (t < nt) { step(I1{}, t); ++t; } }
         return;
     }
 
@@ -816,12 +853,13 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvK p)
     }
 }
 
-struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int threads; };
+struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int threads; int depth; };
 
-#define TILE(bm, bn, wm, wn) { bm, bn, 32, 2, 1, conv_igemm_f32<bm, bn, wm, wn>, 256 }
-#define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v2<bm, bn, wm, wn, bk>, 256 }
-#define TILE3(bm, bn, wm, wn, bk, ksw) { bm, bn, bk, 3, ksw, conv_igemm_f32_v2<bm, bn, wm, wn, bk, ksw>, 256 * ksw }
-#define TILE4(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk>, 512 }
+#define TILE(bm, bn, wm, wn) { bm, bn, 32, 2, 1, conv_igemm_f32<bm, bn, wm, wn>, 256, 1 }
+#define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v2<bm, bn, wm, wn, bk>, 256, 1 }
+#define TILE3(bm, bn, wm, wn, bk, ksw) { bm, bn, bk, 3, ksw, conv_igemm_f32_v2<bm, bn, wm, wn, bk, ksw>, 256 * ksw, 1 }
+#define TILE4(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk>, 512, 1 }
+#define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
     TILE(128, 64, 2, 2),    // 2
@@ -859,6 +897,22 @@ const TileCfg kTiles[] = {
     TILE4(64, 128, 2, 2, 32),   // 34
     TILE4(128, 64, 2, 2, 32),   // 35
     TILE4(32, 128, 2, 2, 64),   // 36
+    TILE5(64, 64, 2, 2, 32, 2),    // 37: v3, two k-tiles of loads in flight per producer
+    TILE5(64, 64, 2, 2, 64, 2),    // 38
+    TILE5(32, 64, 2, 2, 64, 2),    // 39
+    TILE5(128, 128, 2, 2, 32, 2),  // 40
+    TILE5(32, 32, 2, 2, 64, 2),    // 41
+    TILE5(64, 128, 2, 2, 32, 2),   // 42
+    TILE5(128, 64, 2, 2, 32, 2),   // 43
+    TILE5(32, 128, 2, 2, 64, 2),   // 44
+    TILE5(64, 64, 2, 2, 32, 3),    // 45: three in flight
+    TILE5(64, 64, 2, 2, 64, 3),    // 46
+    TILE5(32, 64, 2, 2, 64, 3),    // 47
+    TILE5(128, 128, 2, 2, 32, 3),  // 48
+    TILE5(32, 32, 2, 2, 64, 3),    // 49
+    TILE5(64, 128, 2, 2, 32, 3),   // 50
+    TILE5(128, 64, 2, 2, 32, 3),   // 51
+    TILE5(32, 128, 2, 2, 64, 3),   // 52
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -898,6 +952,7 @@ extern "C" int usot_conv_tile_name(int tile, char *buf, int len)
     const TileCfg &t = kTiles[tile - 1];
     const char *fam = t.threads == 512 && t.ksw == 1 ? "conv_igemm_f32_v3" : (t.stages == 3 ? "conv_igemm_f32_v2" : "conv_igemm_f32");
     if (t.stages == 3 && t.ksw > 1) snprintf(buf, len, "%s<%d,%d,%d,%d> ksw=%d", fam, t.bm, t.bn, t.bk, t.ksw, t.ksw);
+    else if (t.depth > 1)           snprintf(buf, len, "%s<%d,%d,BK=%d,D=%d>", fam, t.bm, t.bn, t.bk, t.depth);
     else if (t.stages == 3)         snprintf(buf, len, "%s<%d,%d,BK=%d>", fam, t.bm, t.bn, t.bk);
     else                            snprintf(buf, len, "%s<%d,%d>", fam, t.bm, t.bn);
     return USOT_OK;

@@ -725,10 +725,9 @@ class Session:
         self.bank, self.cap = bank, self.cap * 2
         self._build()
 
-    def frame(self, x_crop, picks, tsz_scaled, resident=False):
-        """Run one frame.  x_crop: CHW float tensor (host or device); picks: memory indices
-        of the N_q-2 sampled slots; tsz_scaled: target size * scale_z.
-        Returns float64[8] = (argmax, score, penalty, x1, y1, x2, y2, pscore)."""
+    def submit(self, x_crop, picks, tsz_scaled, resident=False):
+        """Enqueue one frame on the CURRENT stream and return immediately (several sessions on
+        separate streams overlap on the GPU).  Pair with collect()."""
         self._ensure_capacity()
         if not resident:
             if x_crop.is_cuda:
@@ -737,20 +736,30 @@ class Session:
                 np.copyto(self._x_host_np, x_crop.numpy().reshape(self._x_host_np.shape))
                 self.x.copy_(self.x_host, non_blocking=True)
         self._set_ctl([0, 1] + [2 + int(i) for i in picks], 2 + self.n, tsz_scaled)
-        tag = float(self.n)
-        self._ctl_f64[6] = tag
+        self._tag = float(self.n)
+        self._ctl_f64[6] = self._tag
+        self._stream = torch.cuda.current_stream()
         self.plan.run()
-        # the decode kernel publishes the result block and then the tag: poll it rather than
-        # sleeping in hipStreamSynchronize (the PrRoIPool + bank append behind it are ordered
-        # before the next frame by the stream)
-        out = self._out_np
+
+    def collect(self):
+        """Wait for the submitted frame's result block: float64[8] = (argmax, score, penalty,
+        x1, y1, x2, y2, pscore).  The decode kernel publishes the results and then the tag: poll it
+        rather than sleeping in hipStreamSynchronize (the PrRoIPool + bank append behind it are
+        ordered before the next frame by the stream)."""
+        out, tag = self._out_np, self._tag
         for _ in range(200000):
             if out[8] == tag:
                 break
         else:
-            torch.cuda.current_stream().synchronize()
+            self._stream.synchronize()
         self.n += 1
         return out[:8].copy()
+
+    def frame(self, x_crop, picks, tsz_scaled, resident=False):
+        """Run one frame.  x_crop: CHW float tensor (host or device); picks: memory indices
+        of the N_q-2 sampled slots; tsz_scaled: target size * scale_z."""
+        self.submit(x_crop, picks, tsz_scaled, resident)
+        return self.collect()
 
     def frame_from_image(self, im, pos, win, avg_chans, picks, tsz_scaled):
         """Whole frame from the raw image: upload the uint8 frame, crop/pad/resize on the
