@@ -87,6 +87,12 @@ int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, int out_f32
 int usot_cvt_f32_to_lp(void *stream, const float *src, void *dst, int64_t n, int dtype);
 int usot_maxpool3x3s2_lp(void *stream, const void *x, void *y, int N, int H, int W, int C, int OH, int OW, int dtype);
 int usot_conv_bf16_tile_count(void);
+/* fused low-precision stem (7x7/s2 conv + BN + ReLU) + 3x3/s2/p1 max-pool on the bf16|fp16 MFMA:
+ * modules.py:70-74,138-141 in one launch.  wfrag: filter bank as MFMA A fragments [4][6][64][8].
+ * The kernel convolves x - mu[ci]; bias must already contain sum_k w[co][k] * mu[ci(k)]. */
+int usot_stem_pool_lp(void *stream, const float *x, const void *wfrag, const float *bias, void *y,
+                      int N, int H, int W, int OH, int OW, int PH, int PW, int dtype,
+                      float mu0, float mu1, float mu2);
 int usot_cvt_f32_to_bf16(void *stream, const float *src, void *dst, int64_t n);
 int usot_maxpool3x3s2_bf16(void *stream, const void *x, void *y, int N, int H, int W, int C, int OH, int OW);
 
@@ -206,6 +212,9 @@ int usot_plan_add_conv_bf16(void *plan, const usot_conv_desc *d);
 int usot_plan_add_conv_lp(void *plan, const usot_conv_desc *d, int dtype, int out_f32);
 int usot_plan_add_cvt_lp(void *plan, const float *src, void *dst, int64_t n, int dtype);
 int usot_plan_add_maxpool_lp(void *plan, const void *x, void *y, int N, int H, int W, int C, int OH, int OW, int dtype);
+int usot_plan_add_stem_pool_lp(void *plan, const float *x, const void *wfrag, const float *bias, void *y,
+                               int N, int H, int W, int OH, int OW, int PH, int PW, int dtype,
+                      float mu0, float mu1, float mu2);
 int usot_plan_add_cvt_bf16(void *plan, const float *src, void *dst, int64_t n);
 int usot_plan_add_maxpool_bf16(void *plan, const void *x, void *y, int N, int H, int W, int C, int OH, int OW);
 int usot_plan_add_groupdw(void *plan, const usot_groupdw_desc *d);

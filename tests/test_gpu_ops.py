@@ -315,7 +315,9 @@ def test_rows_copy_gather_scatter():
     assert torch.equal(out, bank[idx.long()])
     dst = torch.zeros(16, 64, device=DEV)
     hip.check(hip.lib().usot_rows_copy_f32(hip.stream(), hip.ptr(out), hip.ptr(idx), hip.ptr(dst), 4, 64, 1), 'scatter')
-    assert torch.equal(dst[idx.long()], out) and float(dst.abs().sum()) == float(out.abs().sum())
+    want = torch.zeros(16, 64, device=DEV)
+    want[idx.long()] = out
+    assert torch.equal(dst, want)          # rows not named stay untouched
 
 
 def test_plan_run_capture_and_lanes():
@@ -381,3 +383,30 @@ def test_decode_dev_writes_roi_and_tag(gold_host):
     assert o[8] == 42.0
     np.testing.assert_array_equal(roi.cpu().numpy()[1:], gold_host[c + '/out_poolbox'][0])
     assert roi.cpu().numpy()[0] == 0.0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('size,n', [(255, 2), (127, 1), (271, 1), (63, 3)])
+def test_stem_pool_lp(size, n, dtype):
+    """Fused MFMA stem + max-pool vs torch on the SAME rounded operands (filters rounded to the
+    storage type; crop rounded to fp16, or to hi + lo bf16 pairs; fp32 accumulate): differences are
+    accumulation order + one final rounding, i.e. at most 1 ulp of the storage type."""
+    from usot_amd.engine import pack_stem_lp
+    g = torch.Generator().manual_seed(size + n)
+    x = (torch.rand(n, 3, size, size, generator=g) * 2 - 1) * 3
+    mu = (0.25, -0.5, 1.0)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    b = torch.randn(64, generator=g) * 0.1
+    packed = w.permute(1, 2, 3, 0).reshape(147, 64).contiguous()
+    got = hip.stem_pool_lp(x.to(DEV), pack_stem_lp(packed, dtype).to(DEV), b.to(DEV), dtype, mu).float().cpu()
+    xc = x - torch.tensor(mu).view(1, 3, 1, 1)
+    xr, wr = xc.to(dtype).double(), w.to(dtype).double()
+    if dtype == torch.bfloat16:
+        xr = xr + (xc - xc.to(dtype).float()).to(dtype).double()
+    ref = torch.relu(F.conv2d(xr, wr, b.double(), stride=2)).float().to(dtype).float()
+    ref = F.max_pool2d(ref, 3, 2, 1).permute(0, 2, 3, 1)
+    assert got.shape == ref.shape
+    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    err = (got - ref).abs() / ref.abs().clamp_min(1.0)
+    assert float(err.max()) <= 1.01 * ulp, float(err.max())
+    assert float((err > 0).float().mean()) < 0.02          # the rare 1-ulp rounding flips only

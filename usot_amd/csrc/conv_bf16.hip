@@ -55,7 +55,7 @@ constexpr int BKB = 64;            // k-tile in bf16 elements
 constexpr int LDC = 9;             // 16-byte chunks per LDS row (8 data + 1 pad)
 
 template <int BM, int BN, int WM, int WN, bool F16>
-__global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvB p)
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvB p)
 {
     static_assert(WM * WN == 4, "4 wavefronts");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -173,6 +173,66 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvB p)
         __syncthreads();
     }
 
+    // Epilogue.  The accumulator layout gives a lane four channels of one pixel: stored
+    // directly that is 8-byte pieces scattered over 16 pixel rows per instruction, and the
+    // residual is read the same way (measured 1.1-1.4 TB/s on the 1x1 expansion convs, which
+    // are pure HBM traffic).  Instead the fp32 tile is transposed through LDS (free after the
+    // k-loop) so that every lane handles 8 consecutive channels: 16-byte residual loads and
+    // 16-byte stores, 16 lanes per 256-byte row segment.
+    constexpr int OP = BN + 4;                       // fp32 row pitch: 4*odd dwords -> conflict-free
+    if (!p.out_f32 && (p.Cout & 7) == 0) {
+        float *sO = (float *)smem4;
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                *(f32x4 *)(sO + ((wm * TM + j) * 16 + l15) * OP + (wn * TN + i) * 16 + quad * 4) = acc[i][j];
+        __syncthreads();
+        constexpr int CPRW = BN / 8;                 // 16-byte output chunks per row
+        constexpr int RPASS = 256 / CPRW;            // rows per pass
+        constexpr int NP = (BM + RPASS - 1) / RPASS;
+        const int oc = tid % CPRW, orow = tid / CPRW;
+        const int co = bn0 + oc * 8;
+        const bool cok = co < p.Cout;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (p.bias && cok) { b0 = *(const f32x4 *)(p.bias + co); b1 = *(const f32x4 *)(p.bias + co + 4); }
+        constexpr int CH = NP < 4 ? NP : 4;          // residual loads in flight per lane
+#pragma unroll 1
+        for (int q0 = 0; q0 < NP; q0 += CH) {
+            u32x4 rr[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int r = orow + (q0 + q) * RPASS, m = bm0 + r;
+                rr[q] = u32x4{0u, 0u, 0u, 0u};
+                if (p.res && cok && r < BM && m < p.M) rr[q] = *(const u32x4 *)(p.res + (long)m * p.Cout + co);
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int r = orow + (q0 + q) * RPASS, m = bm0 + r;
+                if (!cok || r >= BM || m >= p.M) continue;
+                f32x4 v0 = *(const f32x4 *)(sO + r * OP + oc * 8) + b0;
+                f32x4 v1 = *(const f32x4 *)(sO + r * OP + oc * 8 + 4) + b1;
+                if (p.res) {
+                    v0[0] += unpack_lp<F16>(rr[q][0] & 0xffffu); v0[1] += unpack_lp<F16>(rr[q][0] >> 16);
+                    v0[2] += unpack_lp<F16>(rr[q][1] & 0xffffu); v0[3] += unpack_lp<F16>(rr[q][1] >> 16);
+                    v1[0] += unpack_lp<F16>(rr[q][2] & 0xffffu); v1[1] += unpack_lp<F16>(rr[q][2] >> 16);
+                    v1[2] += unpack_lp<F16>(rr[q][3] & 0xffffu); v1[3] += unpack_lp<F16>(rr[q][3] >> 16);
+                }
+                if (p.act == USOT_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                }
+                u32x4 o;
+                o[0] = pack_lp<F16>(v0[0]) | (pack_lp<F16>(v0[1]) << 16);
+                o[1] = pack_lp<F16>(v0[2]) | (pack_lp<F16>(v0[3]) << 16);
+                o[2] = pack_lp<F16>(v1[0]) | (pack_lp<F16>(v1[1]) << 16);
+                o[3] = pack_lp<F16>(v1[2]) | (pack_lp<F16>(v1[3]) << 16);
+                *(u32x4 *)(p.y + (long)m * p.Cout + co) = o;
+            }
+        }
+        return;
+    }
+
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = bm0 + (wm * TM + j) * 16 + l15;
@@ -266,6 +326,153 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bf16_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Low-precision stem: 7x7/s2 conv (3 -> 64) + folded BN + ReLU + 3x3/s2/p1 max-pool in one
+// kernel, on v_mfma_f32_16x16x32_{bf16,f16}.  modules.py:70-74,138-141.
+//
+// K = 147 is too ragged for the generic implicit GEMM, so the k axis is laid out as
+// 24 rows x 8: row r = ci*7 + kh (21 real rows, 3 zero rows), 8 = kw 0..6 + one zero tap.
+// A lane's B fragment for k-step s is then the 8 consecutive input pixels
+// x[ci][2*sy+kh][2*sx .. 2*sx+7] of row r = 4*s + quad: four 4-byte LDS reads from the
+// staged input patch (the eighth pixel meets a zero weight).  The crop is staged as x - mu[ci]
+// (mu: constant per input channel, its product with the UNROUNDED filters is folded into the bias
+// by the host): stem filters are close to zero-sum while raw 0..255 pixels carry a large mean, so
+// rounding the filters to 8-11 bits would otherwise leak mean * sum(dw) into every output.  The 64x192 filter bank lives in
+// registers as pre-swizzled A fragments (host layout [cblk][kstep][lane][8]).
+// A workgroup owns a 4x8 tile of POOLED pixels = a 9x17 tile of stem pixels (one halo row /
+// column, recomputed: x1.2) = a 23x39 patch of the crop.  Stem outputs go to LDS in the
+// storage type, the pool reads them back 8 channels per lane and writes NHWC 16-byte pieces:
+// the 125x125x64 stem map never reaches HBM (256 MB fp32 + 128 MB at batch 64 before).
+constexpr int SP_P = 4, SP_Q = 8;                   // pooled tile
+constexpr int SP_R = 2 * SP_P + 1, SP_C = 2 * SP_Q + 1;   // 9 x 17 stem pixels
+constexpr int SP_NPIX = SP_R * SP_C;                // 153
+constexpr int SP_NBLK = (SP_NPIX + 15) / 16;        // 10 MFMA pixel blocks
+constexpr int SP_IR = 2 * SP_R + 5, SP_IC = 2 * SP_C + 5;   // 23 x 39 input patch
+constexpr int SP_ICP = 40;                          // padded patch row (elements)
+constexpr int SP_OPB = 144;                         // stem-tile LDS row pitch in bytes (64 ch * 2 + 16)
+
+template <bool F16>
+__global__ __launch_bounds__(256) void stem_pool_lp_kernel(
+    const float *__restrict__ x, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
+    uint16_t *__restrict__ y, int H, int W, int OH, int OW, int PH, int PW, float mu0, float mu1, float mu2)
+{
+    // bf16 keeps 8 significant bits: rounding the CROP to bf16 doubles the end-to-end error of the
+    // whole backbone (measured 4e-2 -> 8e-2 of the feature scale), so the bf16 variant stages the
+    // crop as hi + lo (two bf16, ~16 bits) and issues two MFMAs per fragment; fp16 (11 bits) does not.
+    constexpr bool SPLIT = !F16;
+    constexpr int PLANE = 3 * SP_IR * SP_ICP;
+    __shared__ __attribute__((aligned(16))) uint16_t patch[(SPLIT ? 2 : 1) * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char stile[SP_NBLK * 16 * SP_OPB];
+    const int n = blockIdx.z;
+    const int py0 = blockIdx.y * SP_P, px0 = blockIdx.x * SP_Q;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
+    const int iy0 = 2 * sy0, ix0 = 2 * sx0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, quad = lane >> 4;
+
+    // filter fragments: 4 channel blocks x 6 k-steps, 16 bytes each, coalesced
+    u32x4 wf[4][6];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) wf[cb][ks] = wfrag[(cb * 6 + ks) * 64 + lane];
+
+    // input patch -> LDS in the storage type (out-of-image pixels and the pad column are zero;
+    // they only ever feed stem pixels the pool masks out, or zero weights)
+    const float *xn = x + (long)n * 3 * H * W;
+    for (int i = tid; i < 3 * SP_IR * SP_ICP; i += 256) {
+        const int ci = i / (SP_IR * SP_ICP), r = i - ci * SP_IR * SP_ICP;
+        const int py = r / SP_ICP, px = r - py * SP_ICP;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v = 0.f;
+        if (px < SP_IC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            v = xn[((long)ci * H + iy) * W + ix] - (ci == 0 ? mu0 : (ci == 1 ? mu1 : mu2));
+        const uint32_t hi = pack_lp<F16>(v);
+        patch[i] = (uint16_t)hi;
+        if constexpr (SPLIT) patch[PLANE + i] = (uint16_t)pack_lp<F16>(v - unpack_lp<F16>(hi));
+    }
+    __syncthreads();
+
+    f32x4 bv[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) bv[cb] = *(const f32x4 *)(bias + cb * 16 + quad * 4);
+
+    for (int blk = wave; blk < SP_NBLK; blk += 4) {
+        int pi = blk * 16 + l15;
+        if (pi > SP_NPIX - 1) pi = SP_NPIX - 1;
+        const int sy = pi / SP_C, sx = pi - sy * SP_C;
+        f32x4 acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            int r = 4 * ks + quad;
+            if (r > 20) r = 20;                          // zero-weight rows: any valid address
+            const int ci = r / 7, kh = r - ci * 7;
+            const uint32_t *src = (const uint32_t *)(patch + (ci * SP_IR + 2 * sy + kh) * SP_ICP + 2 * sx);
+            u32x4 xf;
+            xf[0] = src[0]; xf[1] = src[1]; xf[2] = src[2]; xf[3] = src[3];
+            if constexpr (F16) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[cb][ks]),
+                                                                     __builtin_bit_cast(f16x8, xf), acc[cb], 0, 0, 0);
+            } else {
+                const uint32_t *srl = src + PLANE / 2;
+                u32x4 xl;
+                xl[0] = srl[0]; xl[1] = srl[1]; xl[2] = srl[2]; xl[3] = srl[3];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cb][ks]),
+                                                                      __builtin_bit_cast(bf16x8, xf), acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cb][ks]),
+                                                                      __builtin_bit_cast(bf16x8, xl), acc[cb], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            f32x4 v = acc[cb] + bv[cb];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            u32x2 o;
+            o[0] = pack_lp<F16>(v[0]) | (pack_lp<F16>(v[1]) << 16);
+            o[1] = pack_lp<F16>(v[2]) | (pack_lp<F16>(v[3]) << 16);
+            *(u32x2 *)(stile + (blk * 16 + l15) * SP_OPB + (cb * 16 + quad * 4) * 2) = o;
+        }
+    }
+    __syncthreads();
+
+    // 3x3 / stride 2 / pad 1 max-pool: one pooled pixel x 8 channels per lane
+    const int pp = tid >> 3, c8 = tid & 7;
+    const int ppy = pp / SP_Q, ppx = pp - ppy * SP_Q;
+    const int py = py0 + ppy, px = px0 + ppx;
+    if (py >= PH || px >= PW) return;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int ly = 2 * ppy + dy, gy = sy0 + ly;
+        if ((unsigned)gy >= (unsigned)OH) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int lx = 2 * ppx + dx, gx = sx0 + lx;
+            if ((unsigned)gx >= (unsigned)OW) continue;
+            const u32x4 v = *(const u32x4 *)(stile + (ly * SP_C + lx) * SP_OPB + c8 * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m[2 * e] = fmaxf(m[2 * e], unpack_lp<F16>(v[e] & 0xffffu));
+                m[2 * e + 1] = fmaxf(m[2 * e + 1], unpack_lp<F16>(v[e] >> 16));
+            }
+        }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_lp<F16>(m[2 * e]) | (pack_lp<F16>(m[2 * e + 1]) << 16);
+    *(u32x4 *)(y + ((((long)n * PH + py) * PW + px) * 64 + c8 * 8)) = o;
+}
+
 }  // namespace
 
 extern "C" int usot_conv_bf16_tile_count(void) { return kNumTilesB; }
@@ -284,7 +491,7 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     const int ow = (d->W + 2 * d->pad_w - d->dil_w * (d->KW - 1) - 1) / d->stride + 1;
     if (oh != d->OH || ow != d->OW || oh <= 0 || ow <= 0) return USOT_EINVAL;
     if (((uintptr_t)d->x % 16) || ((uintptr_t)d->w % 16) || ((uintptr_t)d->y % (out_f32 ? 16 : 8)) ||
-        (d->res && (uintptr_t)d->res % 8) || (d->bias && (uintptr_t)d->bias % 16)) return USOT_EINVAL;
+        (d->res && (uintptr_t)d->res % 16) || (d->bias && (uintptr_t)d->bias % 16)) return USOT_EINVAL;
     ConvB p;
     p.x = (const uint16_t *)d->x; p.w = (const uint16_t *)d->w; p.res = (const uint16_t *)d->res;
     p.bias = d->bias; p.y = (uint16_t *)d->y;
@@ -304,7 +511,9 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     p.NT = (d->Cout + tc.bn - 1) / tc.bn;
     const long blocks = (long)p.MT * p.NT;
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
-    const size_t lds = (size_t)2 * (tc.bm + tc.bn) * LDC * 16;
+    size_t lds = (size_t)2 * (tc.bm + tc.bn) * LDC * 16;
+    const size_t lds_out = (size_t)tc.bm * (tc.bn + 4) * 4;      // fp32 staging tile of the epilogue
+    if (lds_out > lds) lds = lds_out;
     hipLaunchKernelGGL(dtype ? tc.fn16 : tc.fn, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
@@ -345,4 +554,23 @@ extern "C" int usot_maxpool3x3s2_lp(void *stream, const void *x, void *y, int N,
 extern "C" int usot_maxpool3x3s2_bf16(void *stream, const void *x, void *y, int N, int H, int W, int C, int OH, int OW)
 {
     return usot_maxpool3x3s2_lp(stream, x, y, N, H, W, C, OH, OW, 0);
+}
+
+/* Fused low-precision stem + max-pool.  x NCHW fp32 [N][3][H][W]; wfrag = the 64x147 filter bank
+ * (BN folded) in the storage type, pre-swizzled as MFMA A fragments [4][6][64][8] (see
+ * usot_amd/engine.py: pack_stem_lp); bias fp32[64] INCLUDING sum_k w[co][k] * mu[ci(k)] (the kernel
+ * convolves x - mu); y NHWC [N][PH][PW][64] in the storage type. */
+extern "C" int usot_stem_pool_lp(void *stream, const float *x, const void *wfrag, const float *bias, void *y,
+                                 int N, int H, int W, int OH, int OW, int PH, int PW, int dtype,
+                                 float mu0, float mu1, float mu2)
+{
+    if (!x || !wfrag || !bias || !y || N <= 0 || H < 7 || W < 7 || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
+    if (OH != (H - 7) / 2 + 1 || OW != (W - 7) / 2 + 1) return USOT_EINVAL;
+    if (PH != (OH + 2 - 3) / 2 + 1 || PW != (OW + 2 - 3) / 2 + 1) return USOT_EINVAL;
+    if (((uintptr_t)wfrag % 16) || ((uintptr_t)y % 16) || ((uintptr_t)bias % 16) || N > 65535) return USOT_EINVAL;
+    dim3 grid(usot_cdiv(PW, SP_Q), usot_cdiv(PH, SP_P), N);
+    if (dtype) hipLaunchKernelGGL(stem_pool_lp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2);
+    else       hipLaunchKernelGGL(stem_pool_lp_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
 }

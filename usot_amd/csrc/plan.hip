@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -39,7 +39,7 @@ struct Op {
     const void *p[6];
     int i[8];
     int64_t l[8];
-    float f[2];
+    float f[4];
     double d[2];
 };
 
@@ -107,6 +107,10 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
         case K_CVTB:  rc = usot_cvt_f32_to_lp(s, (const float *)op.p[0], (void *)op.p[1], op.l[0], op.i[6]); break;
         case K_POOLB:
             rc = usot_maxpool3x3s2_lp(s, op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6]);
+            break;
+        case K_STEMB:
+            rc = usot_stem_pool_lp(s, (const float *)op.p[0], op.p[1], (const float *)op.p[2], (void *)op.p[3], op.i[0], op.i[1],
+                                   op.i[2], op.i[3], op.i[4], op.i[5], op.i[7], op.i[6], op.f[1], op.f[2], op.f[3]);
             break;
         case K_ROWS:
             rc = usot_rows_copy_f32(s, (const float *)op.p[0], (const int32_t *)op.p[1], (float *)op.p[2],
@@ -218,6 +222,18 @@ extern "C" int usot_plan_add_cvt_lp(void *plan, const float *src, void *dst, int
     Op *op = push(plan, K_CVTB);
     if (!op) return USOT_ESTATE;
     op->p[0] = src; op->p[1] = dst; op->l[0] = n; op->i[6] = dtype;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_stem_pool_lp(void *plan, const float *x, const void *wfrag, const float *bias, void *y,
+                                          int N, int H, int W, int OH, int OW, int PH, int PW, int dtype,
+                                          float mu0, float mu1, float mu2)
+{
+    Op *op = push(plan, K_STEMB);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = x; op->p[1] = wfrag; op->p[2] = bias; op->p[3] = y;
+    op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = OH; op->i[4] = OW; op->i[5] = PH; op->i[7] = PW; op->i[6] = dtype;
+    op->f[1] = mu0; op->f[2] = mu1; op->f[3] = mu2;
     return USOT_OK;
 }
 

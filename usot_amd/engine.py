@@ -83,6 +83,7 @@ class Weights:
         s = f.bn1.weight.detach().double().cpu() / torch.sqrt(f.bn1.running_var.detach().double().cpu() + f.bn1.eps)
         self.stem_w = (w * s.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(147, 64).float().contiguous().to(device)
         self.stem_b = (f.bn1.bias.detach().double().cpu() - f.bn1.running_mean.detach().double().cpu() * s).float().to(device)
+        self._stem_lp = {}
         self.blocks = []
         for layer in (f.layer1, f.layer2, f.layer3):
             for blk in layer:
@@ -105,6 +106,30 @@ class Weights:
         self.cls_preds = pack(device, [(cm.cls_pred, None), (cm.cls_memory_pred, None)], scale=0.1)
         sm = lambda p: torch.softmax(p.detach().float().cpu(), 0).numpy()
         self.cls_wsm, self.reg_wsm = sm(cm.cls_dw.weight), sm(cm.reg_dw.weight)
+
+    # the low-precision stem convolves x - STEM_MU[ci] (raw BGR 0..255 crops, test_utils.py
+    # feeds them unnormalised) and carries the exact mu term in its bias
+    STEM_MU = (104.0, 117.0, 123.0)
+
+    def stem_lp(self, dtype):
+        """(filter fragments in `dtype`, fp32 bias with the folded mu term)."""
+        if dtype not in self._stem_lp:
+            w = self.stem_w.double().cpu().reshape(3, 49, 64)
+            mu = torch.tensor(self.STEM_MU, dtype=torch.float64).view(3, 1, 1)
+            bias = (self.stem_b.double().cpu() + (w * mu).sum((0, 1))).float().to(self.device)
+            self._stem_lp[dtype] = (pack_stem_lp(self.stem_w, dtype).to(self.device), bias)
+        return self._stem_lp[dtype]
+
+
+def pack_stem_lp(stem_w, dtype):
+    """[147][64] folded stem filters -> MFMA A fragments [4 cblk][6 kstep][64 lanes][8] for
+    usot_stem_pool_lp: lane (l15, quad) of channel block cb, k-step ks holds channel cb*16 + l15,
+    k-row r = 4*ks + quad (r = ci*7 + kh; rows 21..23 zero) and taps kw 0..6 (+ one zero tap)."""
+    w = stem_w.detach().float().cpu().reshape(3, 7, 7, 64)                 # [ci][kh][kw][co]
+    rows = torch.zeros(24, 8, 64)
+    rows[:21, :7] = w.reshape(21, 7, 64)
+    frag = rows.reshape(6, 4, 8, 4, 16).permute(3, 0, 1, 4, 2)             # [cb][ks][quad][l15][8]
+    return frag.reshape(4, 6, 64, 8).to(dtype).contiguous()
 
 
 class Plan:
@@ -307,20 +332,17 @@ class Builder:
 
     def backbone_bf16(self, x, n, size, dtype=torch.bfloat16, neck_f32=False):
         """x NCHW fp32 [n,3,s,s] -> neck output NHWC bf16|fp16 (or fp32 with neck_f32)
-        [n,hf,hf,256].  The stem stays the fp32 VALU kernel (K = 147); its output is packed to
-        the low-precision type once."""
+        [n,hf,hf,256].  Stem + max-pool are one MFMA kernel (usot_stem_pool_lp): the crop is
+        rounded to the storage type as it is staged, the 125x125 stem map never leaves LDS."""
         W, L = self.W, hip.lib()
         dt = 1 if dtype == torch.float16 else 0
         oh = (size - 7) // 2 + 1
-        s0 = self.buf(n, oh, oh, 64)
-        hip.check(L.usot_plan_add_stem(self.plan.h, hip.ptr(x), hip.ptr(W.stem_w), hip.ptr(W.stem_b), hip.ptr(s0),
-                                       n, size, size, oh, oh), 'plan_add_stem')
-        s0b = self.buf(n, oh, oh, 64, dtype=dtype)
-        hip.check(L.usot_plan_add_cvt_lp(self.plan.h, hip.ptr(s0), hip.ptr(s0b), s0.numel(), dt), 'plan_add_cvt_lp')
         ph = (oh - 1) // 2 + 1
         p0 = self.buf(n, ph, ph, 64, dtype=dtype)
-        hip.check(L.usot_plan_add_maxpool_lp(self.plan.h, hip.ptr(s0b), hip.ptr(p0), n, oh, oh, 64, ph, ph, dt),
-                  'plan_add_maxpool_lp')
+        wf, wb = W.stem_lp(dtype)
+        hip.check(L.usot_plan_add_stem_pool_lp(self.plan.h, hip.ptr(x), hip.ptr(wf), hip.ptr(wb), hip.ptr(p0),
+                                               n, size, size, oh, oh, ph, ph, dt, *W.STEM_MU), 'plan_add_stem_pool_lp')
+        self.plan.keep += [wf, wb]
         self.plan.keep += [x]
         cur, h = p0, ph
         for bi, (c1, c2, c3, ds) in enumerate(W.blocks):

@@ -25,7 +25,7 @@ EXPORTS = (
     'usot_groupdw_multi_f32', 'usot_plan_add_groupdw_multi', 'usot_conv2d_batch_f32', 'usot_plan_add_conv_batch', 'usot_conv2d_bf16', 'usot_conv_bf16_tile_count', 'usot_cvt_f32_to_bf16', 'usot_maxpool3x3s2_bf16',
     'usot_plan_add_conv_bf16', 'usot_plan_add_cvt_bf16', 'usot_plan_add_maxpool_bf16',
     'usot_conv2d_lp', 'usot_cvt_f32_to_lp', 'usot_maxpool3x3s2_lp', 'usot_plan_add_conv_lp', 'usot_plan_add_cvt_lp',
-    'usot_plan_add_maxpool_lp',
+    'usot_plan_add_maxpool_lp', 'usot_stem_pool_lp', 'usot_plan_add_stem_pool_lp',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
 )
 
@@ -94,6 +94,8 @@ def lib():
         L.usot_plan_add_cvt_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.usot_plan_add_maxpool_lp.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 7
         L.usot_conv2d_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.usot_stem_pool_lp.argtypes = [C.c_void_p] * 5 + [C.c_int] * 8 + [C.c_float] * 3
+        L.usot_plan_add_stem_pool_lp.argtypes = [C.c_void_p] * 5 + [C.c_int] * 8 + [C.c_float] * 3
         L.usot_plan_add_cvt_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.usot_plan_add_maxpool_bf16.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 6
         L.usot_conv2d_bf16.argtypes = [C.c_void_p, C.c_void_p]
@@ -212,6 +214,22 @@ def stem_conv(x, w, bias):
     OH, OW = (H - 7) // 2 + 1, (W_ - 7) // 2 + 1
     y = torch.empty((N, OH, OW, 64), device=x.device, dtype=torch.float32)
     check(lib().usot_stem_conv_f32(stream(), ptr(x), ptr(w), ptr(bias), ptr(y), N, H, W_, OH, OW), 'usot_stem_conv_f32')
+    return y
+
+
+def stem_pool_lp(x, wfrag, bias, dtype=torch.bfloat16, mu=(0.0, 0.0, 0.0)):
+    """Fused low-precision stem + max-pool: x NCHW fp32 -> NHWC [N][PH][PW][64] in `dtype`;
+    wfrag from usot_amd.engine.pack_stem_lp; the kernel convolves x - mu[ci] (bias must hold the
+    folded mu term)."""
+    _dev(x), _dev(wfrag, dtype), _dev(bias)
+    N, c, H, W_ = x.shape
+    assert c == 3 and x.is_contiguous()
+    OH, OW = (H - 7) // 2 + 1, (W_ - 7) // 2 + 1
+    PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    y = torch.empty((N, PH, PW, 64), device=x.device, dtype=dtype)
+    check(lib().usot_stem_pool_lp(stream(), ptr(x), ptr(wfrag), ptr(bias), ptr(y), N, H, W_, OH, OW, PH, PW,
+                                  1 if dtype == torch.float16 else 0, float(mu[0]), float(mu[1]), float(mu[2])),
+          'usot_stem_pool_lp')
     return y
 
 
