@@ -7,9 +7,10 @@
 // so bias / residual / ReLU / the bf16 pack are per-lane and the store is 8 bytes.
 // A lane feeds one MFMA with 8 consecutive k (16 bytes) of its row: one ds_read_b128 per
 // operand per 16x16x32 step, quad q of the wave owning k-chunk q.  k-tile = 64 bf16 (128 B
-// per row, padded to 144 B in LDS), register-staged double buffering as in conv_igemm_f32.
+// per row, XOR-swizzled in LDS), register-staged double buffering as in conv_igemm_f32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "usot_hip.h"
 #include "common.h"
 
@@ -52,31 +53,56 @@ template <bool F16> __device__ __forceinline__ uint32_t pack_lp(float f) { retur
 template <bool F16> __device__ __forceinline__ float unpack_lp(uint32_t h) { return F16 ? h2f(h) : bf2f(h); }
 
 constexpr int BKB = 64;            // k-tile in bf16 elements
-constexpr int LDC = 9;             // 16-byte chunks per LDS row (8 data + 1 pad)
+// LDS rows are 8 x 16-byte chunks (64 elements), unpadded, with the chunk index XOR-swizzled by
+// f(row) = (row >> 1) & 7.  ds_read_b128 is served in the lane groups {0-3,12-15,20-27},
+// {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS table), 64 banks x 4 B: with a lane reading
+// chunk (4*ks + quad) of row l15 this swizzle gives each group 16 distinct 16-byte slots of the
+// 256-byte bank line (the former 144-byte padded pitch was 2-way conflicted in 7 of 8 slots).
+// The staging writes (8 consecutive lanes = one row's 8 chunks) stay conflict-free.
+constexpr int LDC = 8;
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};     // source of padding taps (LDS-DMA)
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-template <int BM, int BN, int WM, int WN, bool F16>
-__global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvB p)
+// D = k-tiles of global loads in flight per lane.  D = 1: tile t+1 is fetched during the MFMAs of
+// tile t and stored at the end of the iteration (the load has half an iteration to land).  D = 2:
+// a second register buffer, tile t+2 is fetched while t+1 is still in flight; every load is
+// unconditional (padding taps read a valid address and are zeroed at the LDS store; past the last
+// tile the last one is fetched again) so the compiler's vmcnt count stays exact and the store of
+// tile t+1 waits with vmcnt(XI + WI), not 0.
+// ST = LDS stages.  ST = 3 (with D = 0 only): the DMA runs two k-tiles ahead, one raw s_barrier per
+// k-tile and counted s_waitcnt vmcnt(N) instead of __syncthreads (whose workgroup release drains
+// every DMA in flight); used by the 8-wavefront 256x128 tiles, which also need 25 % fewer L1/LDS
+// bytes per MFMA than 128x128 (a 128x128x64 step moves 32 KB per 512 MFMA cycles = 64 B/clk/CU,
+// the whole vector-L1 rate).
+template <int BM, int BN, int WM, int WN, bool F16, int D = 1, int ST = 2>   // D = 0: LDS-DMA staging (below)
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm_bf16(const ConvB p)
 {
-    static_assert(WM * WN == 4, "4 wavefronts");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 wavefronts");
+    static_assert(ST == 2 || (ST == 3 && D == 0), "3 stages need the LDS-DMA path");
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int RPP = NTHR / 8;             // tile rows one staging pass covers
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int XI = (BM + 31) / 32, WI = (BN + 31) / 32;
+    constexpr int XI = (BM + RPP - 1) / RPP, WI = (BN + RPP - 1) / RPP;
     extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
-    u32x4 *sX = smem4;                      // [2][BM][LDC]
-    u32x4 *sW = smem4 + 2 * BM * LDC;       // [2][BN][LDC]
+    u32x4 *sX = smem4;                      // [ST][BM][LDC]
+    u32x4 *sW = smem4 + ST * BM * LDC;      // [ST][BN][LDC]
 
     const int tid = threadIdx.x;
     const int tiles = p.MT * p.NT;
     const int b = xcd_remap_b(blockIdx.x, tiles);
     const int bn0 = (b / p.MT) * BN, bm0 = (b % p.MT) * BM;
 
-    const int lr = tid >> 3, kc = tid & 7;
+    const int lr = tid >> 3;
+    // D = 0 (LDS-DMA): the LDS position of a lane is fixed (wave base + lane * 16), so the swizzle
+    // moves to the SOURCE: the lane at physical chunk (tid & 7) fetches logical chunk kc of its row
+    const int kc = D == 0 ? ((tid & 7) ^ swz(lr)) : (tid & 7);
     int x_ih0[XI], x_iw0[XI];
     long x_nb[XI];
     bool x_ok[XI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-        const int m = bm0 + lr + 32 * i;
-        x_ok[i] = (lr + 32 * i < BM) && (m < p.M);
+        const int m = bm0 + lr + RPP * i;
+        x_ok[i] = (lr + RPP * i < BM) && (m < p.M);
         const int mm = x_ok[i] ? m : 0;
         const int n = mm / p.P, pix = mm - n * p.P;
         const int oh = pix / p.OW, ow = pix - oh * p.OW;
@@ -87,8 +113,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvB p)
     const uint16_t *wp[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const int co = bn0 + lr + 32 * i;
-        wp[i] = p.w + (long)((lr + 32 * i < BN && co < p.Cout) ? co : 0) * p.K + kc * 8;
+        const int co = bn0 + lr + RPP * i;
+        wp[i] = p.w + (long)((lr + RPP * i < BN && co < p.Cout) ? co : 0) * p.K + kc * 8;
     }
     const uint16_t *xp[XI];
     bool xin[XI];
@@ -103,18 +129,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvB p)
         }
     };
     set_tap(0);
-    u32x4 xr[XI], wr[WI];
-    auto load_tile = [&](bool advance) {
+    u32x4 xr[D ? D : 1][XI], wr[D ? D : 1][WI];
+    bool xz[D ? D : 1][XI];
+    auto load_tile = [&](auto dc, bool advance) {
+        constexpr int d = decltype(dc)::value;
         const int c0 = cur_cc * BKB;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (xin[i]) v = *(const u32x4 *)(xp[i] + c0);
-            xr[i] = v;
+            if constexpr (D == 1) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (xin[i]) v = *(const u32x4 *)(xp[i] + c0);
+                xr[d][i] = v;
+                xz[d][i] = true;
+            } else {
+                xr[d][i] = *(const u32x4 *)(xin[i] ? xp[i] + c0 : p.x + kc * 8);
+                xz[d][i] = xin[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-            wr[i] = *(const u32x4 *)wp[i];
+            wr[d][i] = *(const u32x4 *)wp[i];
             wp[i] += advance ? BKB : 0;
         }
         if (advance && ++cur_cc == p.cchunks) {
@@ -122,13 +156,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvB p)
             set_tap(++cur_tap);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto dc, int buf) {
+        constexpr int d = decltype(dc)::value;
 #pragma unroll
         for (int i = 0; i < XI; ++i)
-            if (BM % 32 == 0 || lr + 32 * i < BM) sX[(buf * BM + lr + 32 * i) * LDC + kc] = xr[i];
+            if (BM % RPP == 0 || lr + RPP * i < BM)
+                sX[(buf * BM + lr + RPP * i) * LDC + (kc ^ swz(lr + RPP * i))] = (D == 1 || xz[d][i]) ? xr[d][i] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < WI; ++i)
-            if (BN % 32 == 0 || lr + 32 * i < BN) sW[(buf * BN + lr + 32 * i) * LDC + kc] = wr[i];
+            if (BN % RPP == 0 || lr + RPP * i < BN) sW[(buf * BN + lr + RPP * i) * LDC + (kc ^ swz(lr + RPP * i))] = wr[d][i];
     };
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -140,23 +176,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvB p)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = p.KT;
-    load_tile(nt > 1);
-    store_tile(0);
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        const bool more = t + 1 < nt;
-        if (more) load_tile(t + 2 < nt);
-        const u32x4 *cX = sX + (cur * BM + wm * TM * 16 + l15) * LDC + quad;
-        const u32x4 *cW = sW + (cur * BN + wn * TN * 16 + l15) * LDC + quad;
+    auto mma_tile = [&](int cur) {
+        const u32x4 *cX = sX + (cur * BM + wm * TM * 16 + l15) * LDC;
+        const u32x4 *cW = sW + (cur * BN + wn * TN * 16 + l15) * LDC;
+        const int sq = swz(l15);                       // rows differ from l15 by multiples of 16
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 wf[TN], xf[TM];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) wf[i] = cW[i * 16 * LDC + ks * 4];
+            for (int i = 0; i < TN; ++i) wf[i] = cW[i * 16 * LDC + ((ks * 4 + quad) ^ sq)];
 #pragma unroll
-            for (int j = 0; j < TM; ++j) xf[j] = cX[j * 16 * LDC + ks * 4];
+            for (int j = 0; j < TM; ++j) xf[j] = cX[j * 16 * LDC + ((ks * 4 + quad) ^ sq)];
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -169,8 +199,126 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvB p)
                                                                             __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) store_tile(cur ^ 1);
+    };
+
+    // D = 0: global_load_lds_dwordx4 (LDS-DMA).  Register staging costs a ds_write_b128 pass that
+    // runs at ~79 B/clk/CU (13 cycles per wave instruction, MI355X_MICROARCH.md): measured, the
+    // stores alone were ~180 us of b7.ds's 690.  The DMA writes wave-base + lane*16, i.e. 8 rows x
+    // 8 chunks per instruction in exactly this tile's row-major layout.
+    auto issue_tile = [&](int buf, bool advance) {
+        const int c0 = cur_cc * BKB;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const uint16_t *src = xin[i] ? xp[i] + c0 : (const uint16_t *)g_zero16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(sX + (buf * BM + wave * 8 + RPP * i) * LDC),
+                                             16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)wp[i],
+                                             (__attribute__((address_space(3))) void *)(sW + (buf * BN + wave * 8 + RPP * i) * LDC),
+                                             16, 0, 0);
+            wp[i] += advance ? BKB : 0;
+        }
+        if (advance && ++cur_cc == p.cchunks) {
+            cur_cc = 0;
+            set_tap(++cur_tap);
+        }
+    };
+
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, D >= 2 ? 1 : 0>;
+    (void)sizeof(I1);
+    // asm LDS-DMA: invisible to the compiler's waitcnt bookkeeping (no vmcnt(0) before the next
+    // ds_read or barrier); completion is counted by hand below
+    auto dma16 = [&](const uint16_t *src, const u32x4 *dst) {
+        const uint32_t lds = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)dst);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+    };
+    auto issue_tile_asm = [&](int buf, bool advance) {
+        const int c0 = cur_cc * BKB;
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            dma16(xin[i] ? xp[i] + c0 : (const uint16_t *)g_zero16, sX + (buf * BM + wave * 8 + RPP * i) * LDC);
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            dma16(wp[i], sW + (buf * BN + wave * 8 + RPP * i) * LDC);
+            wp[i] += advance ? BKB : 0;
+        }
+        if (advance && ++cur_cc == p.cchunks) {
+            cur_cc = 0;
+            set_tap(++cur_tap);
+        }
+    };
+
+    const int nt = p.KT;
+    if constexpr (D == 0 && ST == 3) {
+        static_assert(BM % RPP == 0 && BN % RPP == 0, "LDS-DMA stages whole 8-row groups");
+        constexpr int NL = XI + WI;                   // DMA instructions per wave per k-tile
+        // tiles 0 and 1 in flight; tile t+2 is issued into the stage tile t-1 left (every wave passed
+        // barrier t-1 after its last read of it); before barrier t each wave waits until only its
+        // tile t+2 pieces are outstanding, so after the barrier tile t+1 is complete for everyone
+        issue_tile_asm(0, nt > 1);
+        if (nt > 1) issue_tile_asm(1, nt > 2);
+        if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NL) : "memory");
+        else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int st = 0;
+        for (int t = 0; t < nt; ++t) {
+            const int st2 = st == 0 ? 2 : st - 1;     // (t + 2) % 3
+            if (t + 2 < nt) issue_tile_asm(st2, t + 3 < nt);
+            mma_tile(st);
+            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(NL) : "memory");
+            else            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            st = st == 2 ? 0 : st + 1;
+        }
+    } else if constexpr (D == 0) {
+        static_assert(BM % RPP == 0 && BN % RPP == 0, "LDS-DMA stages whole 8-row groups");
+        issue_tile(0, nt > 1);
+        __syncthreads();                              // carries the vmcnt(0) that lands the DMA
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt) issue_tile((t & 1) ^ 1, t + 2 < nt);
+            mma_tile(t & 1);
+            __syncthreads();
+        }
+    } else if constexpr (D == 1) {
+        load_tile(I0{}, nt > 1);
+        store_tile(I0{}, 0);
         __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const int cur = t & 1;
+            const bool more = t + 1 < nt;
+            if (more) load_tile(I0{}, t + 2 < nt);
+            mma_tile(cur);
+            if (more) store_tile(I0{}, cur ^ 1);
+            __syncthreads();
+        }
+    } else {
+        int lt = 0;                                   // next tile to fetch (tile j lives in buffer j & 1)
+        auto load_next = [&](auto dc) { load_tile(dc, lt + 1 < nt); ++lt; };
+        load_next(I0{});
+        load_next(I1{});
+        store_tile(I0{}, 0);
+        __syncthreads();
+        auto step = [&](auto dc_free, auto dc_next, int t) {
+            load_next(dc_free);                       // tile t+2 into the buffer tile t left
+            mma_tile(t & 1);
+            if (t + 1 < nt) store_tile(dc_next, (t & 1) ^ 1);     // tile t+1: fetched one iteration ago
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + 2 <= nt; t += 2) {
+            step(I0{}, I1{}, t);
+            step(I1{}, I0{}, t + 1);
+        }
+        if (t < nt) step(I0{}, I1{}, t);
     }
 
     // Epilogue.  The accumulator layout gives a lane four channels of one pixel: stored
@@ -189,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvB p)
                 *(f32x4 *)(sO + ((wm * TM + j) * 16 + l15) * OP + (wn * TN + i) * 16 + quad * 4) = acc[i][j];
         __syncthreads();
         constexpr int CPRW = BN / 8;                 // 16-byte output chunks per row
-        constexpr int RPASS = 256 / CPRW;            // rows per pass
+        constexpr int RPASS = NTHR / CPRW;           // rows per pass
         constexpr int NP = (BM + RPASS - 1) / RPASS;
         const int oc = tid % CPRW, orow = tid / CPRW;
         const int co = bn0 + oc * 8;
@@ -264,14 +412,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16(const ConvB p)
     }
 }
 
-struct TileB { int bm, bn; void (*fn)(const ConvB); void (*fn16)(const ConvB); };
-#define TB(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false>, conv_igemm_bf16<bm, bn, wm, wn, true> }
+struct TileB { int bm, bn; void (*fn)(const ConvB); void (*fn16)(const ConvB); int threads, stages; };
+#define TB(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false>, conv_igemm_bf16<bm, bn, wm, wn, true>, 256, 2 }
+#define TB2(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 2>, conv_igemm_bf16<bm, bn, wm, wn, true, 2>, 256, 2 }
+#define TB0(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0>, conv_igemm_bf16<bm, bn, wm, wn, true, 0>, 256, 2 }
+#define TB3(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0, 3>, conv_igemm_bf16<bm, bn, wm, wn, true, 0, 3>, wm * wn * 64, 3 }
 const TileB kTilesB[] = {
     TB(128, 128, 2, 2),   // 1
     TB(128, 64, 2, 2),    // 2
     TB(64, 128, 2, 2),    // 3
     TB(64, 64, 2, 2),     // 4
     TB(32, 64, 2, 2),     // 5
+    TB2(128, 128, 2, 2),  // 6: two k-tiles of loads in flight
+    TB2(128, 64, 2, 2),   // 7
+    TB2(64, 128, 2, 2),   // 8
+    TB2(64, 64, 2, 2),    // 9
+    TB0(128, 128, 2, 2),  // 10: LDS-DMA staging
+    TB0(128, 64, 2, 2),   // 11
+    TB0(64, 128, 2, 2),   // 12
+    TB0(64, 64, 2, 2),    // 13
+    TB0(32, 64, 2, 2),    // 14
+    TB3(256, 128, 4, 2),  // 15: 8 wavefronts, 3-stage LDS-DMA pipeline
+    TB3(128, 256, 2, 4),  // 16
+    TB3(128, 128, 2, 2),  // 17: 4 wavefronts, 3 stages (one workgroup per CU)
 };
 constexpr int kNumTilesB = sizeof(kTilesB) / sizeof(kTilesB[0]);
 
@@ -511,10 +674,18 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     p.NT = (d->Cout + tc.bn - 1) / tc.bn;
     const long blocks = (long)p.MT * p.NT;
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
-    size_t lds = (size_t)2 * (tc.bm + tc.bn) * LDC * 16;
+    size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * LDC * 16;
     const size_t lds_out = (size_t)tc.bm * (tc.bn + 4) * 4;      // fp32 staging tile of the epilogue
     if (lds_out > lds) lds = lds_out;
-    hipLaunchKernelGGL(dtype ? tc.fn16 : tc.fn, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    if (lds > 64 * 1024) {
+        static bool raised[2][32] = {{false}};
+        if (!raised[dtype][tile]) {
+            if (hipFuncSetAttribute((const void *)(dtype ? tc.fn16 : tc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return USOT_ELAUNCH;
+            raised[dtype][tile] = true;
+        }
+    }
+    hipLaunchKernelGGL(dtype ? tc.fn16 : tc.fn, dim3((unsigned)blocks), dim3(tc.threads), lds, (hipStream_t)stream, p);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }

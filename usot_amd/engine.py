@@ -320,6 +320,12 @@ class Builder:
         oh, ow = pc.out_hw(h, w)
         y = self.buf(n, oh, ow, pc.cout, dtype=torch.float32 if out_f32 else dtype)
         wb = pc.w_lp(dtype)
+        if tile == 0:
+            tile = LP_TUNING.get((n * oh * ow, pc.cout, pc.kh * pc.kw * pc.cin), 0)
+        if hasattr(self, 'lp_geoms'):       # scripts/tune_lp.py collects the shapes this way
+            self.lp_geoms.append(dict(name=name, N=n, H=h, W=w, Cin=pc.cin, OH=oh, OW=ow, Cout=pc.cout, KH=pc.kh, KW=pc.kw,
+                                      stride=pc.stride, pad=pc.pad, dil=pc.dil, has_res=res is not None,
+                                      M=n * oh * ow, K=pc.kh * pc.kw * pc.cin))
         d = hip.conv_desc(x.data_ptr(), wb.data_ptr(), pc.b.data_ptr(), y.data_ptr(), N=n, H=h, W=w, Cin=pc.cin,
                           OH=oh, OW=ow, Cout=pc.cout, KH=pc.kh, KW=pc.kw, stride=pc.stride, pad=pc.pad, dil=pc.dil,
                           res=res.data_ptr() if res is not None else None, act=act, tile=tile)
@@ -466,6 +472,20 @@ def load_tuning(path=None):
     with open(path) as f:
         raw = json.load(f)
     return {tuple(int(v) for v in k.split(',')): (int(t), int(ks)) for k, (t, ks) in raw.items()}
+
+
+def load_lp_tuning(path=None):
+    """{(M, Cout, K): tile} for the bf16/fp16 kernels (scripts/tune_lp.py); heuristic otherwise."""
+    import json
+    import os
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'tuning_lp_gfx950.json')
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return {tuple(int(v) for v in k.split(',')): int(t) for k, t in json.load(f).items()}
+
+
+LP_TUNING = load_lp_tuning()
 
 
 class Engine:
