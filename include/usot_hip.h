@@ -234,6 +234,16 @@ int usot_plan_add_decode(void *plan, const float *cls, const float *cls_mem, con
                          const double *window, double *out, int S, int instance_size, int stride,
                          float ratio, double penalty_k, double window_influence,
                          const double *tsz_dev, float *roi_out);
+/* the same for up to four banks of different row length (one launch): the session's raw memory
+ * features and their three cached encodings share the row indices.  stash_next (gather only, may
+ * be NULL): idx_dev[n_rows] is copied to stash_next[0], so that a later scatter of the same frame
+ * can take its row from device memory while the host already rewrites the control block. */
+int usot_rows_copy_multi_f32(void *stream, int nseg, const float *const *src, const int32_t *idx_dev,
+                             float *const *dst, int n_rows, const int32_t *row_len, int scatter,
+                             int32_t *stash_next);
+int usot_plan_add_rows_copy_multi(void *plan, int nseg, const float *const *src, const int32_t *idx_dev,
+                                  float *const *dst, int n_rows, const int32_t *row_len, int scatter,
+                             int32_t *stash_next);
 int usot_plan_add_rows_copy(void *plan, const float *src, const int32_t *idx_dev, float *dst,
                             int n_rows, int row_len, int scatter);
 int usot_plan_fork(void *plan, int lane);

@@ -35,6 +35,7 @@ def collect(bld, B, size):
         zk = [bld.buf(B, hk, wk, 512) for hk, wk in ((5, 5), (3, 5), (5, 3))]
         mem = bld.buf(B * 7, 7, 7, 256)
         bld.heads(xf, B, hf, zk, mem, 7)
+        bld.encode_kernel(bld.buf(B, 7, 7, 256), B, 256, 'mem')      # a session encodes ONE new memory feature per frame
         bld.heads(xf, B, hf, zk, None, 0)
     for g in bld.geoms:
         oh = (g['H'] + 2 * g['pad'][0] - g['dil'][0] * (g['KH'] - 1) - 1) // g['stride'] + 1

@@ -138,6 +138,29 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(
     }
 }
 
+// up to four banks with different row lengths, same row indices, one launch (blockIdx.y = bank)
+struct RowsK {
+    const float *src[4];
+    float *dst[4];
+    int row_len4[4];
+    int nseg, n_rows, scatter;
+    int *stash;        // gather only: idx[n_rows] is copied here (see usot_hip.h)
+};
+__global__ __launch_bounds__(256) void rows_copy_multi_kernel(const RowsK k, const int *__restrict__ idx)
+{
+    const int sgm = blockIdx.y;
+    if (k.stash && blockIdx.x == 0 && sgm == 0 && threadIdx.x == 0) k.stash[0] = idx[k.n_rows];
+    const int rl = k.row_len4[sgm];
+    const f32x4 *__restrict__ src = (const f32x4 *)k.src[sgm];
+    f32x4 *__restrict__ dst = (f32x4 *)k.dst[sgm];
+    const long total = (long)k.n_rows * rl;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / rl), e = (int)(i - (long)r * rl);
+        const long sr = k.scatter ? r : idx[r], dr = k.scatter ? idx[r] : r;
+        dst[dr * rl + e] = src[sr * rl + e];
+    }
+}
+
 // ---- SiamFC crop on the device (lib/utils/track_utils.py:30-119): window extraction with
 // mean-colour padding, OpenCV-style fixed-point bilinear resize (the arithmetic restated in
 // usot_amd/hostutils.py::resize_bilinear_u8) and HWC uint8 -> CHW float32, one thread per
@@ -382,6 +405,29 @@ extern "C" int usot_rows_copy_f32(void *stream, const float *src, const int32_t 
     const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(rows_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        src, (const int *)idx_dev, dst, n_rows, row_len / 4, scatter);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+extern "C" int usot_rows_copy_multi_f32(void *stream, int nseg, const float *const *src, const int32_t *idx_dev,
+                                        float *const *dst, int n_rows, const int32_t *row_len, int scatter,
+                                        int32_t *stash_next)
+{
+    if (scatter && stash_next) return USOT_EINVAL;
+    if (nseg < 1 || nseg > 4 || !src || !dst || !idx_dev || !row_len || n_rows <= 0) return USOT_EINVAL;
+    RowsK k;
+    long most = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int q = i < nseg ? i : 0;
+        if (!src[q] || !dst[q] || row_len[q] <= 0 || (row_len[q] & 3)) return USOT_EINVAL;
+        if (((uintptr_t)src[q] % 16) || ((uintptr_t)dst[q] % 16)) return USOT_EINVAL;
+        k.src[i] = src[q]; k.dst[i] = dst[q]; k.row_len4[i] = row_len[q] / 4;
+        const long t = (long)n_rows * k.row_len4[i];
+        if (t > most) most = t;
+    }
+    k.nseg = nseg; k.n_rows = n_rows; k.scatter = scatter; k.stash = stash_next;
+    const int blocks = (int)((most + 255) / 256 > 1024 ? 1024 : (most + 255) / 256);
+    hipLaunchKernelGGL(rows_copy_multi_kernel, dim3(blocks, nseg), dim3(256), 0, (hipStream_t)stream, k, (const int *)idx_dev);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }

@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -108,6 +108,13 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
         case K_POOLB:
             rc = usot_maxpool3x3s2_lp(s, op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6]);
             break;
+        case K_ROWSM: {
+            const float *srcs[4] = {(const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], (const float *)op.p[3]};
+            float *dsts[4] = {(float *)op.l[0], (float *)op.l[1], (float *)op.l[2], (float *)op.l[3]};
+            rc = usot_rows_copy_multi_f32(s, op.i[0], srcs, (const int32_t *)op.p[4], dsts, op.i[1], &op.i[3], op.i[2],
+                                          (int32_t *)op.p[5]);
+            break;
+        }
         case K_STEMB:
             rc = usot_stem_pool_lp(s, (const float *)op.p[0], op.p[1], (const float *)op.p[2], (void *)op.p[3], op.i[0], op.i[1],
                                    op.i[2], op.i[3], op.i[4], op.i[5], op.i[7], op.i[6], op.f[1], op.f[2], op.f[3]);
@@ -222,6 +229,19 @@ extern "C" int usot_plan_add_cvt_lp(void *plan, const float *src, void *dst, int
     Op *op = push(plan, K_CVTB);
     if (!op) return USOT_ESTATE;
     op->p[0] = src; op->p[1] = dst; op->l[0] = n; op->i[6] = dtype;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_rows_copy_multi(void *plan, int nseg, const float *const *src, const int32_t *idx_dev,
+                                             float *const *dst, int n_rows, const int32_t *row_len, int scatter,
+                                             int32_t *stash_next)
+{
+    if (nseg < 1 || nseg > 4 || !src || !dst || !row_len) return USOT_EINVAL;
+    Op *op = push(plan, K_ROWSM);
+    if (!op) return USOT_ESTATE;
+    for (int i = 0; i < nseg; ++i) { op->p[i] = src[i]; op->l[i] = (int64_t)(uintptr_t)dst[i]; op->i[3 + i] = row_len[i]; }
+    op->p[4] = idx_dev; op->p[5] = stash_next;
+    op->i[0] = nseg; op->i[1] = n_rows; op->i[2] = scatter;
     return USOT_OK;
 }
 

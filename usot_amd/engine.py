@@ -681,9 +681,12 @@ class Session:
 
     bank rows: 0 = init-frame feature, 1 = its left/right flip, 2+i = memory feature i
     (the reference keeps these as CPU tensors in python lists and re-uploads seven per
-    frame, usot_tracker.py:222-258,264).  One frame =
-        gather 7 rows by device indices -> backbone -> neck -> heads -> decode
-        -> PrRoIPool of the winning box -> scatter the new row,
+    frame, usot_tracker.py:222-258,264).  The three kernel-side encodings of a memory feature
+    (connect.py:55-74 `_k` branches, a pure function of the feature) are computed ONCE, when the
+    feature is appended, and kept in `bank_enc` beside it; the reference re-encodes the seven
+    picked features every frame (connect.py:251-255).  One frame =
+        gather the 7 picked rows' encodings by device indices -> backbone -> neck -> heads
+        -> decode -> PrRoIPool of the winning box -> encode it -> scatter feature + encodings,
     with one 64-byte control upload before and one 64-byte result download after.
     """
 
@@ -700,6 +703,8 @@ class Session:
         self.bank = torch.zeros(capacity, 7, 7, 256, device=dev)
         for i, f in enumerate((init_feats[0], init_feats[1], init_feats[0])):
             self.bank[i].copy_(hip.to_nhwc(f)[0])
+        self.bank_enc = [torch.zeros(capacity, hk, wk, 256, device=dev) for hk, wk in KGEO]
+        self._encode_rows(0, 3)
         self.n = 1                                   # memory features stored so far
         # Control and result blocks live in pinned (device-mapped, coherent) HOST memory that the
         # kernels address directly: the 64-byte per-frame upload/download needs no copy
@@ -715,17 +720,19 @@ class Session:
         bld = Builder(e.W, e.tuning, e.lanes)
         pl = bld.plan
         self.x = bld.buf(1, 3, self.size, self.size)
-        self.mem_in = bld.buf(7, 7, 7, 256)
+        self.mem_in = bld.buf(1)            # heads() only asks whether there is a memory branch
         tsz_dev = self.ctl[0:56].view(torch.float64)          # [0:2] target size, [6] frame tag
         idx_dev = self.ctl[16:48].view(torch.int32)          # 7 gather rows + 1 scatter row
         self._ctl_f64 = tsz_dev.numpy()
         self._ctl_i32 = idx_dev.numpy()
         self._out_np = self.out8.numpy()
-        bld.fork(2, 1)                               # memory-kernel side runs beside the backbone
-        hip.check(L.usot_plan_add_rows_copy(pl.h, hip.ptr(self.bank), hip.ptr(idx_dev), hip.ptr(self.mem_in),
-                                            7, Session.ROW, 0), 'plan_add_rows_copy')
-        mk = bld.encode_kernel(self.mem_in, 7, 256, 'mem')
-        bld.fork(0, 1)
+        # the 7 picked memory kernels: their cached encodings, three banks in one gather
+        mk = [bld.buf(7, hk, wk, 256) for hk, wk in KGEO]
+        # ... and the append row of this frame is stashed in device memory: the scatter at the end of
+        # the graph runs AFTER the result tag the host waits for, i.e. possibly while the host is
+        # already writing the next frame's control block
+        self.slot_dev = torch.zeros(4, dtype=torch.int32, device=e.device)
+        self._rows_multi(pl, self.bank_enc, idx_dev, mk, 7, scatter=0, stash=self.slot_dev)
         xf, hf = bld.backbone(self.x, 1, self.size)
         bbox, cls2, S = bld.heads(xf, 1, hf, self.zk, self.mem_in, 7, mk=mk, mem_lane=2)
         assert S == self.S
@@ -739,15 +746,36 @@ class Session:
         c = 256
         hip.check(L.usot_plan_add_prroi(pl.h, hip.ptr(xf), hip.ptr(self.roi), hip.ptr(self.feat), 1, c, hf, hf, 7, 7, 1.0,
                                         hf * hf * c, 1, hf * c, c, 49 * c, 1, 7 * c, c), 'plan_add_prroi')
-        idx_slot = self.ctl[44:48].view(torch.int32)
-        hip.check(L.usot_plan_add_rows_copy(pl.h, hip.ptr(self.feat), hip.ptr(idx_slot), hip.ptr(self.bank),
-                                            1, Session.ROW, 1), 'plan_add_rows_copy')
-        pl.keep += [self.bank, self.ctl, self.window, self.out8, tsz_dev, idx_dev, idx_slot] + self.zk
+        new_enc = bld.encode_kernel(self.feat, 1, 256, 'mem')       # the new feature's encodings, once
+        self._rows_multi(pl, [self.feat] + new_enc, self.slot_dev, [self.bank] + self.bank_enc, 1, scatter=1)
+        pl.keep += mk + new_enc + self.bank_enc + [self.slot_dev]
+        pl.keep += [self.bank, self.ctl, self.window, self.out8, tsz_dev, idx_dev] + self.zk
         self.xf, self.cls2, self.bbox, self.plan, self.log = xf, cls2, bbox, pl, bld.log
         # warm-up must not leave a stray row in the bank: point the scatter at a scratch row
         self._set_ctl([0, 1, 2, 2, 2, 2, 2], self.cap - 1, (64.0, 64.0))
         self._ctl_f64[6] = -1.0
         e._finish(pl)
+        torch.cuda.current_stream().synchronize()
+
+    @staticmethod
+    def _rows_multi(pl, srcs, idx, dsts, n_rows, scatter, stash=None):
+        n = len(srcs)
+        rl = [int(bank[0].numel()) for bank in (dsts if scatter else srcs)]      # row = one bank entry
+        hip.check(hip.lib().usot_plan_add_rows_copy_multi(
+            pl.h, n, (C.c_void_p * n)(*[t.data_ptr() for t in srcs]), hip.ptr(idx),
+            (C.c_void_p * n)(*[t.data_ptr() for t in dsts]), n_rows, (C.c_int32 * n)(*rl), scatter,
+            hip.ptr(stash) if stash is not None else None), 'plan_add_rows_copy_multi')
+
+    def _encode_rows(self, lo, hi):
+        """Encode bank rows [lo, hi) into bank_enc (session start: init feature, its flip, memory 0)."""
+        bld = Builder(self.e.W, self.e.tuning, 0)
+        src = bld.buf(hi - lo, 7, 7, 256)
+        src.copy_(self.bank[lo:hi])
+        enc = bld.encode_kernel(src, hi - lo, 256, 'mem')
+        bld.plan.run()
+        torch.cuda.current_stream().synchronize()
+        for g in range(3):
+            self.bank_enc[g][lo:hi].copy_(enc[g])
         torch.cuda.current_stream().synchronize()
 
     def _set_ctl(self, rows, slot, tsz):
@@ -764,7 +792,10 @@ class Session:
     def _grow(self):
         bank = torch.zeros(self.cap * 2, 7, 7, 256, device=self.e.device)
         bank[:self.cap].copy_(self.bank)
-        self.bank, self.cap = bank, self.cap * 2
+        enc = [torch.zeros(self.cap * 2, hk, wk, 256, device=self.e.device) for hk, wk in KGEO]
+        for g in range(3):
+            enc[g][:self.cap].copy_(self.bank_enc[g])
+        self.bank, self.bank_enc, self.cap = bank, enc, self.cap * 2
         self._build()
 
     def submit(self, x_crop, picks, tsz_scaled, resident=False):
