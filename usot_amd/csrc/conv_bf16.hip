@@ -77,7 +77,7 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 template <int BM, int BN, int WM, int WN, bool F16, int D = 1, int ST = 2>   // D = 0: LDS-DMA staging (below)
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm_bf16(const ConvB p)
 {
-    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 wavefronts");
+    static_assert(WM * WN == 4 || WM * WN == 8 || WM * WN == 16, "4, 8 or 16 wavefronts");
     static_assert(ST == 2 || (ST == 3 && D == 0), "3 stages need the LDS-DMA path");
     constexpr int NTHR = WM * WN * 64;
     constexpr int RPP = NTHR / 8;             // tile rows one staging pass covers
@@ -327,55 +327,66 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
     // are pure HBM traffic).  Instead the fp32 tile is transposed through LDS (free after the
     // k-loop) so that every lane handles 8 consecutive channels: 16-byte residual loads and
     // 16-byte stores, 16 lanes per 256-byte row segment.
-    constexpr int OP = BN + 4;                       // fp32 row pitch: 4*odd dwords -> conflict-free
+    // Tiles whose fp32 image exceeds the LDS (256x256) go through in EH channel slices.
+    constexpr int EH = (BM * (BN + 4) * 4 > 144 * 1024) ? 2 : 1;
+    constexpr int BNH = BN / EH;                     // channels per slice
+    constexpr int OP = BNH + 4;                      // fp32 row pitch: 4*odd dwords -> conflict-free
+    static_assert(EH == 1 || (BNH % (TN * 16) == 0), "a wave's channels fall into one slice");
     if (!p.out_f32 && (p.Cout & 7) == 0) {
         float *sO = (float *)smem4;
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-                *(f32x4 *)(sO + ((wm * TM + j) * 16 + l15) * OP + (wn * TN + i) * 16 + quad * 4) = acc[i][j];
-        __syncthreads();
-        constexpr int CPRW = BN / 8;                 // 16-byte output chunks per row
+        constexpr int CPRW = BNH / 8;                // 16-byte output chunks per row
         constexpr int RPASS = NTHR / CPRW;           // rows per pass
         constexpr int NP = (BM + RPASS - 1) / RPASS;
-        const int oc = tid % CPRW, orow = tid / CPRW;
-        const int co = bn0 + oc * 8;
-        const bool cok = co < p.Cout;
-        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-        if (p.bias && cok) { b0 = *(const f32x4 *)(p.bias + co); b1 = *(const f32x4 *)(p.bias + co + 4); }
         constexpr int CH = NP < 4 ? NP : 4;          // residual loads in flight per lane
+        const int oc = tid % CPRW, orow = tid / CPRW;
 #pragma unroll 1
-        for (int q0 = 0; q0 < NP; q0 += CH) {
-            u32x4 rr[CH];
+        for (int eh = 0; eh < EH; ++eh) {
+            if (eh > 0) __syncthreads();             // the previous slice has been read out
+            if ((wn * TN * 16) / BNH == eh) {
+                const int cl0 = wn * TN * 16 - eh * BNH;
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
-                const int r = orow + (q0 + q) * RPASS, m = bm0 + r;
-                rr[q] = u32x4{0u, 0u, 0u, 0u};
-                if (p.res && cok && r < BM && m < p.M) rr[q] = *(const u32x4 *)(p.res + (long)m * p.Cout + co);
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+                        *(f32x4 *)(sO + ((wm * TM + j) * 16 + l15) * OP + cl0 + i * 16 + quad * 4) = acc[i][j];
             }
+            __syncthreads();
+            const int co = bn0 + eh * BNH + oc * 8;
+            const bool cok = co < p.Cout;
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+            if (p.bias && cok) { b0 = *(const f32x4 *)(p.bias + co); b1 = *(const f32x4 *)(p.bias + co + 4); }
+#pragma unroll 1
+            for (int q0 = 0; q0 < NP; q0 += CH) {
+                u32x4 rr[CH];
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
-                const int r = orow + (q0 + q) * RPASS, m = bm0 + r;
-                if (!cok || r >= BM || m >= p.M) continue;
-                f32x4 v0 = *(const f32x4 *)(sO + r * OP + oc * 8) + b0;
-                f32x4 v1 = *(const f32x4 *)(sO + r * OP + oc * 8 + 4) + b1;
-                if (p.res) {
-                    v0[0] += unpack_lp<F16>(rr[q][0] & 0xffffu); v0[1] += unpack_lp<F16>(rr[q][0] >> 16);
-                    v0[2] += unpack_lp<F16>(rr[q][1] & 0xffffu); v0[3] += unpack_lp<F16>(rr[q][1] >> 16);
-                    v1[0] += unpack_lp<F16>(rr[q][2] & 0xffffu); v1[1] += unpack_lp<F16>(rr[q][2] >> 16);
-                    v1[2] += unpack_lp<F16>(rr[q][3] & 0xffffu); v1[3] += unpack_lp<F16>(rr[q][3] >> 16);
+                for (int q = 0; q < CH; ++q) {
+                    const int r = orow + (q0 + q) * RPASS, m = bm0 + r;
+                    rr[q] = u32x4{0u, 0u, 0u, 0u};
+                    if (p.res && cok && r < BM && m < p.M) rr[q] = *(const u32x4 *)(p.res + (long)m * p.Cout + co);
                 }
-                if (p.act == USOT_ACT_RELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                for (int q = 0; q < CH; ++q) {
+                    const int r = orow + (q0 + q) * RPASS, m = bm0 + r;
+                    if (!cok || r >= BM || m >= p.M) continue;
+                    f32x4 v0 = *(const f32x4 *)(sO + r * OP + oc * 8) + b0;
+                    f32x4 v1 = *(const f32x4 *)(sO + r * OP + oc * 8 + 4) + b1;
+                    if (p.res) {
+                        v0[0] += unpack_lp<F16>(rr[q][0] & 0xffffu); v0[1] += unpack_lp<F16>(rr[q][0] >> 16);
+                        v0[2] += unpack_lp<F16>(rr[q][1] & 0xffffu); v0[3] += unpack_lp<F16>(rr[q][1] >> 16);
+                        v1[0] += unpack_lp<F16>(rr[q][2] & 0xffffu); v1[1] += unpack_lp<F16>(rr[q][2] >> 16);
+                        v1[2] += unpack_lp<F16>(rr[q][3] & 0xffffu); v1[3] += unpack_lp<F16>(rr[q][3] >> 16);
+                    }
+                    if (p.act == USOT_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                    }
+                    u32x4 o;
+                    o[0] = pack_lp<F16>(v0[0]) | (pack_lp<F16>(v0[1]) << 16);
+                    o[1] = pack_lp<F16>(v0[2]) | (pack_lp<F16>(v0[3]) << 16);
+                    o[2] = pack_lp<F16>(v1[0]) | (pack_lp<F16>(v1[1]) << 16);
+                    o[3] = pack_lp<F16>(v1[2]) | (pack_lp<F16>(v1[3]) << 16);
+                    *(u32x4 *)(p.y + (long)m * p.Cout + co) = o;
                 }
-                u32x4 o;
-                o[0] = pack_lp<F16>(v0[0]) | (pack_lp<F16>(v0[1]) << 16);
-                o[1] = pack_lp<F16>(v0[2]) | (pack_lp<F16>(v0[3]) << 16);
-                o[2] = pack_lp<F16>(v1[0]) | (pack_lp<F16>(v1[1]) << 16);
-                o[3] = pack_lp<F16>(v1[2]) | (pack_lp<F16>(v1[3]) << 16);
-                *(u32x4 *)(p.y + (long)m * p.Cout + co) = o;
             }
         }
         return;
@@ -416,6 +427,7 @@ struct TileB { int bm, bn; void (*fn)(const ConvB); void (*fn16)(const ConvB); i
 #define TB(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false>, conv_igemm_bf16<bm, bn, wm, wn, true>, 256, 2 }
 #define TB2(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 2>, conv_igemm_bf16<bm, bn, wm, wn, true, 2>, 256, 2 }
 #define TB0(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0>, conv_igemm_bf16<bm, bn, wm, wn, true, 0>, 256, 2 }
+#define TB08(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0>, conv_igemm_bf16<bm, bn, wm, wn, true, 0>, wm * wn * 64, 2 }
 #define TB3(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0, 3>, conv_igemm_bf16<bm, bn, wm, wn, true, 0, 3>, wm * wn * 64, 3 }
 const TileB kTilesB[] = {
     TB(128, 128, 2, 2),   // 1
@@ -435,6 +447,11 @@ const TileB kTilesB[] = {
     TB3(256, 128, 4, 2),  // 15: 8 wavefronts, 3-stage LDS-DMA pipeline
     TB3(128, 256, 2, 4),  // 16
     TB3(128, 128, 2, 2),  // 17: 4 wavefronts, 3 stages (one workgroup per CU)
+    TB08(256, 256, 2, 4), // 18: 8 wavefronts x (128 pixels x 64 channels), 2-stage LDS-DMA
+    TB08(256, 128, 4, 2), // 19
+    TB08(128, 256, 2, 4), // 20
+    TB08(256, 256, 4, 4), // 21: 16 wavefronts x (64 x 64)
+    TB08(256, 256, 4, 2), // 22: 8 wavefronts x (64 pixels x 128 channels)
 };
 constexpr int kNumTilesB = sizeof(kTilesB) / sizeof(kTilesB[0]);
 
@@ -675,7 +692,8 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     const long blocks = (long)p.MT * p.NT;
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
     size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * LDC * 16;
-    const size_t lds_out = (size_t)tc.bm * (tc.bn + 4) * 4;      // fp32 staging tile of the epilogue
+    size_t lds_out = (size_t)tc.bm * (tc.bn + 4) * 4;            // fp32 staging tile of the epilogue
+    if (lds_out > 144 * 1024) lds_out = (size_t)tc.bm * (tc.bn / 2 + 4) * 4;   // two channel slices
     if (lds_out > lds) lds = lds_out;
     if (lds > 64 * 1024) {
         static bool raised[2][32] = {{false}};
