@@ -30,7 +30,9 @@ def norm(sym):
     if fam == '':
         return 'conv_igemm_f32<%d,%d>' % (a[0], a[1])
     if fam == '_v3':
-        return 'conv_igemm_f32_v3<%d,%d,BK=%d>' % (a[0], a[1], a[4])
+        d = a[5] if len(a) > 5 else 1                 # register prefetch depth (tile ids 37-52)
+        return ('conv_igemm_f32_v3<%d,%d,BK=%d,D=%d>' % (a[0], a[1], a[4], d)) if d > 1 else \
+               ('conv_igemm_f32_v3<%d,%d,BK=%d>' % (a[0], a[1], a[4]))
     ksw = a[5] if len(a) > 5 else 1
     if ksw > 1:
         return 'conv_igemm_f32_v2<%d,%d,%d,%d> ksw=%d' % (a[0], a[1], a[4], ksw, ksw)
