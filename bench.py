@@ -270,8 +270,8 @@ def track_mixed(a, rank, world, device):
     sm = torch.ones(b, 7, device=device)
     dt_ = torch.float16 if a.lp == 'fp16' else torch.bfloat16
     for _ in range(max(2, a.warmup)):
-        e.track_mixed(x, model.zf, mem, sm, dtype=dt_)
-    p = e._track[('mixed', b, a.size, 7, dt_)]
+        e.track_mixed(x, model.zf, mem, sm, dtype=dt_, heads_lp=not a.heads_f32)
+    p = e._track[('mixed', b, a.size, 7, dt_, not a.heads_f32)]
     streams.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -282,12 +282,14 @@ def track_mixed(a, rank, world, device):
     dt = streams.max_over_ranks(time.perf_counter() - t0, device=device)
     if rank == 0:
         print(json.dumps({
-            'metric': 'tracker FPS (255x255 search, ResNet-50), %s backbone + fp32 xcorr/heads, batch %d per GPU' % (a.lp, b),
+            'metric': 'tracker FPS (255x255 search, ResNet-50), %s backbone%s + fp32 xcorr, batch %d per GPU'
+                      % (a.lp, '' if a.heads_f32 else ' and head convs', b),
             'value': round(world * b * a.steps / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': a.lp + '+f32', 'data': 'synthetic',
             'config': {'workload': 'configs[4]: %s backbone + fp32 xcorr mixed precision, batch=%d per GPU x %d GPUs, N_q=7'
-                                   % (a.lp, b, world), 'search': a.size, 'hipgraph': True}}))
+                                   % (a.lp, b, world), 'search': a.size, 'hipgraph': True,
+                       'head_convs': 'f32' if a.heads_f32 else a.lp + ' (encoders, conf/value, towers); preds, memory-kernel encoders, GroupDW, reduce f32'}}))
     streams.barrier()
 
 
@@ -302,6 +304,7 @@ def main():
     ap.add_argument('--workload', default='track', choices=['track', 'backbone_bf16', 'track_mixed'])
     ap.add_argument('--lp', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--heads-f32', action='store_true', help='track_mixed: keep every head conv in fp32')
     ap.add_argument('--streams-per-gpu', type=int, default=1,
                     help='independent videos per GPU on separate HIP streams (default 1 = BASELINE configs[1])')
     a = ap.parse_args()

@@ -25,7 +25,9 @@ for B in a.batch:
     bld = Builder(W, {}, 0)
     bld.lp_geoms = []
     x = bld.buf(B, 3, 255, 255)
-    bld.backbone_bf16(x, B, 255)
+    xl, hf = bld.backbone_bf16(x, B, 255)
+    zk = [bld.buf(B, hk, wk, 512) for hk, wk in ((5, 5), (3, 5), (5, 3))]
+    bld.heads_lp(xl, B, hf, zk, bld.buf(B * 7, 7, 7, 256), 7, torch.bfloat16)      # config 5 head shapes
     for g in bld.lp_geoms:
         key = '%d,%d,%d' % (g['M'], g['Cout'], g['K'])
         if key in table:

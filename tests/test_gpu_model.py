@@ -124,9 +124,11 @@ def test_backbone_bf16_tracks_fp32(net, oracle_sd):
     assert np.corrcoef(got.reshape(-1), ref.reshape(-1))[0, 1] > 0.999
 
 
+@pytest.mark.parametrize('heads_lp', [False, True], ids=['heads_f32', 'heads_lp'])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['fp16', 'bf16'])
-def test_track_mixed_precision(net, oracle_sd, dtype):
-    """config 5 path: low-precision MFMA backbone, fp32 xcorr + heads, batch of 2 streams."""
+def test_track_mixed_precision(net, oracle_sd, dtype, heads_lp):
+    """config 5 path: low-precision MFMA backbone (+ optionally the big head convs), fp32 xcorr,
+    batch of 2 streams."""
     z, x = t(synth.crop(60, 2, 127)), t(synth.crop(61, 2, 255))
     mem = t(synth.memory_kernels(62, 14))
     with torch.no_grad():
@@ -135,7 +137,8 @@ def test_track_mixed_precision(net, oracle_sd, dtype):
     net.pr_pool = False
     net.template(z.to(DEV))
     net.pr_pool = True
-    gcls, gbbox, gcm, gxf = net.engine.track_mixed(x.to(DEV), net.zf, mem.to(DEV), torch.ones(2, 7, device=DEV), dtype=dtype)
+    gcls, gbbox, gcm, gxf = net.engine.track_mixed(x.to(DEV), net.zf, mem.to(DEV), torch.ones(2, 7, device=DEV), dtype=dtype,
+                                                   heads_lp=heads_lp)
     tol = 3e-2 if dtype == torch.float16 else 1.5e-1           # fp16: 11 mantissa bits, bf16: 8
     for got, ref in ((gxf, xf), (gcls, cls), (gcm, cm)):
         g_, r_ = npy(got.float()), ref.numpy()

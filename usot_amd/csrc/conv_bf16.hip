@@ -28,7 +28,10 @@ struct ConvB {
     uint16_t *y;
     int N, H, W, Cin, OH, OW, Cout;
     int KH, KW, stride, pad_h, pad_w, dil_h, dil_w;
-    int act;
+    int act, act2, act_split;      // channels < act_split get act, the rest act2
+    int groups;                    // independent problems of identical geometry (the three towers)
+    long x_gs, w_gs, y_gs;         // element strides between groups (y_gs in OUTPUT elements)
+    int b_gs;
     int out_f32;       // store the result as fp32 (the neck output that feeds the fp32 heads)
     int M, K, KT, cchunks, MT, NT, P;
 };
@@ -51,6 +54,16 @@ __device__ __forceinline__ uint32_t f2h(float f) { return (uint32_t)__builtin_bi
 __device__ __forceinline__ float h2f(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
 template <bool F16> __device__ __forceinline__ uint32_t pack_lp(float f) { return F16 ? f2h(f) : f2bf(f); }
 template <bool F16> __device__ __forceinline__ float unpack_lp(uint32_t h) { return F16 ? h2f(h) : bf2f(h); }
+
+__device__ __forceinline__ float act_lp(float v, int a)
+{
+    switch (a) {
+    case USOT_ACT_RELU: return fmaxf(v, 0.0f);
+    case USOT_ACT_EXP:  return expf(v);
+    case USOT_ACT_CONF: return expf(fminf(fmaxf(v, 0.0f), 4.0f));
+    default:            return v;
+    }
+}
 
 constexpr int BKB = 64;            // k-tile in bf16 elements
 // LDS rows are 8 x 16-byte chunks (64 elements), unpadded, with the chunk index XOR-swizzled by
@@ -75,8 +88,9 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 // bytes per MFMA than 128x128 (a 128x128x64 step moves 32 KB per 512 MFMA cycles = 64 B/clk/CU,
 // the whole vector-L1 rate).
 template <int BM, int BN, int WM, int WN, bool F16, int D = 1, int ST = 2>   // D = 0: LDS-DMA staging (below)
-__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm_bf16(const ConvB p)
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm_bf16(const ConvB pin)
 {
+    ConvB p = pin;
     static_assert(WM * WN == 4 || WM * WN == 8 || WM * WN == 16, "4, 8 or 16 wavefronts");
     static_assert(ST == 2 || (ST == 3 && D == 0), "3 stages need the LDS-DMA path");
     constexpr int NTHR = WM * WN * 64;
@@ -89,7 +103,14 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
 
     const int tid = threadIdx.x;
     const int tiles = p.MT * p.NT;
-    const int b = xcd_remap_b(blockIdx.x, tiles);
+    const int bb = xcd_remap_b(blockIdx.x, tiles * p.groups);
+    const int grp = bb / tiles, b = bb - grp * tiles;
+    if (p.groups > 1) {
+        p.x += (long)grp * p.x_gs;
+        p.w += (long)grp * p.w_gs;
+        if (p.bias) p.bias += (long)grp * p.b_gs;
+        p.y = (uint16_t *)((char *)p.y + (long)grp * p.y_gs * (p.out_f32 ? 4 : 2));
+    }
     const int bn0 = (b / p.MT) * BN, bm0 = (b % p.MT) * BM;
 
     const int lr = tid >> 3;
@@ -376,9 +397,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
                         v1[0] += unpack_lp<F16>(rr[q][2] & 0xffffu); v1[1] += unpack_lp<F16>(rr[q][2] >> 16);
                         v1[2] += unpack_lp<F16>(rr[q][3] & 0xffffu); v1[3] += unpack_lp<F16>(rr[q][3] >> 16);
                     }
-                    if (p.act == USOT_ACT_RELU) {
+                    const int av = co < p.act_split ? p.act : p.act2;
+                    if (av == USOT_ACT_RELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                    } else if (av != USOT_ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = act_lp(v0[e], av); v1[e] = act_lp(v1[e], av); }
                     }
                     u32x4 o;
                     o[0] = pack_lp<F16>(v0[0]) | (pack_lp<F16>(v0[1]) << 16);
@@ -407,9 +432,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
                 v[0] += unpack_lp<F16>(r[0] & 0xffffu); v[1] += unpack_lp<F16>(r[0] >> 16);
                 v[2] += unpack_lp<F16>(r[1] & 0xffffu); v[3] += unpack_lp<F16>(r[1] >> 16);
             }
-            if (p.act == USOT_ACT_RELU) {
+            const int av = co < p.act_split ? p.act : p.act2;
+            if (av != USOT_ACT_NONE) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 4; ++e) v[e] = act_lp(v[e], av);
             }
             if (p.out_f32) {
                 *(f32x4 *)((float *)p.y + (long)m * p.Cout + co) = v;
@@ -665,8 +691,8 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     if (dtype != 0 && dtype != 1) return USOT_EINVAL;
     if (!d || !d->x || !d->w || !d->y) return USOT_EINVAL;
     if (d->Cin <= 0 || (d->Cin % BKB) || d->Cout <= 0 || (d->Cout & 3) || d->N <= 0) return USOT_EINVAL;
-    if (d->groups > 1 || d->ksplit > 1 || d->y_nchw) return USOT_EINVAL;
-    if (d->act != USOT_ACT_NONE && d->act != USOT_ACT_RELU) return USOT_EINVAL;
+    if (d->ksplit > 1 || d->y_nchw || d->groups < 0 || (d->groups > 1 && d->res)) return USOT_EINVAL;
+    if (d->act < USOT_ACT_NONE || d->act > USOT_ACT_CONF) return USOT_EINVAL;
     const int oh = (d->H + 2 * d->pad_h - d->dil_h * (d->KH - 1) - 1) / d->stride + 1;
     const int ow = (d->W + 2 * d->pad_w - d->dil_w * (d->KW - 1) - 1) / d->stride + 1;
     if (oh != d->OH || ow != d->OW || oh <= 0 || ow <= 0) return USOT_EINVAL;
@@ -678,6 +704,9 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
     p.dil_h = d->dil_h; p.dil_w = d->dil_w; p.act = d->act; p.out_f32 = out_f32;
+    p.act_split = d->act_split > 0 ? d->act_split : d->Cout; p.act2 = d->act_split > 0 ? d->act2 : d->act;
+    p.groups = d->groups > 1 ? d->groups : 1;
+    p.x_gs = d->x_gs; p.w_gs = d->w_gs; p.y_gs = d->y_gs; p.b_gs = (int)d->b_gs;
     p.P = d->OH * d->OW; p.M = d->N * p.P; p.K = d->KH * d->KW * d->Cin;
     p.cchunks = d->Cin / BKB; p.KT = d->KH * d->KW * p.cchunks;
     int tile = d->tile;
@@ -689,7 +718,7 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     const TileB &tc = kTilesB[tile - 1];
     p.MT = (p.M + tc.bm - 1) / tc.bm;
     p.NT = (d->Cout + tc.bn - 1) / tc.bn;
-    const long blocks = (long)p.MT * p.NT;
+    const long blocks = (long)p.MT * p.NT * p.groups;
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
     size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * LDC * 16;
     size_t lds_out = (size_t)tc.bm * (tc.bn + 4) * 4;            // fp32 staging tile of the epilogue

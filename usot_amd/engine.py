@@ -316,25 +316,70 @@ class Builder:
         return xf, h
 
     # ---- bf16 backbone for the batched MFMA-roofline configuration (BASELINE config 3)
-    def conv_bf16(self, name, pc, x, n, h, w, *, act=ACT_NONE, res=None, tile=0, dtype=torch.bfloat16, out_f32=False):
+    def conv_bf16(self, name, pc, x, n, h, w, *, act=ACT_NONE, res=None, tile=0, dtype=torch.bfloat16, out_f32=False,
+                  act2=ACT_NONE, act_split=0, groups=1, cout=None, x_gs=0, y=None):
+        """Low-precision conv.  groups > 1: `groups` problems of identical geometry, inputs x_gs elements
+        apart, filter rows [g*cout, (g+1)*cout) of the packed bank, outputs stacked (the three towers)."""
         oh, ow = pc.out_hw(h, w)
-        y = self.buf(n, oh, ow, pc.cout, dtype=torch.float32 if out_f32 else dtype)
+        cout = cout or pc.cout
+        if y is None:
+            y = self.buf(groups, n, oh, ow, cout, dtype=torch.float32 if out_f32 else dtype) if groups > 1 else \
+                self.buf(n, oh, ow, cout, dtype=torch.float32 if out_f32 else dtype)
         wb = pc.w_lp(dtype)
+        k = pc.kh * pc.kw * pc.cin
         if tile == 0:
-            tile = LP_TUNING.get((n * oh * ow, pc.cout, pc.kh * pc.kw * pc.cin), 0)
+            tile = LP_TUNING.get((n * oh * ow, cout, k), 0)
         if hasattr(self, 'lp_geoms'):       # scripts/tune_lp.py collects the shapes this way
-            self.lp_geoms.append(dict(name=name, N=n, H=h, W=w, Cin=pc.cin, OH=oh, OW=ow, Cout=pc.cout, KH=pc.kh, KW=pc.kw,
+            self.lp_geoms.append(dict(name=name, N=n, H=h, W=w, Cin=pc.cin, OH=oh, OW=ow, Cout=cout, KH=pc.kh, KW=pc.kw,
                                       stride=pc.stride, pad=pc.pad, dil=pc.dil, has_res=res is not None,
-                                      M=n * oh * ow, K=pc.kh * pc.kw * pc.cin))
+                                      M=n * oh * ow, K=k))
         d = hip.conv_desc(x.data_ptr(), wb.data_ptr(), pc.b.data_ptr(), y.data_ptr(), N=n, H=h, W=w, Cin=pc.cin,
-                          OH=oh, OW=ow, Cout=pc.cout, KH=pc.kh, KW=pc.kw, stride=pc.stride, pad=pc.pad, dil=pc.dil,
-                          res=res.data_ptr() if res is not None else None, act=act, tile=tile)
+                          OH=oh, OW=ow, Cout=cout, KH=pc.kh, KW=pc.kw, stride=pc.stride, pad=pc.pad, dil=pc.dil,
+                          res=res.data_ptr() if res is not None else None, act=act, act2=act2, act_split=act_split,
+                          tile=tile, groups=groups, x_gs=x_gs, w_gs=cout * k, b_gs=cout, y_gs=n * oh * ow * cout)
         hip.check(hip.lib().usot_plan_add_conv_lp(self.plan.h, C.byref(d), 1 if dtype == torch.float16 else 0, int(out_f32)),
                   'plan_add_conv_lp ' + name)
         self.plan.keep += [x, wb, pc.b]
-        k = pc.kh * pc.kw * pc.cin
-        self.log.append((name, n * oh * ow, pc.cout, k, 1, n * oh * ow * pc.cout * k))
+        self.log.append((name, n * oh * ow, cout, k, groups, groups * n * oh * ow * cout * k))
         return y, oh, ow
+
+    def cvt_lp(self, src, dtype):
+        dst = self.buf(*src.shape, dtype=dtype)
+        hip.check(hip.lib().usot_plan_add_cvt_lp(self.plan.h, hip.ptr(src), hip.ptr(dst), src.numel(),
+                                                 1 if dtype == torch.float16 else 0), 'plan_add_cvt_lp')
+        self.plan.keep += [src]
+        return dst
+
+    def heads_lp(self, xf_lp, b, hf, zk, mem_nhwc, m, dtype):
+        """Heads with the big convolutions (search-side encoders, confidence/value, towers) at
+        low-precision storage on the bf16/fp16 MFMA; the depthwise correlations (GroupDW), the
+        Conf_Fusion reduction, the memory-kernel encoders and the 1/4-channel prediction convs stay fp32
+        (BASELINE configs[4]: "fp16 backbone + fp32 xcorr").  xf_lp: neck output NHWC in `dtype`."""
+        W, L = self.W, hip.lib()
+        es = [self.conv_bf16('enc_s%d' % g, W.enc_s[g], xf_lp, b, hf, hf, act=ACT_RELU, dtype=dtype, out_f32=True)[0]
+              for g in range(3)]
+        S = hf - 6
+        tin = self.buf(3, b, S, S, 256)               # tower inputs: [reg, cls, memory]
+        mk = self.encode_kernel(mem_nhwc, b * m, 256, 'mem')
+        dwm = self.buf(b * m, S, S, 256)
+        self.groupdw_flush([self.groupdw(es, zk, tin[0], W.reg_wsm, b, 1, S, S, 256, 512),
+                            self.groupdw(es, zk, tin[1], W.cls_wsm, b, 1, S, S, 0, 512),
+                            self.groupdw(es, mk, dwm, W.cls_wsm, b * m, m, S, S, 0, 256)])
+        cv, _, _ = self.conv_bf16('conf_fusion', W.conf, self.cvt_lp(dwm, dtype), b * m, S, S, act=ACT_CONF, act2=ACT_RELU,
+                                  act_split=256, dtype=dtype, out_f32=True)
+        hip.check(L.usot_plan_add_conf_reduce(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256),
+                  'plan_add_conf_reduce')
+        gs = b * S * S * 256
+        cur = self.cvt_lp(tin, dtype)
+        for i in range(4):
+            cur, _, _ = self.conv_bf16('tower%d' % i, W.tower[i], cur, b, S, S, cout=256, act=ACT_RELU, groups=3, x_gs=gs,
+                                       dtype=dtype, out_f32=(i == 3))
+        bbox = self.buf(b, 4, S, S)
+        cls2 = self.buf(2, b, 1, S, S)
+        self.conv_batch([('bbox_pred', W.bbox_pred, cur[0], b, S, S, dict(act=ACT_EXP, y=bbox, y_nchw=True)),
+                         ('cls_preds', W.cls_preds, cur[1], b, S, S, dict(cout=1, y=cls2, y_nchw=True, groups=2,
+                                                                          x_gs=gs, y_gs=b * S * S, w_rows=1))])
+        return bbox, cls2, S
 
     def backbone_bf16(self, x, n, size, dtype=torch.bfloat16, neck_f32=False):
         """x NCHW fp32 [n,3,s,s] -> neck output NHWC bf16|fp16 (or fp32 with neck_f32)
@@ -641,28 +686,34 @@ class Engine:
         cls_mem = p['cls2'][1].clone() if clone else p['cls2'][1]
         return cls, bbox, cls_mem, p['xf'].permute(0, 3, 1, 2)
 
-    def track_mixed(self, x, zf, template_mem, score_mem, dtype=torch.float16):
-        """BASELINE config 5: low-precision (fp16 | bf16) backbone + neck on MFMA, fp32 encoders /
-        xcorr / heads.  Same returns as track(); batch = independent streams."""
+    def track_mixed(self, x, zf, template_mem, score_mem, dtype=torch.float16, heads_lp=True):
+        """BASELINE config 5: low-precision (fp16 | bf16) backbone + neck on MFMA; heads_lp: the big head
+        convolutions too (Builder.heads_lp), else every head op in fp32.  The depthwise correlations
+        are fp32 either way.  Same returns as track(); batch = independent streams."""
         x = _as_dev_f32(x, self.device)
         b, _, size, _ = x.shape
         if self._zk_key != (zf.data_ptr(), zf._version, tuple(zf.shape)) or b not in self._zenc:
             self.set_template(zf)
         m = int(score_mem.shape[1])
-        key = ('mixed', b, size, m, dtype)
+        key = ('mixed', b, size, m, dtype, bool(heads_lp))
         if key not in self._track:
             bld = Builder(self.W, self.tuning, 0)
             xin = bld.buf(b, 3, size, size)
             mem = bld.buf(b * m, 7, 7, 256)
-            xf, hf = bld.backbone_bf16(xin, b, size, dtype=dtype, neck_f32=True)
-            bbox, cls2, S = bld.heads(xf, b, hf, self._zenc[b]['zk'], mem, m)
+            if heads_lp:
+                xl, hf = bld.backbone_bf16(xin, b, size, dtype=dtype, neck_f32=False)
+                bbox, cls2, S = bld.heads_lp(xl, b, hf, self._zenc[b]['zk'], mem, m, dtype)
+                xf = xl                                   # returned as the neck map (low precision)
+            else:
+                xf, hf = bld.backbone_bf16(xin, b, size, dtype=dtype, neck_f32=True)
+                bbox, cls2, S = bld.heads(xf, b, hf, self._zenc[b]['zk'], mem, m)
             self._finish(bld.plan)
             self._track[key] = dict(x=xin, xf=xf, hf=hf, mem=mem, bbox=bbox, cls2=cls2, S=S, plan=bld.plan, log=bld.log)
         p = self._track[key]
         p['x'].copy_(x)
         p['mem'].copy_(hip.to_nhwc(_as_dev_f32(template_mem, self.device)))
         p['plan'].run()
-        return p['cls2'][0].clone(), p['bbox'].clone(), p['cls2'][1].clone(), p['xf'].permute(0, 3, 1, 2)
+        return p['cls2'][0].clone(), p['bbox'].clone(), p['cls2'][1].clone(), p['xf'].float().permute(0, 3, 1, 2)
 
     def pool(self, xf, boxes):
         """models.py:164-171: PrRoIPool 7x7, scale 1, batch index prepended -> NCHW dense."""
