@@ -82,7 +82,10 @@ int64_t usot_conv_ws_floats(const usot_conv_desc *d);          /* workspace need
  * Cout % 4 == 0.                                                                         */
 int usot_conv2d_bf16(void *stream, const usot_conv_desc *d);
 /* general low-precision form: dtype 0 = bf16, 1 = fp16 (v_mfma_f32_16x16x32_f16); out_f32 != 0
- * stores the result as fp32 (the neck output feeding the fp32 xcorr/heads, BASELINE config 5) */
+ * stores the result as fp32 (outputs feeding the fp32 xcorr / reduce / prediction convs, BASELINE
+ * config 5).  Also honoured: act / act2 / act_split (NONE, RELU, EXP, CONF) and groups with x_gs,
+ * w_gs, b_gs, y_gs (y_gs in OUTPUT elements; no residual with groups).  Not supported: ksplit,
+ * y_nchw, channel-offset outputs.  tile: 0 = heuristic, 1..usot_conv_bf16_tile_count().           */
 int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, int out_f32);
 int usot_cvt_f32_to_lp(void *stream, const float *src, void *dst, int64_t n, int dtype);
 int usot_maxpool3x3s2_lp(void *stream, const void *x, void *y, int N, int H, int W, int C, int OH, int OW, int dtype);

@@ -410,3 +410,31 @@ def test_stem_pool_lp(size, n, dtype):
     err = (got - ref).abs() / ref.abs().clamp_min(1.0)
     assert float(err.max()) <= 1.01 * ulp, float(err.max())
     assert float((err > 0).float().mean()) < 0.02          # the rare 1-ulp rounding flips only
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('tile', [0, 4, 13, 21])
+def test_conv_lp_groups_and_activations(dtype, tile):
+    """Low-precision conv with three grouped problems (the towers), split activations (conf | value of
+    Conf_Fusion, connect.py:123-131) and fp32 output, vs torch on the same rounded operands."""
+    g = torch.Generator().manual_seed(77)
+    G, N, H, Cin, Cout = 3, 2, 13, 64, 64
+    x = torch.randn(G, N, Cin, H, H, generator=g).to(dtype)
+    w = (torch.randn(G * Cout, Cin, 3, 3, generator=g) / 24).to(dtype)
+    b = torch.randn(G * Cout, generator=g) * 0.2
+    xd = x.permute(0, 1, 3, 4, 2).contiguous().to(DEV)
+    wd = w.permute(0, 2, 3, 1).reshape(G * Cout, -1).contiguous().to(DEV)
+    y = hip.conv2d_bf16(xd, wd, b.to(DEV), KH=3, KW=3, pad=(1, 1), act=hip.ACT_RELU, tile=tile, groups=G, out_f32=True)
+    for gi in range(G):
+        ref = F.relu(F.conv2d(x[gi].float(), w[gi * Cout:(gi + 1) * Cout].float(), b[gi * Cout:(gi + 1) * Cout], 1, 1))
+        assert rel_err(y[gi].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 2e-5
+    # conf (exp(clamp(relu))) on the first half of the channels, value (relu) on the second
+    y = hip.conv2d_bf16(xd[0], wd[:Cout], b[:Cout].to(DEV), KH=3, KW=3, pad=(1, 1), act=hip.ACT_CONF, act2=hip.ACT_RELU,
+                        act_split=Cout // 2, tile=tile, out_f32=True)
+    pre = F.conv2d(x[0].float(), w[:Cout].float(), b[:Cout], 1, 1)
+    ref = torch.cat([torch.exp(torch.clamp(F.relu(pre[:, :Cout // 2]), -6, 4)), F.relu(pre[:, Cout // 2:])], 1)
+    assert rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 2e-5
+    y = hip.conv2d_bf16(xd[0], wd[:Cout], (b[:Cout] * 0.1).to(DEV), KH=3, KW=3, pad=(1, 1), act=hip.ACT_EXP, tile=tile)
+    ref = torch.exp(F.conv2d(x[0].float(), w[:Cout].float(), b[:Cout] * 0.1, 1, 1))
+    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    assert float(((y.float().permute(0, 3, 1, 2).cpu() - ref).abs() / ref.abs()).max()) < 1.5 * ulp

@@ -683,9 +683,10 @@ __global__ __launch_bounds__(256) void stem_pool_lp_kernel(
 
 extern "C" int usot_conv_bf16_tile_count(void) { return kNumTilesB; }
 
-/* bf16 NHWC conv: x/w/res/y are bf16 (uint16 storage), bias fp32.  Uses the fields N..dil_w,
- * act (NONE or RELU), tile of usot_conv_desc; y dense NHWC [N][OH][OW][Cout]; res same layout;
- * Cin % 64 == 0, Cout % 4 == 0; groups / ksplit / nchw output are fp32-path features. */
+/* bf16|fp16 NHWC conv: x/w/res/y in the storage type (uint16), bias fp32.  Uses the fields N..dil_w,
+ * act/act2/act_split, groups (+ x_gs, w_gs, b_gs, y_gs), tile of usot_conv_desc; y dense NHWC
+ * [groups][N][OH][OW][Cout]; res same layout (groups == 1 only); Cin % 64 == 0, Cout % 4 == 0;
+ * ksplit / nchw / channel-offset outputs are fp32-path features. */
 extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, int out_f32)
 {
     if (dtype != 0 && dtype != 1) return USOT_EINVAL;

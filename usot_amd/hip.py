@@ -352,21 +352,24 @@ def decode(cls, cls_mem, bbox, window, S, instance_size, stride, ratio, penalty_
     return out
 
 
-def conv2d_bf16(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, act=ACT_NONE, tile=0, out_f32=False):
-    """x NHWC bf16|fp16 [N,H,W,Cin], w packed same dtype [Cout, KH*KW*Cin], bias fp32 -> y NHWC
-    (same dtype, or fp32 with out_f32)."""
+def conv2d_bf16(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, act=ACT_NONE, tile=0, out_f32=False,
+                act2=ACT_NONE, act_split=0, groups=1):
+    """x NHWC bf16|fp16 [N,H,W,Cin] (groups > 1: [G,N,H,W,Cin]), w packed same dtype [G*Cout, KH*KW*Cin],
+    bias fp32 [G*Cout] -> y NHWC [N,OH,OW,Cout] ([G,N,OH,OW,Cout]) in the same dtype, or fp32 with out_f32."""
     lp = x.dtype
     if lp not in (torch.bfloat16, torch.float16):
         raise HipError('conv2d_bf16 takes bf16 or fp16 tensors')
     _dev(x, lp), _dev(w, lp)
-    N, H, W_, Cin = x.shape
-    Cout = w.shape[0]
+    N, H, W_, Cin = x.shape[-4:]
+    Cout = w.shape[0] // groups
     OH = (H + 2 * pad[0] - dil[0] * (KH - 1) - 1) // stride + 1
     OW = (W_ + 2 * pad[1] - dil[1] * (KW - 1) - 1) // stride + 1
-    y = torch.empty((N, OH, OW, Cout), device=x.device, dtype=torch.float32 if out_f32 else lp)
+    shape = (N, OH, OW, Cout) if groups == 1 else (groups, N, OH, OW, Cout)
+    y = torch.empty(shape, device=x.device, dtype=torch.float32 if out_f32 else lp)
     d = conv_desc(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                   N=N, H=H, W=W_, Cin=Cin, OH=OH, OW=OW, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil,
-                  res=res.data_ptr() if res is not None else None, act=act, tile=tile)
+                  res=res.data_ptr() if res is not None else None, act=act, act2=act2, act_split=act_split, tile=tile,
+                  groups=groups, x_gs=N * H * W_ * Cin, w_gs=Cout * KH * KW * Cin, b_gs=Cout, y_gs=N * OH * OW * Cout)
     check(lib().usot_conv2d_lp(stream(), C.byref(d), 1 if lp == torch.float16 else 0, int(out_f32)), 'usot_conv2d_lp')
     return y
 
