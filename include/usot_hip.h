@@ -71,6 +71,12 @@ int usot_conv2d_f32(void *stream, const usot_conv_desc *d);
  * d[0].tile, own ksplit each): shortcut conv + conv1 of a bottleneck, the three dilated
  * encoders of one input, the prediction heads. */
 int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int n);
+/* thin 3x3 / stride 1 / pad 1 convolutions with 1-4 output channels and NCHW output (the prediction
+ * heads, connect.py:236-241,275): up to four descriptors of the same input geometry per launch, one
+ * wavefront per output pixel; honours x, w, bias, y, N, H, W, Cin, Cout, act, groups and the group
+ * strides of the descriptor. */
+int usot_thin_conv3x3_f32(void *stream, const usot_conv_desc *d, int n);
+int usot_plan_add_thin_conv(void *plan, const usot_conv_desc *d, int n);
 int usot_conv_tile_count(void);
 int usot_conv_tile_info(int tile, int *bm, int *bn);           /* tile ids are 1..count */
 int usot_conv_tile_name(int tile, char *buf, int len);         /* kernel symbol of the tile */

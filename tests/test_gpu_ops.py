@@ -438,3 +438,34 @@ def test_conv_lp_groups_and_activations(dtype, tile):
     ref = torch.exp(F.conv2d(x[0].float(), w[:Cout].float(), b[:Cout] * 0.1, 1, 1))
     ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
     assert float(((y.float().permute(0, 3, 1, 2).cpu() - ref).abs() / ref.abs()).max()) < 1.5 * ulp
+
+
+@pytest.mark.parametrize('n,hw', [(1, 25), (2, 27), (1, 7)])
+def test_thin_conv3x3_prediction_heads(n, hw):
+    """usot_thin_conv3x3_f32: bbox_pred (4 ch, exp) + cls/cls_mem preds (two 1-ch groups) in one launch."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(n * 100 + hw)
+    x = torch.randn(3, n, 256, hw, hw, generator=g)                       # three tower outputs
+    wb = torch.randn(4, 256, 3, 3, generator=g) / 48
+    bb = torch.randn(4, generator=g) * 0.1
+    wc = torch.randn(2, 256, 3, 3, generator=g) / 48
+    bc = torch.randn(2, generator=g)
+    xd = x.permute(0, 1, 3, 4, 2).contiguous().to(DEV)
+    wbd, wcd, bbd, bcd = pack_w(wb).to(DEV), pack_w(wc).to(DEV), bb.to(DEV), bc.to(DEV)
+    yb = torch.empty(n, 4, hw, hw, device=DEV)
+    yc = torch.empty(2, n, 1, hw, hw, device=DEV)
+    gs = n * hw * hw * 256
+    descs = [hip.conv_desc(xd[0].data_ptr(), wbd.data_ptr(), bbd.data_ptr(), yb.data_ptr(), N=n, H=hw, W=hw, Cin=256, OH=hw, OW=hw,
+                           Cout=4, KH=3, KW=3, pad=(1, 1), act=hip.ACT_EXP, y_nchw=1),
+             hip.conv_desc(xd[1].data_ptr(), wcd.data_ptr(), bcd.data_ptr(), yc.data_ptr(), N=n, H=hw, W=hw, Cin=256, OH=hw, OW=hw,
+                           Cout=1, KH=3, KW=3, pad=(1, 1), y_nchw=1, groups=2, x_gs=gs, w_gs=2304, b_gs=1, y_gs=n * hw * hw)]
+    arr = (hip.ConvDesc * 2)(*descs)
+    hip.check(hip.lib().usot_thin_conv3x3_f32(hip.stream(), arr, 2), 'thin')
+    ref_b = torch.exp(F.conv2d(x[0], wb, bb, 1, 1))
+    assert rel_err(yb.cpu().numpy(), ref_b.numpy()) < 1e-5
+    for gi in range(2):
+        ref = F.conv2d(x[1 + gi], wc[gi:gi + 1], bc[gi:gi + 1], 1, 1)
+        assert rel_err(yc[gi].cpu().numpy(), ref.numpy()) < 1e-5
+    bad = hip.conv_desc(xd[0].data_ptr(), wbd.data_ptr(), bbd.data_ptr(), yb.data_ptr(), N=n, H=hw, W=hw, Cin=256, OH=hw, OW=hw,
+                        Cout=4, KH=3, KW=3, pad=(0, 0), y_nchw=1)
+    assert hip.lib().usot_thin_conv3x3_f32(hip.stream(), C.byref(bad), 1) != 0

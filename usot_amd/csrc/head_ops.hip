@@ -138,6 +138,88 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(
     }
 }
 
+// ---- thin 3x3 convolutions: the prediction heads (connect.py:236-241,275): bbox_pred 256 -> 4,
+// cls_pred / cls_memory_pred 256 -> 1.  On the tile kernels these are 2304-deep dot products with
+// 1-4 useful output columns of a 32-wide tile (21 us per frame, 0.9 TFLOP/s).  Here one wavefront
+// owns one output pixel of one problem: lane = 4 input channels, 9 taps x 16-byte loads of x and of
+// each filter row, a butterfly reduction, lane 0 stores.  Up to four problems (x groups) per launch.
+struct ThinK {
+    const float *x[4], *w[4], *bias[4];
+    float *y[4];
+    int cout[4], act[4], groups[4], start[5];      // start: first work item of problem i
+    long x_gs[4], w_gs[4], y_gs[4];
+    int b_gs[4];
+    int n, N, H, W, Cin;                           // shared geometry (3x3, stride 1, pad 1)
+};
+
+__device__ __forceinline__ float thin_act(float v, int a)
+{
+    switch (a) {
+    case USOT_ACT_RELU: return fmaxf(v, 0.0f);
+    case USOT_ACT_EXP:  return expf(v);
+    case USOT_ACT_CONF: return expf(fminf(fmaxf(v, 0.0f), 4.0f));
+    default:            return v;
+    }
+}
+
+template <int CO>
+__device__ __forceinline__ void thin_pixel(const ThinK &k, int pi, int g, int pix, int lane)
+{
+    const int P = k.H * k.W;
+    const int n = pix / P, r = pix - n * P;
+    const int oh = r / k.W, ow = r - oh * k.W;
+    const float *xg = k.x[pi] + (long)g * k.x_gs[pi] + (long)n * P * k.Cin;
+    const float *wg = k.w[pi] + (long)g * k.w_gs[pi];
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    for (int c0 = lane * 4; c0 < k.Cin; c0 += 256) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+            if ((unsigned)ih >= (unsigned)k.H || (unsigned)iw >= (unsigned)k.W) continue;     // wave-uniform
+            const f32x4 xv = *(const f32x4 *)(xg + ((long)ih * k.W + iw) * k.Cin + c0);
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                const f32x4 wv = *(const f32x4 *)(wg + ((long)c * 9 + t) * k.Cin + c0);
+                acc[c] = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc[c]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
+    }
+    if (lane == 0) {
+        const float *bg = k.bias[pi] ? k.bias[pi] + (long)g * k.b_gs[pi] : nullptr;
+        float *yg = k.y[pi] + (long)g * k.y_gs[pi];
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+            yg[((long)n * CO + c) * P + r] = thin_act(acc[c] + (bg ? bg[c] : 0.f), k.act[pi]);   // NCHW
+    }
+}
+
+__global__ __launch_bounds__(256) void thin_conv3x3_kernel(const ThinK k)
+{
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= k.start[k.n]) return;
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < k.n && item >= k.start[q]) pi = q;
+    const int local = item - k.start[pi];
+    const int per_g = k.N * k.H * k.W;
+    const int g = local / per_g, pix = local - g * per_g;
+    switch (k.cout[pi]) {
+    case 1: thin_pixel<1>(k, pi, g, pix, lane); break;
+    case 2: thin_pixel<2>(k, pi, g, pix, lane); break;
+    case 3: thin_pixel<3>(k, pi, g, pix, lane); break;
+    default: thin_pixel<4>(k, pi, g, pix, lane); break;
+    }
+}
+
 // up to four banks with different row lengths, same row indices, one launch (blockIdx.y = bank)
 struct RowsK {
     const float *src[4];
@@ -428,6 +510,34 @@ extern "C" int usot_rows_copy_multi_f32(void *stream, int nseg, const float *con
     k.nseg = nseg; k.n_rows = n_rows; k.scatter = scatter; k.stash = stash_next;
     const int blocks = (int)((most + 255) / 256 > 1024 ? 1024 : (most + 255) / 256);
     hipLaunchKernelGGL(rows_copy_multi_kernel, dim3(blocks, nseg), dim3(256), 0, (hipStream_t)stream, k, (const int *)idx_dev);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+extern "C" int usot_thin_conv3x3_f32(void *stream, const usot_conv_desc *d, int n)
+{
+    if (!d || n < 1 || n > 4) return USOT_EINVAL;
+    ThinK k;
+    k.n = n; k.N = d[0].N; k.H = d[0].H; k.W = d[0].W; k.Cin = d[0].Cin;
+    int total = 0;
+    for (int i = 0; i < 4; ++i) {
+        const usot_conv_desc &c = d[i < n ? i : 0];
+        if (i < n) {
+            if (!c.x || !c.w || !c.y || c.res || c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad_h != 1 || c.pad_w != 1 ||
+                c.dil_h != 1 || c.dil_w != 1 || !c.y_nchw || c.ksplit > 1 || c.y_coff || c.act_split > 0) return USOT_EINVAL;
+            if (c.N != k.N || c.H != k.H || c.W != k.W || c.Cin != k.Cin || c.OH != c.H || c.OW != c.W) return USOT_EINVAL;
+            if (c.Cout < 1 || c.Cout > 4 || (c.Cin & 3) || c.N <= 0) return USOT_EINVAL;
+            if (((uintptr_t)c.x % 16) || ((uintptr_t)c.w % 16) || ((c.x_gs | c.w_gs) & 3)) return USOT_EINVAL;
+        }
+        const int groups = c.groups > 1 ? c.groups : 1;
+        k.x[i] = c.x; k.w[i] = c.w; k.bias[i] = c.bias; k.y[i] = c.y;
+        k.cout[i] = c.Cout; k.act[i] = c.act; k.groups[i] = groups;
+        k.x_gs[i] = c.x_gs; k.w_gs[i] = c.w_gs; k.y_gs[i] = c.y_gs; k.b_gs[i] = (int)c.b_gs;
+        k.start[i] = total;
+        if (i < n) total += groups * c.N * c.H * c.W;
+    }
+    for (int i = n; i < 5; ++i) k.start[i] = total;
+    hipLaunchKernelGGL(thin_conv3x3_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, k);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }

@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -108,6 +108,13 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
         case K_POOLB:
             rc = usot_maxpool3x3s2_lp(s, op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6]);
             break;
+        case K_THIN: {
+            usot_conv_desc tmp[4];
+            tmp[0] = op.conv;
+            for (int q = 1; q < op.nconv; ++q) tmp[q] = op.more[q - 1];
+            rc = usot_thin_conv3x3_f32(s, tmp, op.nconv);
+            break;
+        }
         case K_ROWSM: {
             const float *srcs[4] = {(const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], (const float *)op.p[3]};
             float *dsts[4] = {(float *)op.l[0], (float *)op.l[1], (float *)op.l[2], (float *)op.l[3]};
@@ -229,6 +236,17 @@ extern "C" int usot_plan_add_cvt_lp(void *plan, const float *src, void *dst, int
     Op *op = push(plan, K_CVTB);
     if (!op) return USOT_ESTATE;
     op->p[0] = src; op->p[1] = dst; op->l[0] = n; op->i[6] = dtype;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_thin_conv(void *plan, const usot_conv_desc *d, int n)
+{
+    if (!d || n < 1 || n > 4) return USOT_EINVAL;
+    Op *op = push(plan, K_THIN);
+    if (!op) return USOT_ESTATE;
+    op->conv = d[0];
+    for (int q = 1; q < n; ++q) op->more[q - 1] = d[q];
+    op->nconv = n;
     return USOT_OK;
 }
 

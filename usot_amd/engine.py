@@ -277,6 +277,20 @@ class Builder:
                          descs[0].KH * descs[0].KW * descs[0].Cin, len(descs), macs))
         return outs
 
+    def thin_convs(self, items):
+        """The prediction convs (1-4 output channels, 3x3/p1, NCHW output) in one launch of the thin
+        kernel (usot_thin_conv3x3_f32) instead of 32-wide MFMA tiles.  items as for conv_batch."""
+        descs, outs, macs = [], [], 0
+        for nm, pc, x, n, h, w, kw in items:
+            d, y, oh, ow, log, geom = self.conv_desc(nm, pc, x, n, h, w, tile=7, **kw)
+            d.ksplit, d.ws = 1, None
+            descs.append(d)
+            outs.append((y, oh, ow))
+            macs += log[5]
+        arr = (hip.ConvDesc * len(descs))(*descs)
+        hip.check(hip.lib().usot_plan_add_thin_conv(self.plan.h, arr, len(descs)), 'plan_add_thin_conv')
+        return outs
+
     # ---- a1-a4: backbone + neck: x NCHW [n,3,s,s] -> xf NHWC [n,hf,wf,256]
     def backbone(self, x, n, size):
         W, L = self.W, hip.lib()
@@ -376,7 +390,7 @@ class Builder:
                                        dtype=dtype, out_f32=(i == 3))
         bbox = self.buf(b, 4, S, S)
         cls2 = self.buf(2, b, 1, S, S)
-        self.conv_batch([('bbox_pred', W.bbox_pred, cur[0], b, S, S, dict(act=ACT_EXP, y=bbox, y_nchw=True)),
+        self.thin_convs([('bbox_pred', W.bbox_pred, cur[0], b, S, S, dict(act=ACT_EXP, y=bbox, y_nchw=True)),
                          ('cls_preds', W.cls_preds, cur[1], b, S, S, dict(cout=1, y=cls2, y_nchw=True, groups=2,
                                                                           x_gs=gs, y_gs=b * S * S, w_rows=1))])
         return bbox, cls2, S
@@ -469,7 +483,7 @@ class Builder:
                 self.conv('tower%d' % i, W.tower[i], cur, b, S, S, cout=256, act=ACT_RELU, y=tout[i], groups=3,
                           x_gs=gs, y_gs=gs)
                 cur = tout[i]
-            self.conv_batch([('bbox_pred', W.bbox_pred, cur[0], b, S, S, dict(act=ACT_EXP, y=bbox, y_nchw=True)),
+            self.thin_convs([('bbox_pred', W.bbox_pred, cur[0], b, S, S, dict(act=ACT_EXP, y=bbox, y_nchw=True)),
                              ('cls_preds', W.cls_preds, cur[1], b, S, S, dict(cout=1, y=cls2, y_nchw=True, groups=2,
                                                                               x_gs=gs, y_gs=b * S * S, w_rows=1))])
             return bbox, cls2, S

@@ -26,7 +26,7 @@ EXPORTS = (
     'usot_plan_add_conv_bf16', 'usot_plan_add_cvt_bf16', 'usot_plan_add_maxpool_bf16',
     'usot_conv2d_lp', 'usot_cvt_f32_to_lp', 'usot_maxpool3x3s2_lp', 'usot_plan_add_conv_lp', 'usot_plan_add_cvt_lp',
     'usot_plan_add_maxpool_lp', 'usot_stem_pool_lp', 'usot_plan_add_stem_pool_lp',
-    'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi',
+    'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
 )
 
@@ -89,6 +89,8 @@ def lib():
                                            + [C.c_double] * 2 + [C.c_void_p] * 2)
         L.usot_plan_add_rows_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int] * 3
         L.usot_rows_copy_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
+        L.usot_thin_conv3x3_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.usot_plan_add_thin_conv.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_rows_copy_multi_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.usot_plan_add_rows_copy_multi.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.usot_crop_resize_u8_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 9
