@@ -17,6 +17,7 @@ ap.add_argument('--reps', type=int, default=12)
 ap.add_argument('--out', default=os.path.join(ROOT, 'usot_amd', 'data', 'tuning_gfx950.json'))
 ap.add_argument('--verbose', action='store_true')
 ap.add_argument('--split-margin', type=float, default=0.10)
+ap.add_argument('--candidates', default=None, help='also write the 6 fastest (tile, ksplit) per shape here (for scripts/tune_frame.py)')
 a = ap.parse_args()
 
 dev = torch.device('cuda:0')
@@ -50,6 +51,7 @@ for B in a.batch:
             collect(Builder(W, {}, lanes), B, size)
 tiles = hip.tile_table()
 L = hip.lib()
+cands = {}
 table = {}
 if os.path.exists(a.out):
     with open(a.out) as f:
@@ -114,6 +116,7 @@ for key, g in sorted(shapes.items()):
     us, tile, ks = best
     tf = 2.0 * M * Cout * K * groups / us / 1e6
     table['%d,%d,%d,%d' % key] = [tile, ks]
+    cands['%d,%d,%d,%d' % key] = [[t2, k2, round(us2, 2)] for us2, t2, k2 in sorted(rows)[:6]]
     print('%-14s M=%6d N=%5d K=%5d g=%d -> tile %2d (%dx%d) ksplit %d: %7.1f us %6.1f TFLOP/s' % (
         g['name'], M, Cout, K, groups, tile, tiles[tile][0], tiles[tile][1], ks, us, tf), flush=True)
     if a.verbose:
@@ -122,3 +125,6 @@ for key, g in sorted(shapes.items()):
 with open(a.out, 'w') as f:
     json.dump(table, f, indent=0, sort_keys=True)
 print('wrote', a.out, len(table), 'shapes')
+if a.candidates:
+    with open(a.candidates, 'w') as f:
+        json.dump(cands, f, indent=0, sort_keys=True)

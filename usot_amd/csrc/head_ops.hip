@@ -176,9 +176,13 @@ __device__ __forceinline__ void thin_pixel(const ThinK &k, int pi, int g, int pi
     for (int c0 = lane * 4; c0 < k.Cin; c0 += 256) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
+            // branch-free: padding taps read a clamped (valid) pixel and are scaled by 0, so that all 9
+            // pixel loads and 9 x CO filter loads of the lane can be in flight together
             const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
-            if ((unsigned)ih >= (unsigned)k.H || (unsigned)iw >= (unsigned)k.W) continue;     // wave-uniform
-            const f32x4 xv = *(const f32x4 *)(xg + ((long)ih * k.W + iw) * k.Cin + c0);
+            const bool ok = (unsigned)ih < (unsigned)k.H && (unsigned)iw < (unsigned)k.W;
+            const int ihc = min(max(ih, 0), k.H - 1), iwc = min(max(iw, 0), k.W - 1);
+            f32x4 xv = *(const f32x4 *)(xg + ((long)ihc * k.W + iwc) * k.Cin + c0);
+            xv *= ok ? 1.f : 0.f;
 #pragma unroll
             for (int c = 0; c < CO; ++c) {
                 const f32x4 wv = *(const f32x4 *)(wg + ((long)c * 9 + t) * k.Cin + c0);
