@@ -42,7 +42,8 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
-@pytest.mark.parametrize('tile', [0, 4, 7, 8, 11, 12, 13, 15, 16, 19, 20, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36])
+@pytest.mark.parametrize('tile', [0, 4, 7, 8, 11, 12, 13, 15, 16, 19, 20, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36,
+                                  38, 41, 47, 53, 54, 55, 56, 57, 58, 59, 60])
 def test_conv_igemm(case, tile):
     N, Cin, H, W, Cout, k, stride, pad, dil = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))

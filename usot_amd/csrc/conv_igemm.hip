@@ -567,8 +567,12 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
 // tile t+3 are issued only after those of tile t+2 have landed, so a k-step can never be shorter
 // than one L2/HBM round trip (measured: 32x32x64 steps took ~600 ns with the MFMAs removed);
 // D = 2/3 rotate that many register buffers so a step only waits for loads issued D steps ago.
-template <int BM, int BN, int WM, int WN, int BK, int D = 1>
-__global__ __launch_bounds__(512) void conv_igemm_f32_v3(const ConvBatch bt)
+// NPW = producer wavefronts (4 or 8): the producers' k-step (four ds_write_b128 + lgkmcnt(0) ~500 cycles, address
+// VALU + load issue ~450, measured with s_memtime) is what the consumers wait for; eight producers halve the
+// per-wave share.  FP = the consumers fetch ALL fragments of k-tile t+1 while the MFMAs of tile t run (a one-round
+// look-ahead left every 4-MFMA round waiting ~90 cycles on its ds_read_b128: 800 cycles per 16 MFMAs, not 512).
+template <int BM, int BN, int WM, int WN, int BK, int D = 1, int NPW = 4, bool FP = false>
+__global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBatch bt)
 {
     int pi = 0;
 #pragma unroll
@@ -580,14 +584,15 @@ __global__ __launch_bounds__(512) void conv_igemm_f32_v3(const ConvBatch bt)
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int LD = BK + 4;
     constexpr int CPR = BK / 4;
-    constexpr int RPP = 256 / CPR;
+    constexpr int NPT = 64 * NPW;                 // producer threads
+    constexpr int RPP = NPT / CPR;
     constexpr int XI = (BM + RPP - 1) / RPP, WI = (BN + RPP - 1) / RPP;
     constexpr int NR = BK / 16;
     constexpr int STAGE = (BM + BN) * LD;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const bool producer = threadIdx.x >= 256;
-    const int tid = threadIdx.x & 255;
+    const int tid = producer ? (int)threadIdx.x - 256 : (int)threadIdx.x;
     const int tiles = p.MT * p.NT;
     const int total = tiles * p.groups * p.ksplit;
     const int b = xcd_remap(bid0, total);
@@ -755,18 +760,72 @@ __global__ __launch_bounds__(512) void conv_igemm_f32_v3(const ConvBatch bt)
         }
     };
     __syncthreads();
-    if (nt > 0) read_frags(0, 0, 0);
-    int st = 0;
-    for (int t = 0; t < nt; ++t) {
-        const int st1 = st == 2 ? 0 : st + 1;
+    if constexpr (!FP) {
+        if (nt > 0) read_frags(0, 0, 0);
+        int st = 0;
+        for (int t = 0; t < nt; ++t) {
+            const int st1 = st == 2 ? 0 : st + 1;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
-            else if (t + 1 < nt) read_frags(st1, 0, 0);
-            mma(r & 1);
+            for (int r = 0; r < NR; ++r) {
+                if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
+                else if (t + 1 < nt) read_frags(st1, 0, 0);
+                mma(r & 1);
+            }
+            st = st1;
+            __syncthreads();
         }
-        st = st1;
-        __syncthreads();
+    } else {
+        // two whole-tile fragment sets; the producers are two k-tiles ahead, so tile t+1 is complete in LDS
+        // when tile t starts
+        f32x4 gw[2][NR][TN], gx[2][NR][TM];
+        auto read_tile = [&](int st, auto sc) {
+            constexpr int slot = decltype(sc)::value;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float *base = smem + st * STAGE + r * 16;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) gw[slot][r][i] = *(const f32x4 *)(base + fw_off + i * 16 * LD);
+#pragma unroll
+                for (int j = 0; j < TM; ++j) gx[slot][r][j] = *(const f32x4 *)(base + fx_off + j * 16 * LD);
+            }
+        };
+        auto mma_tile = [&](auto sc) {
+            constexpr int slot = decltype(sc)::value;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if constexpr (TM * TN == 1) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(gw[slot][r][0][0], gx[slot][r][0][0], acc[0][0], 0, 0, 0);
+                    acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(gw[slot][r][0][1], gx[slot][r][0][1], acc2, 0, 0, 0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(gw[slot][r][0][2], gx[slot][r][0][2], acc[0][0], 0, 0, 0);
+                    acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(gw[slot][r][0][3], gx[slot][r][0][3], acc2, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int i = 0; i < TN; ++i)
+#pragma unroll
+                            for (int j = 0; j < TM; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gw[slot][r][i][c], gx[slot][r][j][c], acc[i][j], 0, 0, 0);
+                }
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        if (nt > 0) read_tile(0, S0{});
+        int st = 0;
+        auto cstep = [&](auto cur, auto nxt, int t) {
+            const int st1 = st == 2 ? 0 : st + 1;
+            if (t + 1 < nt) read_tile(st1, nxt);
+            mma_tile(cur);
+            st = st1;
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + 2 <= nt; t += 2) {
+            cstep(S0{}, S1{}, t);
+            cstep(S1{}, S0{}, t + 1);
+        }
+        if (t < nt) cstep(S0{}, S1{}, t);
     }
     if constexpr (TM * TN == 1) acc[0][0] += acc2;
 
@@ -859,6 +918,7 @@ struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int t
 #define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v2<bm, bn, wm, wn, bk>, 256, 1 }
 #define TILE3(bm, bn, wm, wn, bk, ksw) { bm, bn, bk, 3, ksw, conv_igemm_f32_v2<bm, bn, wm, wn, bk, ksw>, 256 * ksw, 1 }
 #define TILE4(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk>, 512, 1 }
+#define TILE10(bm, bn, wm, wn, bk, d, npw, fp) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw, fp>, 256 + 64 * npw, d }
 #define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
@@ -913,6 +973,14 @@ const TileCfg kTiles[] = {
     TILE5(64, 128, 2, 2, 32, 3),   // 50
     TILE5(128, 64, 2, 2, 32, 3),   // 51
     TILE5(32, 128, 2, 2, 64, 3),   // 52
+    TILE10(32, 32, 2, 2, 64, 2, 8, false),   // 53: eight producer waves
+    TILE10(32, 32, 2, 2, 64, 3, 8, false),   // 54
+    TILE10(32, 64, 2, 2, 64, 2, 8, false),   // 55
+    TILE10(32, 64, 2, 2, 64, 3, 8, false),   // 56
+    TILE10(64, 64, 2, 2, 64, 2, 8, false),   // 57
+    TILE10(64, 64, 2, 2, 32, 2, 8, false),   // 58
+    TILE10(32, 128, 2, 2, 64, 2, 8, false),  // 59
+    TILE10(64, 32, 2, 2, 64, 2, 8, false),   // 60
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -950,6 +1018,7 @@ extern "C" int usot_conv_tile_name(int tile, char *buf, int len)
 {
     if (tile < 1 || tile > kNumTiles || !buf || len < 8) return USOT_EINVAL;
     const TileCfg &t = kTiles[tile - 1];
+    if (t.threads == 768 && t.ksw == 1) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=8>", t.bm, t.bn, t.bk, t.depth); return USOT_OK; }
     const char *fam = t.threads == 512 && t.ksw == 1 ? "conv_igemm_f32_v3" : (t.stages == 3 ? "conv_igemm_f32_v2" : "conv_igemm_f32");
     if (t.stages == 3 && t.ksw > 1) snprintf(buf, len, "%s<%d,%d,%d,%d> ksw=%d", fam, t.bm, t.bn, t.bk, t.ksw, t.ksw);
     else if (t.depth > 1)           snprintf(buf, len, "%s<%d,%d,BK=%d,D=%d>", fam, t.bm, t.bn, t.bk, t.depth);
