@@ -116,7 +116,7 @@ for key, g in sorted(shapes.items()):
     us, tile, ks = best
     tf = 2.0 * M * Cout * K * groups / us / 1e6
     table['%d,%d,%d,%d' % key] = [tile, ks]
-    cands['%d,%d,%d,%d' % key] = [[t2, k2, round(us2, 2)] for us2, t2, k2 in sorted(rows)[:6]]
+    cands['%d,%d,%d,%d' % key] = [[t2, k2, round(us2, 2)] for us2, t2, k2 in sorted(rows)[:10]]
     print('%-14s M=%6d N=%5d K=%5d g=%d -> tile %2d (%dx%d) ksplit %d: %7.1f us %6.1f TFLOP/s' % (
         g['name'], M, Cout, K, groups, tile, tiles[tile][0], tiles[tile][1], ks, us, tf), flush=True)
     if a.verbose:

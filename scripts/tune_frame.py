@@ -18,7 +18,8 @@ ap.add_argument('--candidates', required=True, help='tune_conv.py --candidates')
 ap.add_argument('--out', required=True)
 ap.add_argument('--size', type=int, default=255)
 ap.add_argument('--reps', type=int, default=40)
-ap.add_argument('--passes', type=int, default=1)
+ap.add_argument("--passes", type=int, default=1)
+ap.add_argument("--top", type=int, default=6, help="isolated candidates tried per shape")
 a = ap.parse_args()
 
 m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to('cuda:0')
@@ -66,7 +67,7 @@ for ps in range(a.passes):
     for k in order:
         cur = e.tuning.get(k)
         results = []
-        for c in cands[k][:6]:
+        for c in cands[k][:a.top]:
             e.tuning[k] = c
             try:
                 us, _ = frame_us()
