@@ -569,9 +569,9 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
 // D = 2/3 rotate that many register buffers so a step only waits for loads issued D steps ago.
 // NPW = producer wavefronts (4 or 8): the producers' k-step (four ds_write_b128 + lgkmcnt(0) ~500 cycles, address
 // VALU + load issue ~450, measured with s_memtime) is what the consumers wait for; eight producers halve the
-// per-wave share.  FP = the consumers fetch ALL fragments of k-tile t+1 while the MFMAs of tile t run (a one-round
-// look-ahead left every 4-MFMA round waiting ~90 cycles on its ds_read_b128: 800 cycles per 16 MFMAs, not 512).
-template <int BM, int BN, int WM, int WN, int BK, int D = 1, int NPW = 4, bool FP = false>
+// per-wave share.  (Fetching ALL fragments of k-tile t+1 during the MFMAs of tile t, instead of one 16-k round
+// ahead, measured 20 % slower and was dropped.)
+template <int BM, int BN, int WM, int WN, int BK, int D = 1, int NPW = 4>
 __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBatch bt)
 {
     int pi = 0;
@@ -760,72 +760,18 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
         }
     };
     __syncthreads();
-    if constexpr (!FP) {
-        if (nt > 0) read_frags(0, 0, 0);
-        int st = 0;
-        for (int t = 0; t < nt; ++t) {
-            const int st1 = st == 2 ? 0 : st + 1;
+    if (nt > 0) read_frags(0, 0, 0);
+    int st = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int st1 = st == 2 ? 0 : st + 1;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
-                else if (t + 1 < nt) read_frags(st1, 0, 0);
-                mma(r & 1);
-            }
-            st = st1;
-            __syncthreads();
+        for (int r = 0; r < NR; ++r) {
+            if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
+            else if (t + 1 < nt) read_frags(st1, 0, 0);
+            mma(r & 1);
         }
-    } else {
-        // two whole-tile fragment sets; the producers are two k-tiles ahead, so tile t+1 is complete in LDS
-        // when tile t starts
-        f32x4 gw[2][NR][TN], gx[2][NR][TM];
-        auto read_tile = [&](int st, auto sc) {
-            constexpr int slot = decltype(sc)::value;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const float *base = smem + st * STAGE + r * 16;
-#pragma unroll
-                for (int i = 0; i < TN; ++i) gw[slot][r][i] = *(const f32x4 *)(base + fw_off + i * 16 * LD);
-#pragma unroll
-                for (int j = 0; j < TM; ++j) gx[slot][r][j] = *(const f32x4 *)(base + fx_off + j * 16 * LD);
-            }
-        };
-        auto mma_tile = [&](auto sc) {
-            constexpr int slot = decltype(sc)::value;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                if constexpr (TM * TN == 1) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(gw[slot][r][0][0], gx[slot][r][0][0], acc[0][0], 0, 0, 0);
-                    acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(gw[slot][r][0][1], gx[slot][r][0][1], acc2, 0, 0, 0);
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(gw[slot][r][0][2], gx[slot][r][0][2], acc[0][0], 0, 0, 0);
-                    acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(gw[slot][r][0][3], gx[slot][r][0][3], acc2, 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int i = 0; i < TN; ++i)
-#pragma unroll
-                            for (int j = 0; j < TM; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gw[slot][r][i][c], gx[slot][r][j][c], acc[i][j], 0, 0, 0);
-                }
-            }
-        };
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
-        if (nt > 0) read_tile(0, S0{});
-        int st = 0;
-        auto cstep = [&](auto cur, auto nxt, int t) {
-            const int st1 = st == 2 ? 0 : st + 1;
-            if (t + 1 < nt) read_tile(st1, nxt);
-            mma_tile(cur);
-            st = st1;
-            __syncthreads();
-        };
-        int t = 0;
-        for (; t + 2 <= nt; t += 2) {
-            cstep(S0{}, S1{}, t);
-            cstep(S1{}, S0{}, t + 1);
-        }
-        if (t < nt) cstep(S0{}, S1{}, t);
+        st = st1;
+        __syncthreads();
     }
     if constexpr (TM * TN == 1) acc[0][0] += acc2;
 
@@ -918,7 +864,7 @@ struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int t
 #define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v2<bm, bn, wm, wn, bk>, 256, 1 }
 #define TILE3(bm, bn, wm, wn, bk, ksw) { bm, bn, bk, 3, ksw, conv_igemm_f32_v2<bm, bn, wm, wn, bk, ksw>, 256 * ksw, 1 }
 #define TILE4(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk>, 512, 1 }
-#define TILE10(bm, bn, wm, wn, bk, d, npw, fp) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw, fp>, 256 + 64 * npw, d }
+#define TILE10(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw>, 256 + 64 * npw, d }
 #define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
@@ -973,14 +919,14 @@ const TileCfg kTiles[] = {
     TILE5(64, 128, 2, 2, 32, 3),   // 50
     TILE5(128, 64, 2, 2, 32, 3),   // 51
     TILE5(32, 128, 2, 2, 64, 3),   // 52
-    TILE10(32, 32, 2, 2, 64, 2, 8, false),   // 53: eight producer waves
-    TILE10(32, 32, 2, 2, 64, 3, 8, false),   // 54
-    TILE10(32, 64, 2, 2, 64, 2, 8, false),   // 55
-    TILE10(32, 64, 2, 2, 64, 3, 8, false),   // 56
-    TILE10(64, 64, 2, 2, 64, 2, 8, false),   // 57
-    TILE10(64, 64, 2, 2, 32, 2, 8, false),   // 58
-    TILE10(32, 128, 2, 2, 64, 2, 8, false),  // 59
-    TILE10(64, 32, 2, 2, 64, 2, 8, false),   // 60
+    TILE10(32, 32, 2, 2, 64, 2, 8),   // 53: eight producer waves
+    TILE10(32, 32, 2, 2, 64, 3, 8),   // 54
+    TILE10(32, 64, 2, 2, 64, 2, 8),   // 55
+    TILE10(32, 64, 2, 2, 64, 3, 8),   // 56
+    TILE10(64, 64, 2, 2, 64, 2, 8),   // 57
+    TILE10(64, 64, 2, 2, 32, 2, 8),   // 58
+    TILE10(32, 128, 2, 2, 64, 2, 8),  // 59
+    TILE10(64, 32, 2, 2, 64, 2, 8),   // 60
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
