@@ -571,6 +571,9 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
 // VALU + load issue ~450, measured with s_memtime) is what the consumers wait for; eight producers halve the
 // per-wave share.  (Fetching ALL fragments of k-tile t+1 during the MFMAs of tile t, instead of one 16-k round
 // ahead, measured 20 % slower and was dropped.)
+// (Fetching ALL fragments of k-tile t+1 in front of tile t's MFMAs - pinned with sched_barrier, hipcc otherwise
+// sinks the reads to the end of the step - shortens the consumer's MFMA phase 828 -> 712 cycles but the burst of
+// ds_read_b128 doubles the producers' ds_write time; k-step 1064 -> 1196.  Not kept.)
 template <int BM, int BN, int WM, int WN, int BK, int D = 1, int NPW = 4>
 __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBatch bt)
 {
@@ -703,11 +706,21 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
         if constexpr (D >= 3) load_next(I2{});
         __syncthreads();
         int st2 = 2;                                  // stage that receives tile t+2
+#ifdef USOT_TRACE   // scripts/trace_kstep.py: s_memtime stamps of one producer wave into the (unused) split-K workspace
+        unsigned *trc = (p.ksplit == 1 && p.ws && bid0 == 0 && tid == 0) ? (unsigned *)p.ws : nullptr;
+#define USOT_STAMP(slot, t) if (trc && (t) < 64) trc[(t) * 8 + (slot)] = (unsigned)__builtin_readcyclecounter()
+#else
+#define USOT_STAMP(slot, t)
+#endif
         auto step = [&](auto dc, int t) {
+            USOT_STAMP(4, t);
             if (t + 2 < nt) store_tile(dc, st2);
+            USOT_STAMP(5, t);
             load_next(dc);
+            USOT_STAMP(6, t);
             st2 = st2 == 2 ? 0 : st2 + 1;
             __syncthreads();
+            USOT_STAMP(7, t);
         };
         int t = 0;
         for (; t + D <= nt; t += D) {
@@ -760,10 +773,14 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
         }
     };
     __syncthreads();
+#ifdef USOT_TRACE
+    unsigned *trc = (p.ksplit == 1 && p.ws && bid0 == 0 && tid == 0) ? (unsigned *)p.ws : nullptr;
+#endif
     if (nt > 0) read_frags(0, 0, 0);
     int st = 0;
     for (int t = 0; t < nt; ++t) {
         const int st1 = st == 2 ? 0 : st + 1;
+        USOT_STAMP(0, t);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
@@ -771,8 +788,11 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
             mma(r & 1);
         }
         st = st1;
+        USOT_STAMP(1, t);
         __syncthreads();
+        USOT_STAMP(2, t);
     }
+#undef USOT_STAMP
     if constexpr (TM * TN == 1) acc[0][0] += acc2;
 
     if (p.ksplit > 1) {

@@ -66,8 +66,9 @@ _lib = None
 
 def lib():
     """The loaded library; raises HipError when it has not been built."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is None:
+        LIB_PATH = os.environ.get('USOT_HIP_LIB', LIB_PATH)      # e.g. the -DUSOT_TRACE build of scripts/trace_kstep.py
         if not os.path.exists(LIB_PATH):
             raise HipError('%s is missing: run `python -m usot_amd.build` (hipcc, gfx950). '
                            'There is no CPU fallback for the tracking forward pass.' % LIB_PATH)
