@@ -20,6 +20,7 @@ ap.add_argument('--size', type=int, default=255)
 ap.add_argument('--reps', type=int, default=40)
 ap.add_argument("--passes", type=int, default=1)
 ap.add_argument("--top", type=int, default=6, help="isolated candidates tried per shape")
+ap.add_argument("--session", action="store_true", help="replay the device-resident Session frame (adds the per-frame encode of the new memory feature) instead of Engine.track")
 a = ap.parse_args()
 
 m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to('cuda:0')
@@ -37,10 +38,16 @@ e.tuning = dict(table)
 
 
 def frame_us():
-    e._track.clear()
-    for _ in range(2):
-        m.track(x, mem, sm)
-    p = e._track[(1, a.size, 7)]
+    if a.session:
+        import bench
+        sess, crops, pp = bench.open_stream(m, torch.device('cuda:0'), seed=0, size=a.size)
+        bench.run_frames(sess, crops, pp, [0.9], 3)
+        p = dict(plan=sess.plan, log=sess.log)
+    else:
+        e._track.clear()
+        for _ in range(2):
+            m.track(x, mem, sm)
+        p = e._track[(1, a.size, 7)]
     best = 1e9
     for _ in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
