@@ -586,16 +586,29 @@ __global__ __launch_bounds__(256) void stem_pool_lp_kernel(
     // input patch -> LDS in the storage type (out-of-image pixels and the pad column are zero;
     // they only ever feed stem pixels the pool masks out, or zero weights)
     const float *xn = x + (long)n * 3 * H * W;
-    for (int i = tid; i < 3 * SP_IR * SP_ICP; i += 256) {
+    // every global load of the patch is issued before the first LDS store (a load -> store loop
+    // serialises ~11 dependent HBM round trips per thread)
+    constexpr int NPL = (3 * SP_IR * SP_ICP + 255) / 256;
+    float pv[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int i = tid + q * 256;
         const int ci = i / (SP_IR * SP_ICP), r = i - ci * SP_IR * SP_ICP;
         const int py = r / SP_ICP, px = r - py * SP_ICP;
         const int iy = iy0 + py, ix = ix0 + px;
         float v = 0.f;
-        if (px < SP_IC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        if (i < 3 * SP_IR * SP_ICP && px < SP_IC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
             v = xn[((long)ci * H + iy) * W + ix] - (ci == 0 ? mu0 : (ci == 1 ? mu1 : mu2));
-        const uint32_t hi = pack_lp<F16>(v);
-        patch[i] = (uint16_t)hi;
-        if constexpr (SPLIT) patch[PLANE + i] = (uint16_t)pack_lp<F16>(v - unpack_lp<F16>(hi));
+        pv[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int i = tid + q * 256;
+        if (i < 3 * SP_IR * SP_ICP) {
+            const uint32_t hi = pack_lp<F16>(pv[q]);
+            patch[i] = (uint16_t)hi;
+            if constexpr (SPLIT) patch[PLANE + i] = (uint16_t)pack_lp<F16>(pv[q] - unpack_lp<F16>(hi));
+        }
     }
     __syncthreads();
 
