@@ -470,3 +470,29 @@ def test_thin_conv3x3_prediction_heads(n, hw):
     bad = hip.conv_desc(xd[0].data_ptr(), wbd.data_ptr(), bbd.data_ptr(), yb.data_ptr(), N=n, H=hw, W=hw, Cin=256, OH=hw, OW=hw,
                         Cout=4, KH=3, KW=3, pad=(0, 0), y_nchw=1)
     assert hip.lib().usot_thin_conv3x3_f32(hip.stream(), C.byref(bad), 1) != 0
+
+
+def test_rows_copy_multi_gather_scatter_and_stash():
+    """Four banks of different row length move with the same device row indices in one launch; the gather
+    also stashes idx[n_rows] (the frame's append row) in device memory."""
+    import ctypes as C
+    lens = [64, 128, 32, 256]
+    banks = [torch.randn(12, n, device=DEV) for n in lens]
+    idx = torch.tensor([5, 0, 11, 7, 9], dtype=torch.int32, device=DEV)        # 4 rows + the stashed entry
+    outs = [torch.zeros(4, n, device=DEV) for n in lens]
+    stash = torch.zeros(4, dtype=torch.int32, device=DEV)
+    pp = lambda ts: (C.c_void_p * 4)(*[t.data_ptr() for t in ts])
+    rl = (C.c_int32 * 4)(*lens)
+    hip.check(hip.lib().usot_rows_copy_multi_f32(hip.stream(), 4, pp(banks), hip.ptr(idx), pp(outs), 4, rl, 0, hip.ptr(stash)), 'gather')
+    for b, o in zip(banks, outs):
+        assert torch.equal(o, b[idx[:4].long()])
+    assert int(stash[0]) == 9
+    dsts = [torch.zeros(12, n, device=DEV) for n in lens]
+    hip.check(hip.lib().usot_rows_copy_multi_f32(hip.stream(), 3, pp(outs), hip.ptr(idx), pp(dsts), 4, rl, 1, None), 'scatter')
+    for k, (o, d) in enumerate(zip(outs, dsts)):
+        want = torch.zeros_like(d)
+        if k < 3:
+            want[idx[:4].long()] = o
+        assert torch.equal(d, want)
+    # a stash pointer is meaningless for a scatter
+    assert hip.lib().usot_rows_copy_multi_f32(hip.stream(), 1, pp(outs), hip.ptr(idx), pp(dsts), 4, rl, 1, hip.ptr(stash)) != 0

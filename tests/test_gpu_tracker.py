@@ -139,3 +139,24 @@ def test_sessions_on_separate_streams_overlap_safely(net):
     torch.cuda.synchronize()
     for k in range(2):
         np.testing.assert_array_equal(np.array(got[k]), np.array(want[k]))
+
+
+def test_session_cached_encodings_equal_reencoding(net):
+    """The session encodes a memory feature once, when it is appended; the reference re-encodes the picked
+    features every frame (connect.py:251-255).  After a few frames every cached row must equal a fresh
+    encoding of the bank row it belongs to."""
+    sess, crops = _open(net, 9)
+    for i in range(4):
+        sess.frame(crops[i % 4], [0, min(i, 1), 0, min(i, 2), 0], (63.5, 63.5))
+    torch.cuda.synchronize()
+    rows = 2 + sess.n
+    from usot_amd.engine import Builder
+    bld = Builder(net.engine.W, net.engine.tuning, 0)
+    src = bld.buf(rows, 7, 7, 256)
+    src.copy_(sess.bank[:rows])
+    enc = bld.encode_kernel(src, rows, 256, 'mem')
+    bld.plan.run()
+    torch.cuda.synchronize()
+    for g in range(3):
+        a, b = sess.bank_enc[g][:rows].cpu().numpy(), enc[g].cpu().numpy()
+        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
