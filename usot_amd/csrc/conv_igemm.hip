@@ -772,6 +772,24 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][i][c], fx[slot][j][c], acc[i][j], 0, 0, 0);
         }
     };
+    // bias and residual of this lane's outputs are fetched NOW, while the producers bring the first k-tiles:
+    // loaded in the epilogue they add a dependent L2/HBM round trip to the tail of every layer, when no
+    // other work is left to hide it.  (vectorised NHWC stores without split-K only.)
+    const bool pre = p.vec_store && p.ksplit == 1;
+    f32x4 pb[TN], pr[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+        const bool cok = pre && co + 3 < p.Cout;
+        pb[i] = (cok && p.bias) ? *(const f32x4 *)(p.bias + (long)g * p.b_gs + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = bm0 + (wm * TM + j) * 16 + l15;
+            pr[i][j] = (cok && p.res && m < p.M)
+                           ? *(const f32x4 *)(p.res + (long)g * p.r_gs + (long)m * p.res_cstride + p.res_coff + co)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     __syncthreads();
 #ifdef USOT_TRACE
     unsigned *trc = (p.ksplit == 1 && p.ws && bid0 == 0 && tid == 0) ? (unsigned *)p.ws : nullptr;
@@ -827,8 +845,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
             if (co >= p.Cout) continue;
             f32x4 v = acc[i][j];
             if (p.vec_store && co + 3 < p.Cout) {
-                if (bg) v += *(const f32x4 *)(bg + co);
-                if (rg) v += *(const f32x4 *)(rg + (long)m * p.res_cstride + p.res_coff + co);
+                v += pb[i] + pr[i][j];                      // prefetched above (zeros where absent)
                 const int a = co < p.act_split ? p.act : p.act2;
                 if (a != USOT_ACT_NONE) {
 #pragma unroll
