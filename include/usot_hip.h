@@ -228,6 +228,12 @@ int usot_plan_add_cvt_bf16(void *plan, const float *src, void *dst, int64_t n);
 int usot_plan_add_maxpool_bf16(void *plan, const void *x, void *y, int N, int H, int W, int C, int OH, int OW);
 int usot_plan_add_groupdw(void *plan, const usot_groupdw_desc *d);
 int usot_plan_add_groupdw_multi(void *plan, const usot_groupdw_desc *d, int nseg);
+/* fused fp32 stem + max-pool on the fp32 MFMA (the 125x125 stem map never reaches HBM); wfrag from
+ * usot_amd/engine.py: pack_stem_f32 */
+int usot_stem_pool_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
+                       int N, int H, int W, int OH, int OW, int PH, int PW);
+int usot_plan_add_stem_pool(void *plan, const float *x, const float *wfrag, const float *bias, float *y,
+                            int N, int H, int W, int OH, int OW, int PH, int PW);
 int usot_plan_add_stem(void *plan, const float *x, const float *w, const float *bias, float *y,
                        int N, int H, int W, int OH, int OW);
 int usot_plan_add_maxpool(void *plan, const float *x, float *y, int N, int H, int W, int C,

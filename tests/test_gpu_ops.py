@@ -496,3 +496,21 @@ def test_rows_copy_multi_gather_scatter_and_stash():
         assert torch.equal(d, want)
     # a stash pointer is meaningless for a scatter
     assert hip.lib().usot_rows_copy_multi_f32(hip.stream(), 1, pp(outs), hip.ptr(idx), pp(dsts), 4, rl, 1, hip.ptr(stash)) != 0
+
+
+@pytest.mark.parametrize('size,n', [(255, 2), (127, 1), (271, 1), (63, 3)])
+def test_stem_pool_f32(size, n):
+    """Fused fp32 MFMA stem + max-pool vs conv2d + relu + max_pool2d (fp32: accumulation order only)."""
+    from usot_amd.engine import pack_stem_f32
+    g = torch.Generator().manual_seed(size * 3 + n)
+    x = torch.rand(n, 3, size, size, generator=g) * 255
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.02
+    w = w - w.mean((1, 2, 3), keepdim=True)
+    b = torch.randn(64, generator=g) * 0.1
+    packed = w.permute(1, 2, 3, 0).reshape(147, 64).contiguous()
+    got = hip.stem_pool(x.to(DEV), pack_stem_f32(packed).to(DEV), b.to(DEV)).cpu()
+    ref = F.max_pool2d(F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=2)).float(), 3, 2, 1).permute(0, 2, 3, 1)
+    assert got.shape == ref.shape
+    assert rel_err(got.numpy(), ref.numpy()) < 2e-5
+    two = hip.maxpool3x3s2(hip.stem_conv(x.to(DEV), packed.to(DEV), b.to(DEV))).cpu()
+    assert rel_err(got.numpy(), two.numpy()) < 2e-5

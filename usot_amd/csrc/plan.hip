@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -107,6 +107,10 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
         case K_CVTB:  rc = usot_cvt_f32_to_lp(s, (const float *)op.p[0], (void *)op.p[1], op.l[0], op.i[6]); break;
         case K_POOLB:
             rc = usot_maxpool3x3s2_lp(s, op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6]);
+            break;
+        case K_STEMP:
+            rc = usot_stem_pool_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], (float *)op.p[3],
+                                    op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6]);
             break;
         case K_THIN: {
             usot_conv_desc tmp[4];
@@ -236,6 +240,16 @@ extern "C" int usot_plan_add_cvt_lp(void *plan, const float *src, void *dst, int
     Op *op = push(plan, K_CVTB);
     if (!op) return USOT_ESTATE;
     op->p[0] = src; op->p[1] = dst; op->l[0] = n; op->i[6] = dtype;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_stem_pool(void *plan, const float *x, const float *wfrag, const float *bias, float *y,
+                                       int N, int H, int W, int OH, int OW, int PH, int PW)
+{
+    Op *op = push(plan, K_STEMP);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = x; op->p[1] = wfrag; op->p[2] = bias; op->p[3] = y;
+    op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = OH; op->i[4] = OW; op->i[5] = PH; op->i[6] = PW;
     return USOT_OK;
 }
 

@@ -138,6 +138,104 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Fused fp32 stem + max-pool on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate): the tracked
+// frame never needs the 125x125x64 stem map itself, only its 3x3/s2 pooled image (modules.py:138-141).
+// k axis as in the low-precision kernel: 24 rows (ci*7 + kh; rows 21-23 zero) x 8 taps (kw 0-6 + one zero
+// tap) = 48 MFMA k-steps of 4: step s, lane quad q -> row s/2, tap (s&1)*4 + q.  Wavefront w owns channel
+// block w (16 channels) for every pixel of the tile, so its 48 A operands (filters) live in registers and a
+// B operand is one ds_read_b32 of the staged crop patch per MFMA.  A workgroup = 4x4 pooled pixels = 9x9
+// stem pixels (halo recomputed) = a 23x23 patch; stem outputs meet in LDS for the pool.
+constexpr int FP_P = 4;                              // pooled tile edge
+constexpr int FP_S = 2 * FP_P + 1;                   // 9 stem pixels per edge
+constexpr int FP_NPIX = FP_S * FP_S;                 // 81
+constexpr int FP_NBLK = (FP_NPIX + 15) / 16;         // 6 MFMA pixel blocks
+constexpr int FP_I = 2 * FP_S + 5;                   // 23 patch rows / columns
+constexpr int FP_IP = FP_I + 1;                      // padded patch row (the zero tap reads one past)
+constexpr int FP_OP = 64 + 4;                        // stem-tile LDS row pitch (floats)
+
+__global__ __launch_bounds__(256) void stem_pool_f32_kernel(
+    const float *__restrict__ x, const float *__restrict__ wfrag, const float *__restrict__ bias,
+    float *__restrict__ y, int H, int W, int OH, int OW, int PH, int PW)
+{
+    __shared__ float patch[3 * FP_I * FP_IP + 8];
+    __shared__ __attribute__((aligned(16))) float stile[FP_NBLK * 16 * FP_OP];
+    const int n = blockIdx.z;
+    const int py0 = blockIdx.y * FP_P, px0 = blockIdx.x * FP_P;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
+    const int iy0 = 2 * sy0, ix0 = 2 * sx0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, quad = lane >> 4;
+
+    float wf[48];                                    // this wave's channel block, [step][lane] in global
+#pragma unroll
+    for (int st = 0; st < 48; ++st) wf[st] = wfrag[(wave * 48 + st) * 64 + lane];
+
+    const float *xn = x + (long)n * 3 * H * W;
+    constexpr int NPL = (3 * FP_I * FP_IP + 8 + 255) / 256;
+    float pv[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int i = tid + q * 256;
+        const int ci = i / (FP_I * FP_IP), r = i - ci * FP_I * FP_IP;
+        const int py = r / FP_IP, px = r - py * FP_IP;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v = 0.f;
+        if (ci < 3 && px < FP_I && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xn[((long)ci * H + iy) * W + ix];
+        pv[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int i = tid + q * 256;
+        if (i < 3 * FP_I * FP_IP + 8) patch[i] = pv[q];
+    }
+    __syncthreads();
+
+    const f32x4 bv = *(const f32x4 *)(bias + wave * 16 + quad * 4);
+#pragma unroll 1
+    for (int blk = 0; blk < FP_NBLK; ++blk) {
+        int pi = blk * 16 + l15;
+        if (pi > FP_NPIX - 1) pi = FP_NPIX - 1;
+        const int sy = pi / FP_S, sx = pi - sy * FP_S;
+        const float *pb = patch + (2 * sy) * FP_IP + 2 * sx + quad;      // + row/tap offset of the step
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+#pragma unroll
+        for (int st = 0; st < 48; ++st) {
+            const int row = st / 2 > 20 ? 20 : st / 2;                   // zero-filter rows: any valid address
+            const int off = ((row / 7) * FP_I + row % 7) * FP_IP + (st & 1) * 4;
+            if (st & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st], pb[off], acc2, 0, 0, 0);
+            else        acc  = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st], pb[off], acc, 0, 0, 0);
+        }
+        f32x4 v = acc + acc2 + bv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        *(f32x4 *)(stile + (blk * 16 + l15) * FP_OP + wave * 16 + quad * 4) = v;
+    }
+    __syncthreads();
+
+    // 3x3 / stride 2 / pad 1 max-pool: 16 pooled pixels x 16 channel quads
+    const int pp = tid >> 4, c4 = tid & 15;
+    const int ppy = pp / FP_P, ppx = pp - ppy * FP_P;
+    const int py = py0 + ppy, px = px0 + ppx;
+    if (py >= PH || px >= PW) return;
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int ly = 2 * ppy + dy, gy = sy0 + ly;
+        if ((unsigned)gy >= (unsigned)OH) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int lx = 2 * ppx + dx, gx = sx0 + lx;
+            if ((unsigned)gx >= (unsigned)OW) continue;
+            const f32x4 v = *(const f32x4 *)(stile + (ly * FP_S + lx) * FP_OP + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+        }
+    }
+    *(f32x4 *)(y + ((((long)n * PH + py) * PW + px) * 64 + c4 * 4)) = m;
+}
+
 }  // namespace
 
 extern "C" int usot_stem_conv_f32(void *stream, const float *x, const float *w, const float *bias,
@@ -163,6 +261,22 @@ extern "C" int usot_maxpool3x3s2_f32(void *stream, const float *x, float *y,
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        x, y, N, H, W, C / 4, OH, OW);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+/* Fused fp32 stem + max-pool (frame plans: the stem map itself is not needed).  wfrag = the BN-folded
+ * filter bank as MFMA A operands [4 channel blocks][48 k-steps][64 lanes] (usot_amd/engine.py:
+ * pack_stem_f32), bias fp32[64], y NHWC [N][PH][PW][64]. */
+extern "C" int usot_stem_pool_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
+                                  int N, int H, int W, int OH, int OW, int PH, int PW)
+{
+    if (!x || !wfrag || !bias || !y || N <= 0 || N > 65535 || H < 7 || W < 7) return USOT_EINVAL;
+    if (OH != (H - 7) / 2 + 1 || OW != (W - 7) / 2 + 1) return USOT_EINVAL;
+    if (PH != (OH + 2 - 3) / 2 + 1 || PW != (OW + 2 - 3) / 2 + 1) return USOT_EINVAL;
+    if (((uintptr_t)y % 16) || ((uintptr_t)bias % 16)) return USOT_EINVAL;
+    dim3 grid(usot_cdiv(PW, FP_P), usot_cdiv(PH, FP_P), N);
+    hipLaunchKernelGGL(stem_pool_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, wfrag, bias, y, H, W, OH, OW, PH, PW);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }

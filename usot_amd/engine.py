@@ -111,6 +111,11 @@ class Weights:
     # feeds them unnormalised) and carries the exact mu term in its bias
     STEM_MU = (104.0, 117.0, 123.0)
 
+    def stem_f32(self):
+        if 'f32' not in self._stem_lp:
+            self._stem_lp['f32'] = pack_stem_f32(self.stem_w).to(self.device)
+        return self._stem_lp['f32']
+
     def stem_lp(self, dtype):
         """(filter fragments in `dtype`, fp32 bias with the folded mu term)."""
         if dtype not in self._stem_lp:
@@ -119,6 +124,17 @@ class Weights:
             bias = (self.stem_b.double().cpu() + (w * mu).sum((0, 1))).float().to(self.device)
             self._stem_lp[dtype] = (pack_stem_lp(self.stem_w, dtype).to(self.device), bias)
         return self._stem_lp[dtype]
+
+
+def pack_stem_f32(stem_w):
+    """[147][64] folded stem filters -> fp32 MFMA A operands [4 cblk][48 kstep][64 lanes] for
+    usot_stem_pool_f32: k-step s, lane (l15, quad) of channel block cb holds channel cb*16 + l15, k-row s // 2
+    (r = ci*7 + kh; rows 21..23 zero) and tap (s % 2)*4 + quad (tap 7 zero)."""
+    w = stem_w.detach().float().cpu().reshape(3, 7, 7, 64)                 # [ci][kh][kw][co]
+    rows = torch.zeros(24, 8, 64)
+    rows[:21, :7] = w.reshape(21, 7, 64)
+    frag = rows.reshape(24, 2, 4, 4, 16).permute(3, 0, 1, 2, 4)            # [cb][row][half][quad][l15]
+    return frag.reshape(4, 48, 64).contiguous()
 
 
 def pack_stem_lp(stem_w, dtype):
@@ -292,15 +308,24 @@ class Builder:
         return outs
 
     # ---- a1-a4: backbone + neck: x NCHW [n,3,s,s] -> xf NHWC [n,hf,wf,256]
-    def backbone(self, x, n, size):
+    def backbone(self, x, n, size, need_stem=True):
+        """need_stem=False (frame plans): stem + max-pool in one MFMA kernel, the stem map is never stored;
+        feature_extractor() (modules.py:137-151 returns it as x_) keeps the two-kernel form."""
         W, L = self.W, hip.lib()
         oh = (size - 7) // 2 + 1
-        s0 = self.buf(n, oh, oh, 64)
-        hip.check(L.usot_plan_add_stem(self.plan.h, hip.ptr(x), hip.ptr(W.stem_w), hip.ptr(W.stem_b), hip.ptr(s0),
-                                       n, size, size, oh, oh), 'plan_add_stem')
         ph = (oh - 1) // 2 + 1
         p0 = self.buf(n, ph, ph, 64)
-        hip.check(L.usot_plan_add_maxpool(self.plan.h, hip.ptr(s0), hip.ptr(p0), n, oh, oh, 64, ph, ph), 'plan_add_maxpool')
+        s0 = None
+        if need_stem:
+            s0 = self.buf(n, oh, oh, 64)
+            hip.check(L.usot_plan_add_stem(self.plan.h, hip.ptr(x), hip.ptr(W.stem_w), hip.ptr(W.stem_b), hip.ptr(s0),
+                                           n, size, size, oh, oh), 'plan_add_stem')
+            hip.check(L.usot_plan_add_maxpool(self.plan.h, hip.ptr(s0), hip.ptr(p0), n, oh, oh, 64, ph, ph), 'plan_add_maxpool')
+        else:
+            wf = W.stem_f32()
+            hip.check(L.usot_plan_add_stem_pool(self.plan.h, hip.ptr(x), hip.ptr(wf), hip.ptr(W.stem_b), hip.ptr(p0),
+                                                n, size, size, oh, oh, ph, ph), 'plan_add_stem_pool')
+            self.plan.keep += [wf]
         self.plan.keep += [x]
         cur, h = p0, ph
         stages = [s0]
@@ -662,7 +687,7 @@ class Engine:
                 bld.fork(2, 1)
                 mk = bld.encode_kernel(mem, b * m, 256, 'mem')
                 bld.fork(0, 1)
-            xf, hf = bld.backbone(x, b, size)
+            xf, hf = bld.backbone(x, b, size, need_stem=False)
             zk = self._zenc[b]['zk']
             bbox, cls2, S = bld.heads(xf, b, hf, zk, mem, m, mk=mk, mem_lane=2 if m else None)
             self._finish(bld.plan)
@@ -798,7 +823,7 @@ class Session:
         # already writing the next frame's control block
         self.slot_dev = torch.zeros(4, dtype=torch.int32, device=e.device)
         self._rows_multi(pl, self.bank_enc, idx_dev, mk, 7, scatter=0, stash=self.slot_dev)
-        xf, hf = bld.backbone(self.x, 1, self.size)
+        xf, hf = bld.backbone(self.x, 1, self.size, need_stem=False)
         bbox, cls2, S = bld.heads(xf, 1, hf, self.zk, self.mem_in, 7, mk=mk, mem_lane=2)
         assert S == self.S
         self.roi = bld.buf(5)

@@ -26,7 +26,7 @@ EXPORTS = (
     'usot_plan_add_conv_bf16', 'usot_plan_add_cvt_bf16', 'usot_plan_add_maxpool_bf16',
     'usot_conv2d_lp', 'usot_cvt_f32_to_lp', 'usot_maxpool3x3s2_lp', 'usot_plan_add_conv_lp', 'usot_plan_add_cvt_lp',
     'usot_plan_add_maxpool_lp', 'usot_stem_pool_lp', 'usot_plan_add_stem_pool_lp',
-    'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv',
+    'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
 )
 
@@ -91,6 +91,8 @@ def lib():
         L.usot_plan_add_rows_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int] * 3
         L.usot_rows_copy_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
         L.usot_thin_conv3x3_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.usot_stem_pool_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7
+        L.usot_plan_add_stem_pool.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7
         L.usot_plan_add_thin_conv.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_rows_copy_multi_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.usot_plan_add_rows_copy_multi.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -220,6 +222,18 @@ def stem_conv(x, w, bias):
     OH, OW = (H - 7) // 2 + 1, (W_ - 7) // 2 + 1
     y = torch.empty((N, OH, OW, 64), device=x.device, dtype=torch.float32)
     check(lib().usot_stem_conv_f32(stream(), ptr(x), ptr(w), ptr(bias), ptr(y), N, H, W_, OH, OW), 'usot_stem_conv_f32')
+    return y
+
+
+def stem_pool(x, wfrag, bias):
+    """Fused fp32 stem + max-pool: x NCHW fp32 -> NHWC [N][PH][PW][64]; wfrag from engine.pack_stem_f32."""
+    _dev(x), _dev(wfrag), _dev(bias)
+    N, c, H, W_ = x.shape
+    assert c == 3 and x.is_contiguous()
+    OH, OW = (H - 7) // 2 + 1, (W_ - 7) // 2 + 1
+    PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    y = torch.empty((N, PH, PW, 64), device=x.device, dtype=torch.float32)
+    check(lib().usot_stem_pool_f32(stream(), ptr(x), ptr(wfrag), ptr(bias), ptr(y), N, H, W_, OH, OW, PH, PW), 'usot_stem_pool_f32')
     return y
 
 
