@@ -870,8 +870,11 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
 }
 
 // split-K second pass: sum the partial slabs, then the same epilogue.
-__global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvK p)
+__global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvBatch bt)
 {
+    // blockIdx.y = problem of the batched launch (problems that were not split have no work here)
+    const ConvK &p = bt.p[blockIdx.y];
+    if (p.ksplit <= 1) return;
     const long per_g = (long)p.M * p.Cout;
     const long total = per_g * p.groups;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1108,14 +1111,16 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(tc.fn, dim3((unsigned)blocks), dim3(tc.threads), lds, s, bt);
     if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
-    for (int i = 0; i < n; ++i) {
-        const ConvK &p = bt.p[i];
-        if (p.ksplit > 1) {
-            const long total = (long)p.M * p.Cout * p.groups;
-            const int gb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-            hipLaunchKernelGGL(conv_splitk_epilogue, dim3(gb), dim3(256), 0, s, p);
-            if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
+    long most = 0;                                // ONE reduction launch for every split problem of the batch
+    for (int i = 0; i < n; ++i)
+        if (bt.p[i].ksplit > 1) {
+            const long total = (long)bt.p[i].M * bt.p[i].Cout * bt.p[i].groups;
+            if (total > most) most = total;
         }
+    if (most > 0) {
+        const int gb = (int)((most + 255) / 256 > 4096 ? 4096 : (most + 255) / 256);
+        hipLaunchKernelGGL(conv_splitk_epilogue, dim3(gb, n), dim3(256), 0, s, bt);
+        if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
     }
     return USOT_OK;
 }
