@@ -478,6 +478,9 @@ const TileB kTilesB[] = {
     TB08(128, 256, 2, 4), // 20
     TB08(256, 256, 4, 4), // 21: 16 wavefronts x (64 x 64)
     TB08(256, 256, 4, 2), // 22: 8 wavefronts x (64 pixels x 128 channels)
+    TB08(256, 128, 4, 4), // 23: 16 wavefronts x (64 x 32)
+    TB08(128, 256, 2, 8), // 24: 16 wavefronts x (64 x 32)
+    TB08(128, 128, 4, 4), // 25: 16 wavefronts x (32 x 32)
 };
 constexpr int kNumTilesB = sizeof(kTilesB) / sizeof(kTilesB[0]);
 
