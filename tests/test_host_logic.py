@@ -191,3 +191,39 @@ def test_poly_iou_and_rect_helpers():
     assert cxy_wh_2_rect(np.array([10.0, 8.0]), np.array([4.0, 6.0])) == [8.0, 5.0, 4.0, 6.0]
     cx, cy, w, h = get_axis_aligned_bbox(np.array([2.0, 3.0, 10.0, 20.0]))
     assert (cx, cy, w, h) == (7.0, 13.0, 10.0, 20.0)
+
+
+def test_stem_fragment_packing_is_a_plain_convolution():
+    """engine.pack_stem_f32 / pack_stem_lp lay the 7x7x3 stem filters out as MFMA A operands over a padded
+    k axis (24 rows x 8 taps).  Summing fragment x patch element exactly as the kernels index them must give
+    the ordinary stride-2 convolution (host-only check of the layout contract with csrc/stem_pool.hip and
+    csrc/conv_bf16.hip)."""
+    import torch
+    import torch.nn.functional as F
+    from usot_amd.engine import pack_stem_f32, pack_stem_lp
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(64, 3, 7, 7, generator=g)
+    x = torch.randn(1, 3, 11, 13, generator=g)
+    packed = w.permute(1, 2, 3, 0).reshape(147, 64).contiguous()          # Weights.stem_w layout
+    ref = F.conv2d(x, w, stride=2)[0]                                     # [64, 3, 4]
+    xp = F.pad(x[0], (0, 8))                                              # the zero tap reads one column past
+    f32 = pack_stem_f32(packed)                                           # [4][48][64]
+    lp = pack_stem_lp(packed, torch.float32)                              # [4][6][64][8]
+    for (sy, sx) in ((0, 0), (2, 3), (1, 2)):
+        for co in (0, 17, 63):
+            cb, l15 = divmod(co, 16)
+            acc = 0.0
+            for st in range(48):                                          # fp32 MFMA: step st, quad q -> row st//2, tap (st%2)*4+q
+                row = min(st // 2, 20)
+                ci, kh = divmod(row, 7)
+                for q in range(4):
+                    acc += float(f32[cb, st, q * 16 + l15]) * float(xp[ci, 2 * sy + kh, 2 * sx + (st % 2) * 4 + q])
+            assert abs(acc - float(ref[co, sy, sx])) < 1e-4 * max(1.0, abs(float(ref[co, sy, sx])))
+            acc = 0.0
+            for ks in range(6):                                           # 16x16x32 MFMA: step ks, quad q -> row 4*ks+q, 8 taps
+                for q in range(4):
+                    row = min(4 * ks + q, 20)
+                    ci, kh = divmod(row, 7)
+                    for t8 in range(8):
+                        acc += float(lp[cb, ks, q * 16 + l15, t8]) * float(xp[ci, 2 * sy + kh, 2 * sx + t8])
+            assert abs(acc - float(ref[co, sy, sx])) < 1e-4 * max(1.0, abs(float(ref[co, sy, sx])))
