@@ -150,7 +150,7 @@ def video_loop(model, device, frames=200):
     class Info:
         arch = 'USOT'
     trk = USOTTracker(Info())
-    ims = [synth.frame(77, t=t)[0] for t in range(16)]
+    ims = [np.ascontiguousarray(synth.frame(77, t=t)[0]) for t in range(16)]      # dense HWC uint8, as cv2.imread returns
     im0, (cx, cy) = synth.frame(77, t=0)
     state = trk.init(im0, np.array([cx, cy]), np.array([52.0, 38.0]), model)
     for i in range(10):
