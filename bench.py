@@ -17,7 +17,10 @@ convolution, per-launch time from HIP events on the launching stream) and `cpu_b
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -60,6 +63,7 @@ def open_stream(model, device, seed, size=255):
     feats = [model.extract_memory_feature(ori_x=crops[0:1], search_bbox=roi),
              model.extract_memory_feature(ori_x=crops[0:1].flip(3), search_bbox=roi)]
     window = np.outer(np.hanning(p.score_size), np.hanning(p.score_size))
+    model.engine.session_capacity = 16384     # bank rows: the timed region must not regrow (and re-capture) the session
     return model.engine.open_session(p, window, feats), crops, p
 
 
@@ -84,7 +88,7 @@ def run_frames_multi(group, n):
 
 def roofline(sess, frames):
     """Dominant kernel = the conv_igemm_f32 tile instance with the largest total time."""
-    prof = sess.plan.profile(frames=frames, reps=2)
+    prof = sess.plan.profile(frames=frames, reps=1)      # every op once per pass, in frame order (cold operands, as in a replay)
     tiles = hip.tile_table()
     convs = iter(sess.log)
     agg, total_ms, conv_ms, conv_flops = {}, 0.0, 0.0, 0.0
@@ -101,15 +105,22 @@ def roofline(sess, frames):
         conv_flops += 2.0 * macs
     tile, (n, ms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
     ach = fl / (ms * 1e-3) / 1e12
-    traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes (if this kernel was profiled)
+    # HBM bytes per launch cannot be counted from inside this process: they come from the committed
+    # rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by scripts/pmc_to_traffic.py with the
+    # source commit recorded); a kernel that was not profiled there reports null, never a stale number.
+    traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
-            traffic = json.load(f).get(hip.tile_name(tile), {}).get('hbm_bytes_per_launch')
+            pmc = json.load(f)
+        traffic = pmc.get(hip.tile_name(tile), {}).get('hbm_bytes_per_launch')
+        if traffic is not None:
+            traffic_src = 'profiles/pmc_traffic.json@%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)' \
+                          % pmc.get('_meta', {}).get('commit', 'round1')
     except Exception:
         pass
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
+        'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
         'kernel': hip.tile_name(tile), 'launches_per_frame': n,
         'avg_launch_us': round(ms / n * 1e3, 2), 'algorithmic_gflop_per_frame': round(fl / 1e9, 3),
         'all_convs': {'gflop_per_frame': round(conv_flops / 1e9, 3), 'us_per_frame': round(conv_ms * 1e3, 1),
@@ -138,7 +149,7 @@ def xcorr_bandwidth(device, samples=128, iters=20):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     gbps = samples * GROUPDW_BYTES_PER_SAMPLE / (ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': 'groupdw_nhwc_kernel', 'samples': samples, 'ms': round(ms, 4),
+    return {'bound': 'hbm', 'kernel': hip.groupdw_variant_name(samples), 'samples': samples, 'ms': round(ms, 4),
             'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}
 
 
@@ -205,77 +216,138 @@ def cpu_baseline(budget_s=12.0):
             if dt > budget_s or n >= 200:
                 break
     return {'value': round(n / dt, 3), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d frames of the same workload (1 crop 255x255, N_q=7, fp32) in %.1f s, torch-CPU oracle' % (n, dt)}
+            'sample': '%d frames of the same workload (1 crop 255x255, N_q=7, fp32) in %.1f s: the torch-CPU oracle '
+                      'restatement under no_grad with the duplicate search-side encodes of connect.py:251-264 computed '
+                      'once (the reference runs them three times), i.e. a faster CPU path than the literal reference' % (n, dt)}
 
 
 BF16_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF is 2:1 sparse)
 BACKBONE_GFLOP = 28.192642        # one 255^2 crop through stem..layer3
 
 
-def backbone_bf16(a, device):
-    """BASELINE configs[2]: batch-64 bf16 backbone (+neck), the MFMA-roofline run.  Separate
-    workload, separate JSON line; the default invocation stays configs[1]."""
-    model, _ = build_model(0, 1, device)
-    e = model.engine
-    x = torch.from_numpy(synth.crop(3000, a.batch, a.size)).to(device)
-    for _ in range(max(2, a.warmup)):
-        e.features_bf16(x)
-    p = e._feat[('bf16', a.batch, a.size)]
+def _timed(run, min_seconds, steps=0):
+    """Run `run()` at least `steps` times and for at least `min_seconds`; returns (n, seconds)."""
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        p['plan'].run()
+    run()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    est = max(time.perf_counter() - t0, 1e-6)
+    n = max(int(steps), int(math.ceil(min_seconds / est)), 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run()
+    torch.cuda.synchronize()
+    return n, time.perf_counter() - t0
+
+
+def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, min_seconds=1.0, top=5):
+    """BASELINE configs[2]: batch-64 bf16 backbone (+neck) on v_mfma_f32_16x16x32_bf16, the MFMA-roofline
+    run.  Whole-graph replay for crops/s; per-conv HIP-event times (plan.profile, each op once per
+    pass in graph order) for TFLOP/s over the convolutions."""
+    e = model.engine
+    x = torch.from_numpy(synth.crop(3000, batch, size)).to(device)
+    for _ in range(max(2, warmup)):
+        e.features_bf16(x)
+    p = e._feat[('bf16', batch, size)]
+    n, dt = _timed(p['plan'].run, min_seconds, steps)
     prof = p['plan'].profile(frames=3, reps=1)
     convs = iter(p['log'])
-    ms_conv = fl_conv = 0.0
+    ms_conv = fl_conv = ms_all = 0.0
     rows = []
     for kind, tile, ks, groups, ms in prof:
+        ms_all += ms
         if kind == 11:                                   # K_CONVB
             name, M, N, K, g, macs = next(convs)
             ms_conv += ms
             fl_conv += 2.0 * macs
             rows.append((ms, name, M, N, K, 2.0 * macs / ms / 1e9))
-    top = sorted(rows, reverse=True)[:5]
     ach = fl_conv / (ms_conv * 1e-3) / 1e12
+    return {
+        'workload': 'configs[2]: batch=%d search crops %dx%d bf16, backbone + neck convs on v_mfma_f32_16x16x32_bf16, '
+                    'fp32 accumulate, one hipGraph' % (batch, size, size),
+        'value': round(batch * n / dt, 1), 'unit': 'crops/s', 'steps': n, 'ms_per_step': round(dt / n * 1e3, 3),
+        'roofline': {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(ach / BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                     'kernel': 'conv_igemm_bf16 family (all %d conv launches)' % len(rows),
+                     'algorithmic_gflop_per_step': round(fl_conv / 1e9, 1), 'conv_ms_per_step': round(ms_conv, 3),
+                     'all_ops_ms_per_step': round(ms_all, 3),
+                     'end_to_end_tflops': round(batch * (BACKBONE_GFLOP + 0.504) * n / dt / 1e3, 1),
+                     'slowest': [{'op': nm, 'M': M, 'N': N, 'K': K, 'ms': round(ms, 3), 'tflops': round(tf, 1)}
+                                 for ms, nm, M, N, K, tf in sorted(rows, reverse=True)[:top]]},
+    }
+
+
+def backbone_bf16(a, device):
+    """`--workload backbone_bf16`: configs[2] as its own JSON line."""
+    model, _ = build_model(0, 1, device)
+    r = measure_backbone_bf16(model, device, a.batch, a.size, a.steps, a.warmup, a.min_seconds)
     line = {
         'metric': 'backbone crops/s (255x255, ResNet-50 layer3 + neck, bf16, batch %d)' % a.batch,
-        'value': round(a.batch * a.steps / dt, 1), 'unit': 'crops/s', 'n_gpus': 1, 'steps': a.steps, 'warmup': a.warmup,
-        'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'value': r['value'], 'unit': 'crops/s', 'n_gpus': 1, 'steps': r['steps'], 'warmup': a.warmup,
+        'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'configs[2]: batch=%d search crops bf16, backbone + neck convs on '
-                               'v_mfma_f32_16x16x32_bf16, fp32 accumulate' % a.batch, 'search': a.size, 'hipgraph': True},
-        'roofline': {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(ach / BF16_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': 'conv_igemm_bf16 (all 45 launches)',
-                     'algorithmic_gflop_per_step': round(fl_conv / 1e9, 1), 'conv_ms_per_step': round(ms_conv, 3),
-                     'end_to_end_tflops': round(a.batch * (BACKBONE_GFLOP + 0.504) * a.steps / dt / 1e3, 1),
-                     'slowest': [{'op': n, 'M': M, 'N': N, 'K': K, 'ms': round(ms, 3), 'tflops': round(tf, 1)}
-                                 for ms, n, M, N, K, tf in top]},
+        'config': {'workload': r['workload'], 'search': a.size, 'hipgraph': True},
+        'roofline': r['roofline'],
     }
     print(json.dumps(line))
 
 
-def track_mixed(a, rank, world, device):
-    """BASELINE configs[4]: fp16 backbone + fp32 xcorr/heads, `--batch` independent streams per GPU
-    (32 per GPU = 256 on 8 GPUs), N_q = 7.  One step = one batched frame on every rank."""
-    model, wbytes = build_model(rank, world, device)
+def measure_track_mixed(model, device, batch=32, size=255, lp='fp16', heads_f32=False, seed=0, steps=0, warmup=2,
+                        min_seconds=1.0):
+    """BASELINE configs[4], one GPU's share: `batch` independent streams in lock step, low-precision
+    backbone (+ big head convs), fp32 depthwise xcorr / reduce / predictions, N_q = 7.  Returns
+    (plan dict, frames/s fields) — the caller owns barriers for the multi-GPU form."""
     e = model.engine
-    b = a.batch
     t = lambda arr: torch.from_numpy(arr).to(device)
+    pr = model.pr_pool
     model.pr_pool = False
-    model.template(t(synth.crop(5000 + rank, b, 127)))
-    x = t(synth.crop(6000 + rank, b, a.size))
-    mem = t(synth.memory_kernels(7000 + rank, 7 * b))
-    sm = torch.ones(b, 7, device=device)
-    dt_ = torch.float16 if a.lp == 'fp16' else torch.bfloat16
-    for _ in range(max(2, a.warmup)):
-        e.track_mixed(x, model.zf, mem, sm, dtype=dt_, heads_lp=not a.heads_f32)
-    p = e._track[('mixed', b, a.size, 7, dt_, not a.heads_f32)]
+    model.template(t(synth.crop(5000 + seed, batch, 127)))
+    model.pr_pool = pr
+    x = t(synth.crop(6000 + seed, batch, size))
+    mem = t(synth.memory_kernels(7000 + seed, 7 * batch))
+    sm = torch.ones(batch, 7, device=device)
+    dt_ = torch.float16 if lp == 'fp16' else torch.bfloat16
+    for _ in range(max(2, warmup)):
+        e.track_mixed(x, model.zf, mem, sm, dtype=dt_, heads_lp=not heads_f32)
+    return e._track[('mixed', batch, size, 7, dt_, not heads_f32)]
+
+
+def measure_lockstep_f32(model, device, batch=4, size=255, steps=0, min_seconds=1.0):
+    """fp32 lock-step throughput mode: `batch` independent streams batched into ONE fp32 plan (same
+    kernels and the same 1e-4 parity as configs[1]; M = batch x 961 pixels fills the chip where one
+    stream cannot), N_q = 7."""
+    e = model.engine
+    t = lambda arr: torch.from_numpy(arr).to(device)
+    pr = model.pr_pool
+    model.pr_pool = False
+    model.template(t(synth.crop(5100, batch, 127)))
+    model.pr_pool = pr
+    x = t(synth.crop(6100, batch, size))
+    mem = t(synth.memory_kernels(7100, 7 * batch))
+    sm = torch.ones(batch, 7, device=device)
+    for _ in range(2):
+        e.track(x, model.zf, template_mem=mem, score_mem=sm)
+    p = e._track[(batch, size, 7)]
+    n, dt = _timed(p['plan'].run, min_seconds, steps)
+    return {'workload': 'fp32 lock-step: %d streams in one fp32 plan (backbone + heads, N_q=7), hipGraph replay, inputs '
+                        'resident' % batch,
+            'value': round(batch * n / dt, 1), 'unit': 'frames/s', 'batch': batch, 'steps': n,
+            'ms_per_step': round(dt / n * 1e3, 4), 'dtype': 'f32'}
+
+
+def track_mixed(a, rank, world, device):
+    """`--workload track_mixed`: BASELINE configs[4] as its own JSON line (fp16 backbone + fp32 xcorr,
+    `--batch` independent streams per GPU: 32 per GPU = 256 on 8 GPUs).  One step = one batched frame
+    on every rank."""
+    model, wbytes = build_model(rank, world, device)
+    b = a.batch
+    p = measure_track_mixed(model, device, b, a.size, a.lp, a.heads_f32, seed=rank, warmup=a.warmup)
+    steps = agree_steps(p['plan'].run, a.steps, a.min_seconds, device)
     streams.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         p['plan'].run()
     torch.cuda.synchronize()
     streams.barrier()
@@ -284,13 +356,44 @@ def track_mixed(a, rank, world, device):
         print(json.dumps({
             'metric': 'tracker FPS (255x255 search, ResNet-50), %s backbone%s + fp32 xcorr, batch %d per GPU'
                       % (a.lp, '' if a.heads_f32 else ' and head convs', b),
-            'value': round(world * b * a.steps / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps,
-            'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': a.lp + '+f32', 'data': 'synthetic',
+            'value': round(world * b * steps / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': steps,
+            'steps_requested': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.lp + '+f32', 'data': 'synthetic',
             'config': {'workload': 'configs[4]: %s backbone + fp32 xcorr mixed precision, batch=%d per GPU x %d GPUs, N_q=7'
                                    % (a.lp, b, world), 'search': a.size, 'hipgraph': True,
+                       'weights': 'synthetic seed 0 (calibrated BN), %s broadcast %d B' % (streams.backend_name(), wbytes),
                        'head_convs': 'f32' if a.heads_f32 else a.lp + ' (encoders, conf/value, towers); preds, memory-kernel encoders, GroupDW, reduce f32'}}))
     streams.barrier()
+
+
+def agree_steps(run, steps, min_seconds, device, probe=5):
+    """Number of timed steps: the requested K, raised so that the timed region lasts at least
+    `min_seconds` (a 20-step window of a 0.9 ms frame is 18 ms: nothing can be sampled in it).  The
+    estimate is the max over ranks, so every rank times the same number of steps."""
+    if min_seconds <= 0:
+        return int(steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(probe):
+        run()
+    torch.cuda.synchronize()
+    est = streams.max_over_ranks((time.perf_counter() - t0) / probe, device=device)
+    return max(int(steps), int(math.ceil(min_seconds / max(est, 1e-6))))
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (one process per GPU,
+    RCCL through torch.distributed) and pass rank 0's JSON line through.  The reference fans out with
+    mpiexec (scripts/test_epochs_usot.py:19-49)."""
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -299,7 +402,10 @@ def main():
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--size', type=int, default=255)
+    ap.add_argument('--min-seconds', type=float, default=2.0,
+                    help='the timed region lasts at least this long: steps = max(--steps, ceil(min_seconds / step time)); 0 = exactly --steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the configs[2]/[4]/lock-step sub-objects of the default line')
     ap.add_argument('--no-xcorr', action='store_true')
     ap.add_argument('--workload', default='track', choices=['track', 'backbone_bf16', 'track_mixed'])
     ap.add_argument('--lp', default='fp16', choices=['fp16', 'bf16'])
@@ -309,16 +415,22 @@ def main():
                     help='independent videos per GPU on separate HIP streams (default 1 = BASELINE configs[1])')
     a = ap.parse_args()
 
-    rank, local, world = streams.init()
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit('--gpus %d needs: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
-                             '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (a.gpus, a.gpus, a.gpus))
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(a)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
-    torch.set_num_threads(host_threads())        # the box shows 256 hardware threads under a 16-CPU quota
-    device = torch.device('cuda', local)
+    ndev = torch.cuda.device_count()
+    rank, local, world = streams.env_world()
+    if world != a.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    # one rank per GPU; when fewer GPUs are visible than ranks (a 1-GPU box running the N-rank path as a
+    # functional test) ranks share devices and the weight broadcast falls back to gloo — RCCL refuses two
+    # ranks on one device
+    oversub = world > ndev
+    device = torch.device('cuda', local % ndev)
     torch.cuda.set_device(device)
+    streams.init(backend='gloo' if oversub else None, device_index=device.index)
+    torch.set_num_threads(host_threads())        # the box shows 256 hardware threads under a 16-CPU quota
     if a.workload == 'backbone_bf16':
         if rank == 0:
             backbone_bf16(a, device)
@@ -336,31 +448,45 @@ def main():
     sess, crops, p, conf, _ = group[0]
     go = (lambda n: run_frames(sess, crops, p, conf, n)) if S == 1 else (lambda n: run_frames_multi(group, n))
     go(a.warmup)
+    steps = agree_steps(lambda: go(1), a.steps, a.min_seconds, device)
 
     streams.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    go(a.steps)
+    go(steps)
     torch.cuda.synchronize()
     streams.barrier()
     dt = streams.max_over_ranks(time.perf_counter() - t0, device=device)
 
     if rank == 0:
-        fps = world * S * a.steps / dt
+        fps = world * S * steps / dt
         line = {
             'metric': 'tracker FPS (255x255 search, ResNet-50)', 'value': round(fps, 2), 'unit': 'frames/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 4),
+            'n_gpus': world, 'steps': steps, 'steps_requested': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: batch=1 ResNet-50(layer3)+neck, fused depthwise xcorr, cls/reg/'
                                    'memory heads (N_q=7), decode + PrRoIPool, fp32, 1 stream per GPU',
                        'search': a.size, 'template': 127, 'streams': world * S, 'streams_per_gpu': S, 'weights': 'synthetic seed 0 '
-                       '(calibrated BN), RCCL broadcast %d B' % wbytes, 'hipgraph': True},
+                       '(calibrated BN), %s broadcast %d B' % (streams.backend_name(), wbytes), 'hipgraph': True,
+                       'devices_visible': ndev},
         }
         line['roofline'] = roofline(sess, frames=10)
         if not a.no_xcorr:
             line['xcorr_hbm'] = xcorr_bandwidth(device)
         if world == 1:
             line['video_loop_pcie_inclusive'] = video_loop(model, device)
+        if world == 1 and not a.no_extras:
+            # the two low-precision north-star configurations and the fp32 lock-step mode, measured by the
+            # same process (each a few seconds; their own full lines: --workload backbone_bf16 / track_mixed)
+            line['backbone_bf16_b64'] = measure_backbone_bf16(model, device, 64, a.size)
+            pm = measure_track_mixed(model, device, 32, a.size)
+            n, t = _timed(pm['plan'].run, 1.0)
+            line['track_mixed_b32'] = {
+                'workload': 'configs[4], one GPU: fp16 backbone + head convs, fp32 xcorr / reduce / predictions, 32 streams in '
+                            'lock step, N_q=7, one hipGraph', 'value': round(32 * n / t, 1), 'unit': 'frames/s',
+                'steps': n, 'ms_per_step': round(t / n * 1e3, 3), 'dtype': 'fp16+f32'}
+            line['lockstep_f32_b4'] = measure_lockstep_f32(model, device, 4, a.size)
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line))

@@ -142,6 +142,9 @@ typedef struct usot_groupdw_desc {
                                   * 3: LDS row streaming; 4: ring (taps in LDS, rows streamed once) */
 } usot_groupdw_desc;
 int usot_groupdw_f32(void *stream, const usot_groupdw_desc *d);
+/* the cols_per_thread code the launcher resolves 0 (auto) to for this many samples (benchmarks name
+ * the kernel they time with it) */
+int usot_groupdw_auto_variant(int total_samples, int OW);
 /* up to three segments of identical geometry (the cls, reg and memory GroupDWs of a frame)
  * in ONE launch */
 int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, int nseg);
@@ -162,6 +165,19 @@ int usot_prroi_pool_forward_f32(void *stream, const float *feat, const float *ro
                                 int R, int C, int H, int W, int PH, int PW, float scale,
                                 int64_t f_sb, int64_t f_sc, int64_t f_sh, int64_t f_sw,
                                 int64_t o_sr, int64_t o_sc, int64_t o_sh, int64_t o_sw);
+
+/* ---- the reference's native symbol, with the reference's signature
+ * (lib/models/prroi_pool/src/prroi_pooling_gpu_impl.cuh:20-28; launcher .cu:387-402): contiguous
+ * NCHW float32 features, rois [R][5], contiguous [R][C][PH][PW] output, top_count = R*C*PH*PW,
+ * enqueued on `stream`.  prroi_pooling_gpu.c:22-44 links against it unchanged.
+ * A shim over usot_prroi_pool_forward_f32; on a bad argument or a failed launch it prints one line
+ * to stderr and returns — it does not exit(-1) as the reference's launcher does
+ * (prroi_pooling_gpu_impl.cu:20-27).                                                          */
+typedef struct ihipStream_t *hipStream_t;      /* identical to <hip/hip_runtime_api.h>'s typedef */
+void PrRoIPoolingForwardGpu(hipStream_t stream, const float *bottom_data, const float *bottom_rois,
+                            float *top_data, const int channels_, const int height_, const int width_,
+                            const int pooled_height_, const int pooled_width_,
+                            const float spatial_scale_, const int top_count);
 
 /* ---- layout changes at the API edge: generic 4-D strided copy ----------------------
  * dst[n][a][b][c] (dense) = src[n*s0 + a*s1 + b*s2 + c*s3]                              */

@@ -20,7 +20,7 @@ def libpath():
 def declared_symbols():
     with open(os.path.join(ROOT, 'include', 'usot_hip.h')) as f:
         text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
-    return sorted(set(re.findall(r'\b(usot_[a-z0-9_]+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(usot_[a-z0-9_]+|PrRoIPooling[A-Za-z]+)\s*\(', text)))
 
 
 def test_library_exports_every_declared_symbol(libpath):
@@ -30,6 +30,7 @@ def test_library_exports_every_declared_symbol(libpath):
     for s in syms:
         assert hasattr(L, s), s
     assert set(hip.EXPORTS) <= set(syms)
+    assert 'PrRoIPoolingForwardGpu' in syms     # the reference's own native symbol (prroi_pooling_gpu_impl.cuh:20-28)
     L.usot_abi_version.restype = ctypes.c_int
     assert L.usot_abi_version() == 1
     L.usot_strerror.restype = ctypes.c_char_p

@@ -2,6 +2,8 @@
 oracle/prroi_pool_ref.c) on seeded inputs.  Tolerances are scaled-relative:
 |got-ref| / max(|ref|, mean|ref|) — fp32 MFMA is an exact fmaf chain, so the only
 difference to the oracle is summation order (K up to 4608)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -41,9 +43,24 @@ CONV_CASES = [
 ]
 
 
+def _all_tiles():
+    """0 (heuristic) and every tile id of the library's table — the shipped tuning table
+    (usot_amd/data/tuning_gfx950.json) may name any of them."""
+    import ctypes
+    from usot_amd import build
+    n = ctypes.CDLL(build.LIB).usot_conv_tile_count() if os.path.exists(build.LIB) else 60
+    return list(range(0, n + 1))
+
+
+def _tuned_ksplits():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(hip.__file__)), 'data', 'tuning_gfx950.json')) as f:
+        ks = sorted({int(v[1]) for v in json.load(f).values() if int(v[1]) > 1})
+    return sorted(set(ks) | {2, 3, 9})
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
-@pytest.mark.parametrize('tile', [0, 4, 7, 8, 11, 12, 13, 15, 16, 19, 20, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36,
-                                  38, 41, 47, 53, 54, 55, 56, 57, 58, 59, 60])
+@pytest.mark.parametrize('tile', _all_tiles())
 def test_conv_igemm(case, tile):
     N, Cin, H, W, Cout, k, stride, pad, dil = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
@@ -64,7 +81,7 @@ def test_conv_igemm(case, tile):
     assert rel_err(y.cpu().numpy(), ref.numpy()) < 2e-5
 
 
-@pytest.mark.parametrize('ksplit', [2, 3, 9])
+@pytest.mark.parametrize('ksplit', _tuned_ksplits())
 def test_conv_splitk(ksplit):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(1, 256, 25, 25, generator=g)
@@ -188,6 +205,99 @@ def test_prroi_pool_vs_c_oracle(layout):
     assert np.all(got[3] == 0) and np.all(got[6] == 0)        # zero-width roi, fully outside roi
     empty = hip.prroi_pool(fd, torch.zeros(0, 5, device=DEV), 7, 7, 1.0)
     assert tuple(empty.shape) == (0, 256, 7, 7)
+
+
+def _prroi_tol(rois, ph=7, pw=7):
+    rois = np.asarray(rois, np.float64)
+    b = np.minimum((rois[:, 3] - rois[:, 1]) / pw, (rois[:, 4] - rois[:, 2]) / ph)
+    return 2e-5 + 1e-6 / np.maximum(b, 1e-9)          # see tests/test_oracle_prpool_exact.py::tol
+
+
+@pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
+def test_prroi_pool_vs_independent_float64_oracle(layout):
+    """240 + 120 random RoIs (non-aligned, hanging over every edge, sub-pixel, oversized, degenerate)
+    against oracle/prroi_exact.py — written from the operator's definition (separable hat-function
+    integrals), sharing no formula with the kernel or with prroi_pool_ref.c."""
+    import prroi_exact as ex
+    from prroi_cases import random_rois
+    for seed, (B, C, H, W), n in ((5, (2, 64, 15, 17), 240), (6, (1, 64, 31, 31), 120)):
+        g = torch.Generator().manual_seed(seed)
+        f = torch.randn(B, C, H, W, generator=g)
+        rois = random_rois(seed, n, B, H, W)
+        want = ex.prroi_pool_exact(f.numpy(), rois, 7, 7)
+        fd = f.to(DEV)
+        if layout == 'nhwc':
+            fd = fd.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        got = hip.prroi_pool(fd, torch.from_numpy(rois).to(DEV), 7, 7, 1.0, out_nhwc=(layout == 'nhwc')).cpu().numpy()
+        err = np.abs(got - want).reshape(n, -1).max(1) / max(1.0, float(f.abs().max()))
+        bad = err > _prroi_tol(rois)
+        assert not bad.any(), (rois[bad], err[bad])
+        # and the two float32 implementations (kernel, restated launcher) stay within a few ulp of each other
+        ref = orc.prroi_pool(f, torch.from_numpy(rois), 7, 7, 1.0).numpy()
+        assert np.max(np.abs(got - ref)) < 4e-6 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_prroi_reference_symbol_exact_signature():
+    """PrRoIPoolingForwardGpu(stream, bottom_data, bottom_rois, top_data, C, H, W, PH, PW, scale,
+    top_count) — the reference's own extern "C" symbol (prroi_pooling_gpu_impl.cuh:20-28) as a
+    binding compiled from prroi_pooling_gpu.c:22-44 would call it."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(78)
+    f = torch.randn(2, 48, 15, 17, generator=g)
+    rois = torch.tensor(ROIS, dtype=torch.float32)
+    ref = orc.prroi_pool(f, rois, 7, 7, 1.0)
+    fd, rd = f.to(DEV), rois.to(DEV)
+    out = torch.zeros(len(ROIS), 48, 7, 7, device=DEV)                     # at::zeros in the binding
+    L = hip.lib()
+    L.PrRoIPoolingForwardGpu(hip.stream(), hip.ptr(fd), hip.ptr(rd), hip.ptr(out), 48, 15, 17, 7, 7,
+                             C.c_float(1.0), out.numel())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.max(np.abs(got - ref.numpy())) < 2e-6 * max(1.0, float(ref.abs().max()))
+    # spatial_scale is applied to the roi, pooled size is free
+    out2 = torch.zeros(len(ROIS), 48, 3, 5, device=DEV)
+    L.PrRoIPoolingForwardGpu(hip.stream(), hip.ptr(fd), hip.ptr(rd), hip.ptr(out2), 48, 15, 17, 3, 5,
+                             C.c_float(0.5), out2.numel())
+    ref2 = orc.prroi_pool(f, rois, 3, 5, 0.5)
+    assert np.max(np.abs(out2.cpu().numpy() - ref2.numpy())) < 2e-6 * max(1.0, float(ref2.abs().max()))
+    # a top_count that is not a whole number of RoIs is refused (stderr line, no launch, no exit)
+    out3 = torch.full((3, 48, 7, 7), 7.0, device=DEV)
+    L.PrRoIPoolingForwardGpu(hip.stream(), hip.ptr(fd), hip.ptr(rd), hip.ptr(out3), 48, 15, 17, 7, 7,
+                             C.c_float(1.0), out3.numel() - 1)
+    torch.cuda.synchronize()
+    assert float(out3.min()) == 7.0
+
+
+def test_decode_nan_follows_numpy_argmax():
+    """np.argmax (usot_tracker.py:163) returns the FIRST NaN when the penalised score holds any,
+    else the first maximum; the kernel must do the same and never index with a sentinel
+    (round-1 advisor finding: every pscore NaN -> read far out of bounds)."""
+    p = orc.Hyper(255)
+    S = p.score_size
+    n = S * S
+    window = torch.from_numpy(np.outer(np.hanning(S), np.hanning(S))).reshape(-1).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    cls, cm = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    bbox = torch.rand(4, n, generator=g) * 40 + 5
+    run = lambda c, m, b: hip.decode(c.to(DEV), m.to(DEV), b.to(DEV), window, S, 255, 8, p.ratio, p.penalty_k,
+                                     p.window_influence, 60.0, 50.0).cpu().numpy()
+    base = run(cls, cm, bbox)
+    assert 0 <= int(base[0]) < n
+    nan = float('nan')
+    allnan = run(torch.full((n,), nan), torch.full((n,), nan), bbox)
+    assert int(allnan[0]) == 0 and np.isnan(allnan[7])
+    for where in ([400], [17, 300, 599], [624], [255, 256]):          # across the 256-thread stripes
+        c2 = cls.clone()
+        c2[where] = nan
+        o = run(c2, cm, bbox)
+        assert int(o[0]) == min(where), (where, o[0])
+    b2 = bbox.clone()
+    b2[:, 77] = nan                                                   # NaN box -> NaN penalty -> NaN pscore
+    assert int(run(cls, cm, b2)[0]) == 77
+    # ties: first maximum wins
+    flat = run(torch.zeros(n), torch.zeros(n), torch.full((4, n), 20.0))
+    w = window.cpu().numpy()
+    assert int(flat[0]) == int(np.argmax(w))
 
 
 def test_permutes_roundtrip():

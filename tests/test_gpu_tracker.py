@@ -160,3 +160,70 @@ def test_session_cached_encodings_equal_reencoding(net):
     for g in range(3):
         a, b = sess.bank_enc[g][:rows].cpu().numpy(), enc[g].cpu().numpy()
         assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
+
+
+def test_memory_features_is_a_view_of_the_bank_and_paths_can_switch(net):
+    """usot_tracker.py:264 keeps one pooled tensor per frame in state['memory_features']; the fused
+    path backs that list with the session's device bank (no None entries), and switching
+    `fused` off mid-video carries on with the same queue."""
+    ref, _ = run(net, 12, 9, (52.0, 38.0), False)
+    trk = USOTTracker(Info())
+    im, (cx, cy) = synth.frame(12, t=0)
+    state = trk.init(im, np.array([cx, cy]), np.array([52.0, 38.0]), net)
+    rows = [[cx, cy, 52.0, 38.0, 0.0]]
+    for f in range(1, 9):
+        trk.fused = f < 5 or f >= 7           # frames 5 and 6 run the generic update() on the same state
+        state = trk.track(state, synth.frame(12, t=f)[0])
+        rows.append([*state['target_pos'], *state['target_sz'], float(state['cls_score'])])
+    feats = state['memory_features']
+    assert len(feats) == 9 == len(state['memory_confidences']) and state['session'].n == 9
+    for i in (0, 3, 5, 8, -1):
+        t = feats[i]
+        assert isinstance(t, torch.Tensor) and tuple(t.shape) == (1, 256, 7, 7) and t.is_cuda
+    assert torch.equal(feats[-1], state['session'].memory_feature(8))
+    assert len(feats[2:5]) == 3
+    with pytest.raises(IndexError):
+        feats[9]
+    np.testing.assert_allclose(np.array(rows), ref, atol=1e-3, rtol=0)
+
+
+def test_session_honours_mem_queue_size(net):
+    """N_q comes from the yaml (USOTConfig.mem_queue_size); the device session is built for it
+    instead of assuming 7, and a row count that does not match raises instead of corrupting the
+    control block."""
+    from usot_amd import hip
+    from usot_amd.tracker import USOTConfig, select_memory
+    out = {}
+    for nq in (7, 5):
+        p = USOTConfig()
+        p.mem_queue_size = nq
+        p.renew()
+        p.sf_size = p.score_size
+        t = lambda a: torch.from_numpy(a).cuda()
+        net.pr_pool = True
+        net.template(t(synth.crop(1021, 1, 127)), template_bbox=torch.tensor([[3.5, 3.5, 10.5, 10.5]]).cuda())
+        crops = t(synth.crop(2021, 4, 255))
+        roi = torch.tensor([[9.0, 9.0, 16.0, 16.0]]).cuda()
+        feats = [net.extract_memory_feature(ori_x=crops[0:1], search_bbox=roi),
+                 net.extract_memory_feature(ori_x=crops[0:1].flip(3), search_bbox=roi)]
+        window = np.outer(np.hanning(p.score_size), np.hanning(p.score_size))
+        sess = net.engine.open_session(p, window, feats)
+        assert sess.nq == nq
+        conf = [0.9]
+        res = []
+        for i in range(4):
+            picks = select_memory(conf, nq)
+            assert len(picks) == nq - 2
+            o = sess.frame(crops[i], picks, (63.5, 63.5))
+            conf.append(float(o[1]))
+            res.append(o)
+            # the generic model API on the same memory set gives the same response maps -> same decode
+            mem = torch.cat([feats[0], feats[1]] + [sess.memory_feature(j) for j in picks], 0)
+            cls, bbox, cm, xf = net.track(crops[i:i + 1], template_mem=mem, score_mem=torch.ones(1, nq).cuda())
+            s = p.ratio * torch.sigmoid(cls) + (1 - p.ratio) * torch.sigmoid(cm)
+            assert abs(float(s.reshape(-1)[int(o[0])]) - float(o[1])) < 2e-5
+        out[nq] = np.array(res)
+        if nq == 5:
+            with pytest.raises(hip.HipError):
+                sess.submit(crops[0], [0, 0, 0, 0, 0], (63.5, 63.5))
+    assert out[5].shape == out[7].shape

@@ -2,6 +2,7 @@
 // permutes at the API edge, and the on-device decode of a frame's response maps.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include "usot_hip.h"
 #include "common.h"
 
@@ -48,31 +49,28 @@ __device__ __forceinline__ float pr_tap(const float *d, int h, int w, const PrK 
     return d[h * p.f_sh + w * p.f_sw];
 }
 
-__device__ __forceinline__ float pr_cell(const float *d, int s_h, int s_w, float y0, float x0,
+// Closed-form integral of the bilinear hat over one unit cell (prroi_pooling_gpu_impl.cu:71-106).
+// With t measured from a cell corner, the 1-D weight of that corner over [a, b] is
+// W(a, b) = int_a^b (1 - t) dt = (b - b*b/2) - (a - a*a/2).  A cell needs only two W per axis (near
+// and far corner); the four corner terms are their outer product, accumulated in the order
+// (h0,w0), (h0,w1), (h1,w0), (h1,w1) — the per-term float32 rounding of the reference's launcher.
+__device__ __forceinline__ float pr_hat(float a, float b)
+{
+    return b - 0.5f * b * b - a + 0.5f * a * a;
+}
+
+__device__ __forceinline__ float pr_cell(const float *d, int h0, int w0, float y0, float x0,
                                          float y1, float x1, const PrK &p)
 {
-    const int e_h = s_h + 1, e_w = s_w + 1;
-    float alpha = x0 - (float)s_w, beta = y0 - (float)s_h;
-    float lim_alpha = x1 - (float)s_w, lim_beta = y1 - (float)s_h;
-    float tmp = (lim_alpha - 0.5f * lim_alpha * lim_alpha - alpha + 0.5f * alpha * alpha)
-              * (lim_beta - 0.5f * lim_beta * lim_beta - beta + 0.5f * beta * beta);
-    float sum = pr_tap(d, s_h, s_w, p) * tmp;
-
-    alpha = (float)e_w - x1; lim_alpha = (float)e_w - x0;
-    tmp = (lim_alpha - 0.5f * lim_alpha * lim_alpha - alpha + 0.5f * alpha * alpha)
-        * (lim_beta - 0.5f * lim_beta * lim_beta - beta + 0.5f * beta * beta);
-    sum += pr_tap(d, s_h, e_w, p) * tmp;
-
-    alpha = x0 - (float)s_w; beta = (float)e_h - y1;
-    lim_alpha = x1 - (float)s_w; lim_beta = (float)e_h - y0;
-    tmp = (lim_alpha - 0.5f * lim_alpha * lim_alpha - alpha + 0.5f * alpha * alpha)
-        * (lim_beta - 0.5f * lim_beta * lim_beta - beta + 0.5f * beta * beta);
-    sum += pr_tap(d, e_h, s_w, p) * tmp;
-
-    alpha = (float)e_w - x1; lim_alpha = (float)e_w - x0;
-    tmp = (lim_alpha - 0.5f * lim_alpha * lim_alpha - alpha + 0.5f * alpha * alpha)
-        * (lim_beta - 0.5f * lim_beta * lim_beta - beta + 0.5f * beta * beta);
-    sum += pr_tap(d, e_h, e_w, p) * tmp;
+    const int h1 = h0 + 1, w1 = w0 + 1;
+    const float wx_near = pr_hat(x0 - (float)w0, x1 - (float)w0);
+    const float wx_far  = pr_hat((float)w1 - x1, (float)w1 - x0);
+    const float wy_near = pr_hat(y0 - (float)h0, y1 - (float)h0);
+    const float wy_far  = pr_hat((float)h1 - y1, (float)h1 - y0);
+    float sum = pr_tap(d, h0, w0, p) * (wx_near * wy_near);
+    sum += pr_tap(d, h0, w1, p) * (wx_far * wy_near);
+    sum += pr_tap(d, h1, w0, p) * (wx_near * wy_far);
+    sum += pr_tap(d, h1, w1, p) * (wx_far * wy_far);
     return sum;
 }
 
@@ -338,7 +336,9 @@ __global__ __launch_bounds__(256) void decode_kernel(
         rr = fmax(rr, 1.0 / rr);
         const double pen = exp(-(rr * sr - 1.0) * penalty_k);
         const double ps = pen * (double)sc * (1.0 - window_influence) + window[i] * window_influence;
-        if (ps > bv) { bv = ps; bi = i; }
+        // np.argmax semantics (usot_tracker.py:163): first maximum, and a NaN counts as the maximum
+        // (the first NaN wins).  `bi` stays a valid index whatever the maps hold.
+        if (bi == 0x7fffffff || ps > bv || (ps != ps && bv == bv)) { bv = ps; bi = i; }
     }
     best_v[threadIdx.x] = bv;
     best_i[threadIdx.x] = bi;
@@ -347,7 +347,12 @@ __global__ __launch_bounds__(256) void decode_kernel(
         if (threadIdx.x < off) {
             const double ov = best_v[threadIdx.x + off];
             const int oi = best_i[threadIdx.x + off];
-            if (ov > best_v[threadIdx.x] || (ov == best_v[threadIdx.x] && oi < best_i[threadIdx.x])) {
+            const double mv = best_v[threadIdx.x];
+            const int mi = best_i[threadIdx.x];
+            const bool on = ov != ov, mn = mv != mv;
+            const bool take = oi != 0x7fffffff &&
+                (mi == 0x7fffffff || (on && !mn) || (on == mn && (on ? oi < mi : (ov > mv || (ov == mv && oi < mi)))));
+            if (take) {
                 best_v[threadIdx.x] = ov;
                 best_i[threadIdx.x] = oi;
             }
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(256) void decode_kernel(
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const int i = best_i[0];
+        const int i = min(max(best_i[0], 0), n - 1);
         const int r = i / S, c = i - r * S;
         const double gx = (double)((c - S / 2) * stride + instance_size / 2);
         const double gy = (double)((r - S / 2) * stride + instance_size / 2);
@@ -429,6 +434,31 @@ extern "C" int usot_prroi_pool_forward_f32(void *stream, const float *feat, cons
     hipLaunchKernelGGL(prroi_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
+}
+
+/* The reference's own native symbol with its own signature (prroi_pooling_gpu_impl.cuh:20-28,
+ * .cu:387-402): contiguous NCHW features [B][C][H][W], rois [R][5], contiguous output
+ * [R][C][PH][PW], top_count = R*C*PH*PW.  A binding compiled from the reference's
+ * prroi_pooling_gpu.c:22-44 links against this.  The reference's launcher prints the runtime error
+ * and calls exit(-1); this one prints the same kind of line and returns (a library must not end the
+ * process); callers that want a status use usot_prroi_pool_forward_f32. */
+extern "C" void PrRoIPoolingForwardGpu(hipStream_t stream, const float *bottom_data, const float *bottom_rois,
+                                       float *top_data, const int channels_, const int height_, const int width_,
+                                       const int pooled_height_, const int pooled_width_,
+                                       const float spatial_scale_, const int top_count)
+{
+    const long per_roi = (long)channels_ * pooled_height_ * pooled_width_;
+    if (per_roi <= 0 || top_count < 0 || top_count % per_roi) {
+        fprintf(stderr, "PrRoIPoolingForwardGpu: invalid argument (top_count %d, C %d, PH %d, PW %d)\n",
+                top_count, channels_, pooled_height_, pooled_width_);
+        return;
+    }
+    const long HW = (long)height_ * width_, PP = (long)pooled_height_ * pooled_width_;
+    const int rc = usot_prroi_pool_forward_f32((void *)stream, bottom_data, bottom_rois, top_data,
+                                               (int)(top_count / per_roi), channels_, height_, width_,
+                                               pooled_height_, pooled_width_, spatial_scale_,
+                                               channels_ * HW, HW, width_, 1, channels_ * PP, PP, pooled_width_, 1);
+    if (rc != USOT_OK) fprintf(stderr, "PrRoIPoolingForwardGpu: %s\n", usot_strerror(rc));
 }
 
 extern "C" int usot_permute4_f32(void *stream, const float *src, float *dst,

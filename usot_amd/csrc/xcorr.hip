@@ -624,6 +624,18 @@ extern "C" int usot_xcorr_depthwise_f32(void *stream, const float *x, const floa
     return USOT_OK;
 }
 
+// variant the launcher picks for `total` samples of an OW-wide response when cols_per_thread == 0
+static int groupdw_auto_mode(int total, int OW)
+{
+    const int nstrip0 = (OW + 4) / 5;
+    return (total >= 64 && (nstrip0 == 5 || nstrip0 == 6)) ? 4 : 1;
+}
+
+extern "C" int usot_groupdw_auto_variant(int total_samples, int OW)
+{
+    return groupdw_auto_mode(total_samples, OW);
+}
+
 extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, int nseg)
 {
     if (!d || nseg < 1 || nseg > 3) return USOT_EINVAL;
@@ -648,9 +660,7 @@ extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, 
     }
     // variant: 0 -> auto (5x1 strips for a frame's 9 samples, ring for >= 64 samples);
     // 1 strips, 5/50/52 5x5 patches (register budgets), 2 column threads, 3 LDS row streaming, 4 ring
-    const int nstrip0 = (p.OW + 4) / 5;
-    const int mode = d[0].cols_per_thread != 0 ? d[0].cols_per_thread
-                   : ((total >= 64 && (nstrip0 == 5 || nstrip0 == 6)) ? 4 : 1);
+    const int mode = d[0].cols_per_thread != 0 ? d[0].cols_per_thread : groupdw_auto_mode(total, p.OW);
     hipStream_t s = (hipStream_t)stream;
     if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 50 && mode != 52) return USOT_EINVAL;
     if (mode == 4) {            // ring: workgroup per (sample, 64-channel group), taps in LDS

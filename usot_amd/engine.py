@@ -13,6 +13,7 @@ returned cls/bbox maps).  reference call graph: lib/models/models.py:173-206,
 lib/models/connect.py:221-281, lib/models/modules.py:137-151.
 """
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -799,7 +800,12 @@ class Session:
         # Control and result blocks live in pinned (device-mapped, coherent) HOST memory that the
         # kernels address directly: the 64-byte per-frame upload/download needs no copy
         # kernels at all — the host writes ctl, launches the graph, synchronises, reads out.
-        self.ctl = torch.zeros(64, dtype=torch.uint8).pin_memory()
+        # layout: [0:16] target size (2 doubles), [48:56] frame tag (double), [64:] N_q gather rows +
+        # 1 scatter row (int32)
+        self.nq = int(getattr(p, 'mem_queue_size', 7))
+        if self.nq < 4:
+            raise hip.HipError('mem_queue_size must be >= 4 (init, flip, >= 1 sampled, last); got %d' % self.nq)
+        self.ctl = torch.zeros(64 + 4 * (self.nq + 1 + (self.nq + 1) % 2), dtype=torch.uint8).pin_memory()
         self.out8 = torch.zeros(16, dtype=torch.float64).pin_memory()   # 8 results + completion tag
         self.x_host = torch.zeros(1, 3, self.size, self.size).pin_memory()
         self._x_host_np = self.x_host.numpy()
@@ -809,22 +815,24 @@ class Session:
         e, L = self.e, hip.lib()
         bld = Builder(e.W, e.tuning, e.lanes)
         pl = bld.plan
+        nq = self.nq
         self.x = bld.buf(1, 3, self.size, self.size)
+        self.x.zero_()                      # the warm-up replay below reads it (torch.empty memory may decode as NaN)
         self.mem_in = bld.buf(1)            # heads() only asks whether there is a memory branch
         tsz_dev = self.ctl[0:56].view(torch.float64)          # [0:2] target size, [6] frame tag
-        idx_dev = self.ctl[16:48].view(torch.int32)          # 7 gather rows + 1 scatter row
+        idx_dev = self.ctl[64:64 + 4 * (nq + 1)].view(torch.int32)   # N_q gather rows + 1 scatter row
         self._ctl_f64 = tsz_dev.numpy()
         self._ctl_i32 = idx_dev.numpy()
         self._out_np = self.out8.numpy()
         # the 7 picked memory kernels: their cached encodings, three banks in one gather
-        mk = [bld.buf(7, hk, wk, 256) for hk, wk in KGEO]
+        mk = [bld.buf(nq, hk, wk, 256) for hk, wk in KGEO]
         # ... and the append row of this frame is stashed in device memory: the scatter at the end of
         # the graph runs AFTER the result tag the host waits for, i.e. possibly while the host is
         # already writing the next frame's control block
         self.slot_dev = torch.zeros(4, dtype=torch.int32, device=e.device)
-        self._rows_multi(pl, self.bank_enc, idx_dev, mk, 7, scatter=0, stash=self.slot_dev)
+        self._rows_multi(pl, self.bank_enc, idx_dev, mk, nq, scatter=0, stash=self.slot_dev)
         xf, hf = bld.backbone(self.x, 1, self.size, need_stem=False)
-        bbox, cls2, S = bld.heads(xf, 1, hf, self.zk, self.mem_in, 7, mk=mk, mem_lane=2)
+        bbox, cls2, S = bld.heads(xf, 1, hf, self.zk, self.mem_in, nq, mk=mk, mem_lane=2)
         assert S == self.S
         self.roi = bld.buf(5)
         self.feat = bld.buf(1, 7, 7, 256)
@@ -842,7 +850,7 @@ class Session:
         pl.keep += [self.bank, self.ctl, self.window, self.out8, tsz_dev, idx_dev] + self.zk
         self.xf, self.cls2, self.bbox, self.plan, self.log = xf, cls2, bbox, pl, bld.log
         # warm-up must not leave a stray row in the bank: point the scatter at a scratch row
-        self._set_ctl([0, 1, 2, 2, 2, 2, 2], self.cap - 1, (64.0, 64.0))
+        self._set_ctl([0, 1] + [2] * (nq - 2), self.cap - 1, (64.0, 64.0))
         self._ctl_f64[6] = -1.0
         e._finish(pl)
         torch.cuda.current_stream().synchronize()
@@ -871,7 +879,10 @@ class Session:
     def _set_ctl(self, rows, slot, tsz):
         self._ctl_f64[0] = float(tsz[0])
         self._ctl_f64[1] = float(tsz[1])
-        self._ctl_i32[:] = list(rows) + [slot]
+        rows = list(rows)
+        if len(rows) != self.nq:
+            raise hip.HipError('%d memory rows for a session built for mem_queue_size = %d' % (len(rows), self.nq))
+        self._ctl_i32[:] = rows + [slot]
 
     def _ensure_capacity(self):
         """Grow BEFORE anything is written into the plan's input buffer: growing rebuilds the
@@ -910,13 +921,31 @@ class Session:
         rather than sleeping in hipStreamSynchronize (the PrRoIPool + bank append behind it are
         ordered before the next frame by the stream)."""
         out, tag = self._out_np, self._tag
-        for _ in range(200000):
+        for _ in range(20000):                  # a frame is ~1 ms: spin first ...
             if out[8] == tag:
                 break
-        else:
-            self._stream.synchronize()
+        else:                                   # ... then give the core away between polls
+            deadline = time.monotonic() + 20.0
+            while out[8] != tag and time.monotonic() < deadline:
+                time.sleep(5e-5)
+            if out[8] != tag:
+                self._stream.synchronize()
+                if out[8] != tag:
+                    raise hip.HipError('frame %r never published its result block (tag reads %r): '
+                                       'the frame graph did not run to the decode kernel' % (tag, float(out[8])))
         self.n += 1
         return out[:8].copy()
+
+    def append_feature(self, feat):
+        """Append a memory feature computed OUTSIDE the frame graph (NCHW-shaped [1,256,7,7], any strides):
+        bank row + its three kernel-side encodings.  Lets a caller that switches from the fused path to
+        the generic `update()` mid-video keep one memory queue (usot_tracker.py:264)."""
+        self._ensure_capacity()
+        torch.cuda.current_stream().synchronize()
+        row = 2 + self.n
+        self.bank[row].copy_(hip.to_nhwc(_as_dev_f32(feat, self.e.device))[0])
+        self._encode_rows(row, row + 1)
+        self.n += 1
 
     def frame(self, x_crop, picks, tsz_scaled, resident=False):
         """Run one frame.  x_crop: CHW float tensor (host or device); picks: memory indices
@@ -947,3 +976,34 @@ class Session:
     def memory_feature(self, i):
         """Memory feature i as an NCHW-shaped view [1,256,7,7] of its bank row."""
         return self.bank[2 + i:3 + i].permute(0, 3, 1, 2)
+
+
+class MemoryFeatures(object):
+    """`state['memory_features']` on the fused path: the list the reference keeps
+    (usot_tracker.py:264 appends one pooled [1,256,7,7] tensor per frame), backed by the session's
+    device bank instead of growing a python list of tensors.  Indexing returns a view of the bank
+    row (valid until the bank is regrown); `append` writes a feature computed outside the frame
+    graph into the bank, so the generic `update()` branch can take over mid-video."""
+
+    def __init__(self, session):
+        self.session = session
+
+    def __len__(self):
+        return self.session.n
+
+    def __getitem__(self, i):
+        n = len(self)
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(n))]
+        i = int(i)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError('memory feature %d of %d' % (i, n))
+        return self.session.memory_feature(i)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def append(self, feat):
+        self.session.append_feature(feat)

@@ -28,6 +28,7 @@ EXPORTS = (
     'usot_plan_add_maxpool_lp', 'usot_stem_pool_lp', 'usot_plan_add_stem_pool_lp',
     'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
+    'PrRoIPoolingForwardGpu', 'usot_groupdw_auto_variant',
 )
 
 
@@ -128,6 +129,8 @@ def lib():
         L.usot_conf_fusion_reduce_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4
         L.usot_prroi_pool_forward_f32.argtypes = ([C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_float]
                                                   + [C.c_int64] * 8)
+        L.PrRoIPoolingForwardGpu.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_int]
+        L.PrRoIPoolingForwardGpu.restype = None
         L.usot_permute4_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_int64] * 4
         L.usot_decode_f32.argtypes = ([C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_float]
                                       + [C.c_double] * 4)
@@ -303,6 +306,15 @@ def groupdw(xs, zs, wsm, x_rep=1, cols=0):
                      z_cs=[Cc] * 3, z_co=[0] * 3, cols=cols)
     check(lib().usot_groupdw_f32(stream(), C.byref(d)), 'usot_groupdw_f32')
     return out
+
+
+GROUPDW_VARIANTS = {1: 'groupdw_nhwc_kernel<5,1> (strips)', 2: 'groupdw_nhwc_col_kernel', 3: 'groupdw_nhwc_stream_kernel',
+                    4: 'groupdw_nhwc_ring_kernel', 5: 'groupdw_nhwc_kernel<5,5> (patches)', 6: 'groupdw_dma_kernel'}
+
+
+def groupdw_variant_name(samples, ow=25):
+    """Kernel the launcher's auto mode runs for `samples` samples (what a benchmark times)."""
+    return GROUPDW_VARIANTS.get(int(lib().usot_groupdw_auto_variant(int(samples), int(ow))), 'groupdw')
 
 
 def conf_fusion_reduce(cv, B, M):

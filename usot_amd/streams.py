@@ -17,8 +17,10 @@ def env_world():
             int(os.environ.get('WORLD_SIZE', 1)))
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+def init(backend=None, device_index=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1).
+    backend None = RCCL ("nccl") on a GPU box, gloo on CPU.  device_index: the GPU of this rank
+    (default LOCAL_RANK)."""
     rank, local, world = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -26,9 +28,21 @@ def init(backend=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local if device_index is None else device_index)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def backend_name():
+    if not (dist.is_available() and dist.is_initialized()):
+        return 'no'
+    b = dist.get_backend()
+    return 'RCCL' if b == 'nccl' else b
+
+
+def _collective_device(device):
+    """gloo moves host memory; RCCL moves device memory."""
+    return torch.device('cpu') if dist.get_backend() == 'gloo' else device
 
 
 def broadcast_weights(model, src=0, device=None):
@@ -39,7 +53,7 @@ def broadcast_weights(model, src=0, device=None):
     sd = model.state_dict()
     fkeys = [k for k, v in sd.items() if v.is_floating_point()]
     ikeys = [k for k, v in sd.items() if not v.is_floating_point()]
-    dev = device if device is not None else sd[fkeys[0]].device
+    dev = _collective_device(device if device is not None else sd[fkeys[0]].device)
     flat = torch.cat([sd[k].detach().reshape(-1).float().to(dev) for k in fkeys])
     dist.broadcast(flat, src=src)
     ints = torch.stack([sd[k].detach().reshape(()).to(dev) for k in ikeys]) if ikeys else None
@@ -64,7 +78,7 @@ def shard(items, rank, world):
 def max_over_ranks(value, device=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device or 'cpu')
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_collective_device(device or 'cpu'))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)          # timing scalar only, not on the data path
     return float(t.item())
 

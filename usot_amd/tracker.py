@@ -173,7 +173,9 @@ class USOTTracker(object):
         state['memory_features'] = [feats[0]]
         state['memory_confidences'] = [0.9]
         if self.fused and hasattr(model, 'engine') and dev.type == 'cuda':
+            from .engine import MemoryFeatures
             state['session'] = model.engine.open_session(p, window, feats)
+            state['memory_features'] = MemoryFeatures(state['session'])      # list-like view of the device bank
         return state
 
     def _flipped(self, img, box):
@@ -229,7 +231,7 @@ class USOTTracker(object):
         conf = state['memory_confidences']
         picks = select_memory(conf, p.mem_queue_size)
 
-        sess = state.get('session')
+        sess = state.get('session') if self.fused else None     # fused may be switched off mid-video
         if sess is None or not self.device_crop:
             x_crop, _ = get_subwindow_tracking(im, target_pos, p.instance_size, python2round(s_x), state['avg_chans'])
         if sess is not None:
@@ -240,7 +242,8 @@ class USOTTracker(object):
                 out = sess.frame(x_crop, picks, target_sz * scale_z)
             pos, sz = self._apply_box(p, out[3:7], out[2], out[1], target_pos, target_sz * scale_z, scale_z)
             score = np.float32(out[1])
-            state['memory_features'].append(None)          # the feature lives in the session's bank
+            # the frame graph has already appended the pooled feature to the session's bank, which
+            # state['memory_features'] views (usot_tracker.py:264)
         else:
             dev = _dev_of(net)
             feats = state['memory_features']
