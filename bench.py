@@ -67,9 +67,27 @@ def open_stream(model, device, seed, size=255):
     return model.engine.open_session(p, window, feats), crops, p
 
 
+class Confidences:
+    """state['memory_confidences'] of the benchmark loop: the tracker's numpy mirror of the list
+    (USOTTracker._conf_array) without the list — append + a view of the filled part."""
+
+    def __init__(self, first=0.9, cap=1 << 16):
+        self.buf = np.empty(cap, np.float64)
+        self.buf[0], self.n = first, 1
+
+    def append(self, v):
+        if self.n == len(self.buf):
+            self.buf = np.concatenate([self.buf, np.empty_like(self.buf)])
+        self.buf[self.n] = v
+        self.n += 1
+
+    def view(self):
+        return self.buf[:self.n]
+
+
 def run_frames(sess, crops, p, conf, n):
     for i in range(n):
-        picks = select_memory(conf, p.mem_queue_size)
+        picks = select_memory(conf.view(), p.mem_queue_size)
         out = sess.frame(crops[i % crops.shape[0]], picks, (63.5, 63.5))
         conf.append(float(out[1]))
 
@@ -81,7 +99,7 @@ def run_frames_multi(group, n):
     for i in range(n):
         for sess, crops, p, conf, st in group:
             with torch.cuda.stream(st):
-                sess.submit(crops[i % crops.shape[0]], select_memory(conf, p.mem_queue_size), (63.5, 63.5))
+                sess.submit(crops[i % crops.shape[0]], select_memory(conf.view(), p.mem_queue_size), (63.5, 63.5))
         for sess, crops, p, conf, st in group:
             conf.append(float(sess.collect()[1]))
 
@@ -130,27 +148,46 @@ def roofline(sess, frames):
     }
 
 
-def xcorr_bandwidth(device, samples=128, iters=20):
-    """Fused GroupDW at a size beyond the 256 MiB Infinity Cache: achieved GB/s on the
-    ALGORITHMIC bytes of SURVEY §8(d) (3 161 088 B per sample), HIP events on the stream."""
-    g = torch.Generator(device='cpu').manual_seed(7)
+def xcorr_bandwidth(device, sizes=(2048, 128), iters=20):
+    """Fused GroupDW far beyond the 256 MiB Infinity Cache: achieved GB/s on the ALGORITHMIC bytes of
+    SURVEY §8(d) (3 161 088 B per sample), HIP events on the launching stream.  `achieved` is the
+    steady-state figure (2048 samples = 6.5 GB moved per launch); `by_samples` adds the 405 MB case
+    (128 samples = exactly one wave of workgroups, so ramp-up and drain are not amortised)."""
     geo = ((5, 5), (3, 5), (5, 3))
-    xs = [torch.randn(samples, 25 + hk - 1, 25 + wk - 1, 256, generator=g).to(device) for hk, wk in geo]
-    zs = [torch.randn(samples, hk, wk, 256, generator=g).to(device) for hk, wk in geo]
     w = np.array([0.3, 0.3, 0.4], np.float32)
-    for _ in range(3):
-        hip.groupdw(xs, zs, w)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        hip.groupdw(xs, zs, w)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    gbps = samples * GROUPDW_BYTES_PER_SAMPLE / (ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': hip.groupdw_variant_name(samples), 'samples': samples, 'ms': round(ms, 4),
-            'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}
+    rows = []
+    for samples in sizes:
+        g = torch.Generator(device=device).manual_seed(7)
+        xs = [torch.randn(samples, 25 + hk - 1, 25 + wk - 1, 256, generator=g, device=device) for hk, wk in geo]
+        zs = [torch.randn(samples, hk, wk, 256, generator=g, device=device) for hk, wk in geo]
+        for _ in range(3):
+            hip.groupdw(xs, zs, w)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            hip.groupdw(xs, zs, w)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        rows.append({'samples': samples, 'kernel': hip.groupdw_variant_name(samples), 'ms': round(ms, 4),
+                     'bytes': samples * GROUPDW_BYTES_PER_SAMPLE,
+                     'achieved': round(samples * GROUPDW_BYTES_PER_SAMPLE / (ms * 1e-3) / 1e9, 1)})
+        del xs, zs
+    top = rows[0]
+    return {'bound': 'hbm', 'kernel': top['kernel'], 'samples': top['samples'], 'ms': top['ms'],
+            'achieved': top['achieved'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(top['achieved'] / HBM_PEAK_GBPS, 4),
+            'traffic': xcorr_traffic(top['kernel']), 'by_samples': rows}
+
+
+def xcorr_traffic(kernel):
+    """HBM bytes per sample of the GroupDW kernel from the committed PMC passes (profiles/pmc_xcorr.json), if
+    that kernel was profiled."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_xcorr.json')) as f:
+            return json.load(f).get(kernel)
+    except Exception:
+        return None
 
 
 def video_loop(model, device, frames=200):
@@ -444,7 +481,7 @@ def main():
     group = []
     for k in range(S):
         sess, crops, p = open_stream(model, device, seed=rank * S + k, size=a.size)
-        group.append((sess, crops, p, [0.9], torch.cuda.Stream() if S > 1 else torch.cuda.current_stream()))
+        group.append((sess, crops, p, Confidences(), torch.cuda.Stream() if S > 1 else torch.cuda.current_stream()))
     sess, crops, p, conf, _ = group[0]
     go = (lambda n: run_frames(sess, crops, p, conf, n)) if S == 1 else (lambda n: run_frames_multi(group, n))
     go(a.warmup)

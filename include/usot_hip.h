@@ -137,9 +137,11 @@ typedef struct usot_groupdw_desc {
     int32_t x_cs[3], x_co[3], z_cs[3], z_co[3];
     float wsm[3];
     int32_t S, x_rep, OH, OW, C;
-    int32_t cols_per_thread;     /* kernel variant: 0 auto (strips for a frame, ring for >= 64 samples);
+    int32_t cols_per_thread;     /* kernel variant: 0 auto (strips for a frame; from 64 samples up the LDS-DMA
+                                  * kernel for 25- and 27-wide responses, else ring);
                                   * 1: 5x1 strips; 50: 5x5 patches; 2: column threads;
-                                  * 3: LDS row streaming; 4: ring (taps in LDS, rows streamed once) */
+                                  * 3: LDS row streaming; 4: ring (taps in LDS, rows streamed once);
+                                  * 6: LDS-DMA (loader waves feed row-sets to LDS, 7-column strip waves) */
 } usot_groupdw_desc;
 int usot_groupdw_f32(void *stream, const usot_groupdw_desc *d);
 /* the cols_per_thread code the launcher resolves 0 (auto) to for this many samples (benchmarks name

@@ -9,6 +9,10 @@ CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(CSRC, 'libusot_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC]
+# per-file flags.  xcorr.hip: hipcc's SLP vectoriser packs the depthwise FMAs into v_pk_fma_f32 pairs, which
+# on gfx950 run at the scalar-FMA rate but need operand pairs in adjacent registers: the LDS-DMA GroupDW
+# kernel goes from 109 VGPRs to 256 + spills with it
+FILE_FLAGS = {'xcorr.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():
@@ -37,10 +41,13 @@ def build(force=False, verbose=False):
     cc = _hipcc()
     objs = []
     procs = []
+    hdrs = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(INCLUDE, '*.h')) + [os.path.abspath(__file__)]
     for src in sources():
         obj = src[:-4] + '.o'
         objs.append(obj)
-        cmd = [cc] + FLAGS + ['-c', src, '-o', obj]
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src] + hdrs):
+            continue                              # object is newer than its source and every header
+        cmd = [cc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -77,7 +77,7 @@ def select_memory(conf, n_q):
     for i in range(k):
         a = min(int(int(i * gap) * n), n - 1)
         b = min(int(int((i + 1) * gap) * n), n - 1)
-        picks.append(a if a >= b else int(np.argmax(np.array(conf[a:b]))) + a)
+        picks.append(a if a >= b else int(np.argmax(np.asarray(conf[a:b]))) + a)
     picks.append(n - 1)
     return picks
 
@@ -223,13 +223,30 @@ class USOTTracker(object):
         pos = np.array([target_pos[0] + dx, target_pos[1] + dy])
         return pos, tsz * (1 - lr) + lr * np.array([rw, rh])
 
+    @staticmethod
+    def _conf_array(state, conf):
+        """numpy mirror of state['memory_confidences'] (the list the reference keeps, usot_tracker.py:265):
+        select_memory takes argmax over quarter-length slices of it every frame, which on a python
+        list costs a list -> array conversion that grows with the video (60 us per frame at 2 000
+        frames).  Rebuilt whenever the caller has edited the list."""
+        buf, n = state.get('_conf_buf'), len(conf)
+        m = state.get('_conf_n', 0)
+        if buf is None or m > n or n > len(buf) or (m and buf[m - 1] != conf[m - 1]):
+            buf = np.empty(max(1024, 2 * n), np.float64)
+            buf[:n] = conf
+            state['_conf_buf'] = buf
+        elif n > m:
+            buf[m:n] = conf[m:n]
+        state['_conf_n'] = n
+        return buf[:n]
+
     def track(self, state, im):
         """usot_tracker.py:202-276."""
         p, net = state['p'], state['net']
         target_pos, target_sz = state['target_pos'], state['target_sz']
         s_x, scale_z = search_scale(target_sz, p)
         conf = state['memory_confidences']
-        picks = select_memory(conf, p.mem_queue_size)
+        picks = select_memory(self._conf_array(state, conf), p.mem_queue_size)
 
         sess = state.get('session') if self.fused else None     # fused may be switched off mid-video
         if sess is None or not self.device_crop:
