@@ -10,7 +10,7 @@ in this process only:
      into /root/reference);
   3. forward passes run under no_grad and eval().
 
-Usage:  python tests/golden/make_golden.py [calib] [model] [host] [e2e]
+Usage:  python tests/golden/make_golden.py [calib] [model] [host] [e2e] [datasets] [family]
 """
 import json
 import os
@@ -58,9 +58,9 @@ torch.manual_seed(0)
 torch.set_num_threads(8)
 
 
-def build(calibrated):
+def build(calibrated, family='zero_dc'):
     net = ref_models.USOT()
-    sd = synth.torch_state_dict(net, seed=0, calibrated=calibrated)
+    sd = synth.torch_state_dict(net, seed=0, calibrated=calibrated, family=family)
     missing = net.load_state_dict(sd, strict=True)
     return net, sd
 
@@ -69,9 +69,9 @@ def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def do_calib():
+def do_calib(family='zero_dc'):
     """One train-mode pass with momentum 1 so running stats == batch stats of this input."""
-    net, _ = build(calibrated=False)
+    net, _ = build(calibrated=False, family=family)
     keys = {k: list(v.shape) for k, v in net.state_dict().items()}
     with open(os.path.join(GOLD, 'state_dict_keys.json'), 'w') as f:
         json.dump(keys, f, indent=0, sort_keys=True)
@@ -87,8 +87,8 @@ def do_calib():
     out = {k: v.numpy() for k, v in net.state_dict().items()
            if k.endswith('running_mean') or k.endswith('running_var')}
     os.makedirs(synth.DATA_DIR, exist_ok=True)
-    np.savez_compressed(synth.CALIB_FILE, **out)
-    print('calibration: %d tensors -> %s' % (len(out), synth.CALIB_FILE))
+    np.savez_compressed(synth.calib_file(family), **out)
+    print('calibration: %d tensors -> %s' % (len(out), synth.calib_file(family)))
 
 
 def do_model():
@@ -384,7 +384,62 @@ def do_e2e():
     np.savez_compressed(os.path.join(GOLD, 'golden_e2e.npz'), **out)
 
 
+def do_family():
+    """Second weight family ('dc': non-zero-DC filters, ordinary last-BN gains; usot_amd/synth.py): BN
+    statistics calibrated like the first, then ONE tracked frame (template by centre crop, N_q = 7) through
+    the reference model twice — in its own float32 arithmetic and converted to float64.  The fixture holds
+    both; the GPU test reports HIP-vs-float64 beside reference-float32-vs-float64."""
+    do_calib('dc')
+    g = {}
+    for fam in ('zero_dc', 'dc'):
+        net, sd = build(calibrated=True, family=fam)
+        net.eval()
+        net.pr_pool = False
+        z, x, mem = t(synth.crop(40, 1, 127)), t(synth.crop(41, 1, 255)), t(synth.memory_kernels(47, 7))
+        with torch.no_grad():
+            net.template(z)
+            o32 = net.track(x, template_mem=mem, score_mem=torch.full((1, 7), 0.9))
+            net64 = net.double()
+            net64.template(z.double())
+            o64 = net64.track(x.double(), template_mem=mem.double(), score_mem=torch.full((1, 7), 0.9).double())
+        for nm, a, b in zip(('cls', 'bbox', 'cls_mem'), o32, o64):
+            g['%s/%s/f32' % (fam, nm)], g['%s/%s/f64' % (fam, nm)] = a.numpy(), b.numpy()
+            d = np.abs(a.numpy().astype(np.float64) - b.numpy())
+            s = np.maximum(np.abs(b.numpy()), np.abs(b.numpy()).mean())
+            print('%-8s %-8s reference f32 vs f64: scaled max %.2e' % (fam, nm, float((d / s).max())))
+    np.savez_compressed(os.path.join(GOLD, 'golden_family.npz'), **g)
+
+
+def do_datasets():
+    """f3: the REFERENCE's load_dataset (lib/dataset_loader/benchmark.py:8-230, pure Python) run on a
+    fake datasets_test/ tree; its results, with paths made relative, are the fixture the CPU test
+    compares usot_amd.benchmarks.load_dataset with.  The loader resolves its data root from its own
+    __file__ (../../datasets_test), so the module object's __file__ is pointed at a temporary tree —
+    nothing is written under /root/reference."""
+    import importlib.util
+    import tempfile
+    import fake_datasets
+    spec = importlib.util.spec_from_file_location('ref_benchmark', os.path.join(REF, 'lib', 'dataset_loader', 'benchmark.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        tmp = os.path.realpath(tmp)
+        fake_datasets.build(tmp)
+        os.makedirs(os.path.join(tmp, 'lib', 'dataset_loader'))       # '..' components are resolved by the OS
+        mod.__file__ = os.path.join(tmp, 'lib', 'dataset_loader', 'benchmark.py')
+        for name in fake_datasets.DATASETS:
+            out[name] = fake_datasets.normalise(mod.load_dataset(name), tmp)
+        try:
+            mod.load_dataset('NOSUCH')
+        except ValueError as e:
+            out['__unsupported__'] = str(e)
+    with open(os.path.join(GOLD, 'golden_datasets.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('datasets:', {k: len(v['order']) for k, v in out.items() if isinstance(v, dict)})
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['calib', 'model', 'host']
     for w in what:
-        {'calib': do_calib, 'model': do_model, 'host': do_host, 'e2e': do_e2e}[w]()
+        {'calib': do_calib, 'model': do_model, 'host': do_host, 'e2e': do_e2e, 'datasets': do_datasets, 'family': do_family}[w]()

@@ -20,14 +20,26 @@ import numpy as np
 
 DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
 CALIB_FILE = os.path.join(DATA_DIR, 'calib_bn_seed0.npz')
+# Weight families.  'zero_dc' (default, every golden): zero-mean filters, small last-BN gain per
+# bottleneck.  'dc': the same draws WITHOUT the mean subtraction and with ordinary last-BN gains — filters
+# that pass the DC level of post-ReLU maps, so every BatchNorm subtracts two large numbers.  It exists to
+# show parity on a badly conditioned network too: there the reference's own float32 arithmetic is far from
+# a float64 evaluation, and the claim to check is "HIP is as close to float64 as the reference is"
+# (tests/test_gpu_model.py::test_second_weight_family_vs_float64).
+FAMILIES = ('zero_dc', 'dc')
+
+
+def calib_file(family='zero_dc'):
+    return CALIB_FILE if family == 'zero_dc' else os.path.join(DATA_DIR, 'calib_bn_%s_seed0.npz' % family)
 
 
 def _rng(seed, name):
     return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
 
 
-def make_param(name, shape, seed=0):
+def make_param(name, shape, seed=0, family='zero_dc'):
     """One state-dict entry (numpy) for `name` with `shape`."""
+    assert family in FAMILIES, family
     shape = tuple(int(s) for s in shape)
     g = _rng(seed, name)
     leaf = name.rsplit('.', 1)[-1]
@@ -55,9 +67,10 @@ def make_param(name, shape, seed=0):
         # zero-DC filters: post-ReLU inputs have mean ~ std, and a filter that passes that
         # DC level makes the following BN subtract two large numbers (fp32 noise x10 per
         # stage, every implementation alike).  Trained filters are near zero-mean too.
-        w -= w.mean(axis=(1, 2, 3), keepdims=True)
+        if family == 'zero_dc':
+            w -= w.mean(axis=(1, 2, 3), keepdims=True)
         return w.astype(np.float32)
-    if name.endswith('.bn3.weight'):                     # small last-BN gain per bottleneck,
+    if name.endswith('.bn3.weight') and family == 'zero_dc':                     # small last-BN gain per bottleneck,
         return g.uniform(0.08, 0.2, shape).astype(np.float32)    # cf. zero-init-residual
     if leaf == 'weight':                                 # BN gamma
         return g.uniform(0.6, 1.4, shape).astype(np.float32)
@@ -66,13 +79,13 @@ def make_param(name, shape, seed=0):
     raise KeyError('no synthetic rule for %s %s' % (name, shape))
 
 
-def make_state_dict(shapes, seed=0, calibrated=True):
+def make_state_dict(shapes, seed=0, calibrated=True, family='zero_dc'):
     """`shapes`: {name: shape}.  Returns {name: np.ndarray}."""
-    sd = {k: make_param(k, s, seed) for k, s in shapes.items()}
+    sd = {k: make_param(k, s, seed, family) for k, s in shapes.items()}
     if calibrated:
         if seed != 0:
             raise ValueError('BN calibration is only recorded for seed 0')
-        with np.load(CALIB_FILE) as z:
+        with np.load(calib_file(family)) as z:
             for k in z.files:
                 if k in sd:
                     assert sd[k].shape == z[k].shape, k
@@ -80,11 +93,11 @@ def make_state_dict(shapes, seed=0, calibrated=True):
     return sd
 
 
-def torch_state_dict(model, seed=0, calibrated=True):
+def torch_state_dict(model, seed=0, calibrated=True, family='zero_dc'):
     """State dict (torch CPU tensors) for any module exposing the reference's keys."""
     import torch
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = make_state_dict(shapes, seed, calibrated)
+    sd = make_state_dict(shapes, seed, calibrated, family)
     return {k: torch.from_numpy(np.ascontiguousarray(v)).reshape(shapes[k]) for k, v in sd.items()}
 
 
