@@ -177,17 +177,21 @@ def xcorr_bandwidth(device, sizes=(2048, 128), iters=20):
     top = rows[0]
     return {'bound': 'hbm', 'kernel': top['kernel'], 'samples': top['samples'], 'ms': top['ms'],
             'achieved': top['achieved'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(top['achieved'] / HBM_PEAK_GBPS, 4),
-            'traffic': xcorr_traffic(top['kernel']), 'by_samples': rows}
+            'algorithmic_bytes': top['bytes'], **xcorr_traffic(top['kernel'], top['samples']), 'by_samples': rows}
 
 
-def xcorr_traffic(kernel):
-    """HBM bytes per sample of the GroupDW kernel from the committed PMC passes (profiles/pmc_xcorr.json), if
-    that kernel was profiled."""
+def xcorr_traffic(kernel, samples):
+    """HBM bytes per launch of the GroupDW kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_xcorr.json: FETCH_SIZE x 2 + WRITE_SIZE per sample, scripts/pmc_xcorr_to_json.py); null
+    when that kernel was not profiled."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_xcorr.json')) as f:
-            return json.load(f).get(kernel)
+            pmc = json.load(f)
+        per = pmc[kernel]['hbm_bytes_per_sample']
+        return {'traffic': int(per) * samples, 'traffic_to_algorithmic': pmc[kernel]['ratio_to_algorithmic'],
+                'traffic_source': 'profiles/pmc_xcorr.json@%s' % pmc.get('_meta', {}).get('commit', '')}
     except Exception:
-        return None
+        return {'traffic': None}
 
 
 def video_loop(model, device, frames=200):
