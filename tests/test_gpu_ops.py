@@ -382,7 +382,8 @@ def test_conv_bf16(case, tile):
 
 
 @pytest.mark.parametrize('pos,win', [((240.3, 180.7), 255), ((10.2, 8.9), 255), ((470.0, 350.0), 301), ((200.5, 100.5), 188),
-                                     ((5.0, 355.0), 127), ((240.0, 180.0), 271), ((100.0, 100.0), 612)])
+                                     ((5.0, 355.0), 127), ((240.0, 180.0), 271), ((100.0, 100.0), 612),
+                                     ((240.0, 180.0), 510), ((30.0, 300.0), 510), ((240.0, 180.0), 509), ((240.0, 180.0), 511)])
 def test_device_crop_matches_host_crop(pos, win):
     """crop + mean pad + fixed-point bilinear + HWC->CHW on the device == hostutils, bit for bit."""
     from usot_amd import hostutils, synth

@@ -121,6 +121,17 @@ def test_resize_builtin_properties():
     ramp = np.tile(np.arange(64, dtype=np.uint8)[None, :, None] * 4, (8, 1, 3))
     out = hostutils.resize_bilinear_u8(ramp, 128, 8).astype(int)
     assert np.all(np.diff(out[0, :, 0]) >= 0)          # monotone ramp stays monotone
+    # exact 2x downscale: cv2.resize(INTER_LINEAR) silently uses INTER_AREA = rounded 2x2 block means
+    big = g.integers(0, 256, (60, 44, 3), dtype=np.uint8)
+    half = hostutils.resize_bilinear_u8(big, 22, 30)
+    q = big.astype(int)
+    assert np.array_equal(half, ((q[0::2, 0::2] + q[0::2, 1::2] + q[1::2, 0::2] + q[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    # one direction only is NOT the area path (OpenCV needs iscale_x == iscale_y == 2)
+    assert hostutils.resize_bilinear_u8(big, 22, 31).shape == (31, 22, 3)
+    # coefficients: float source coordinate, round-half-even, every pair sums to 2048
+    for n_src, n_dst in ((301, 255), (188, 255), (612, 255), (127, 255), (509, 255)):
+        s0, s1, w0, w1 = hostutils._resize_axis(n_src, n_dst)
+        assert np.all(w0 + w1 == 2048) and s0.min() >= 0 and s1.max() == n_src - 1 and np.all(s1 - s0 <= 1)
 
 
 def test_flip_matches_imgaug_convention():

@@ -259,17 +259,18 @@ struct CropK {
 
 __device__ __forceinline__ void crop_axis(int d, int n_src, int n_dst, int &s0, int &s1, int &w0, int &w1)
 {
-    const double scale = (double)n_src / (double)n_dst;
-    double f = ((double)d + 0.5) * scale - 0.5;
-    long s = (long)floor(f);
-    f -= (double)s;
-    if (s < 0) { f = 0.0; s = 0; }
-    if (s >= n_src - 1) { f = 0.0; s = n_src - 1; }
-    const float ff = (float)f;
-    w1 = (int)rintf(ff * 2048.0f);
-    w0 = (int)rintf((1.0f - ff) * 2048.0f);
-    s0 = (int)s;
-    s1 = min((int)s + 1, n_src - 1);
+    // OpenCV's own arithmetic (see hostutils._resize_axis): double scale = 1 / (dst / src), the source
+    // coordinate rounded to float BEFORE the floor, float fraction, round-half-even coefficients
+    const double scale = 1.0 / ((double)n_dst / (double)n_src);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.0f; s = 0; }
+    if (s >= n_src - 1) { f = 0.0f; s = n_src - 1; }
+    w1 = (int)rintf(f * 2048.0f);
+    w0 = (int)rintf((1.0f - f) * 2048.0f);
+    s0 = s;
+    s1 = min(s + 1, n_src - 1);
 }
 
 __device__ __forceinline__ int crop_px(const CropK &p, int wx, int wy, int c)
@@ -287,6 +288,15 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const CropK p)
     if (p.win == p.S) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) p.out[((long)c * p.S + dy) * p.S + dx] = (float)crop_px(p, dx, dy, c);
+        return;
+    }
+    if (p.win == 2 * p.S) {          // exact 2x downscale: cv2.resize switches INTER_LINEAR to INTER_AREA
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int v = (crop_px(p, 2 * dx, 2 * dy, c) + crop_px(p, 2 * dx + 1, 2 * dy, c) +
+                           crop_px(p, 2 * dx, 2 * dy + 1, c) + crop_px(p, 2 * dx + 1, 2 * dy + 1, c) + 2) >> 2;
+            p.out[((long)c * p.S + dy) * p.S + dx] = (float)v;
+        }
         return;
     }
     int xa, xb, wxa, wxb, ya, yb, wya, wyb;

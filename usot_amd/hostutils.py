@@ -45,32 +45,41 @@ def python2round(f):
 
 
 def _resize_axis(n_src, n_dst):
-    """Source index pairs and 11-bit fixed-point weights of OpenCV's INTER_LINEAR."""
-    scale = n_src / float(n_dst)
+    """Source index pairs and 11-bit fixed-point weights of OpenCV's INTER_LINEAR, in OpenCV's own
+    arithmetic (imgproc resize.cpp, `resize` linear branch): scale = 1 / (dst / src) in double; the
+    source coordinate is ROUNDED TO FLOAT before `cvFloor`, and the fraction is a float subtraction;
+    coefficients = saturate_cast<short>(c * 2048), i.e. round-half-even."""
+    scale = 1.0 / (float(n_dst) / float(n_src))
     d = np.arange(n_dst, dtype=np.float64)
-    f = (d + 0.5) * scale - 0.5
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
     s = np.floor(f).astype(np.int64)
-    f = f - s
+    f = (f - s.astype(np.float32)).astype(np.float32)
     lo = s < 0
     f[lo], s[lo] = 0.0, 0
     hi = s >= n_src - 1
     f[hi], s[hi] = 0.0, n_src - 1
-    f = f.astype(np.float32)
-    w1 = np.rint(f * 2048.0).astype(np.int64)
-    w0 = np.rint((1.0 - f) * 2048.0).astype(np.int64)
+    w1 = np.rint(f * np.float32(2048.0)).astype(np.int64)
+    w0 = np.rint((np.float32(1.0) - f) * np.float32(2048.0)).astype(np.int64)
     s1 = np.minimum(s + 1, n_src - 1)
     return s, s1, w0, w1
 
 
 def resize_bilinear_u8(img, dst_w, dst_h):
-    """uint8 HxWxC bilinear resize following OpenCV's fixed-point two-pass scheme
-    (horizontal pass in int32 with 11-bit weights, vertical pass
-    ((w0*(a>>4))>>16) + ((w1*(b>>4))>>16) + 2) >> 2)."""
+    """uint8 HxWxC `cv2.resize(img, (dst_w, dst_h))` (default INTER_LINEAR) restated: OpenCV's fixed-point
+    two-pass scheme (horizontal pass in int32 with 11-bit weights, vertical pass
+    ((w0*(a>>4))>>16) + ((w1*(b>>4))>>16) + 2) >> 2), and its special case: an EXACT 2x downscale in both
+    directions is silently switched to INTER_AREA (`resize`: "if interpolation == INTER_LINEAR && is_area_fast
+    && iscale_x == 2 && iscale_y == 2"), whose uint8 fast path is (a + b + c + d + 2) >> 2 over each 2x2
+    block.  cv2 is not in this image, so this stays UNPINNED; the crop only reaches it when
+    the search window is not already model-sized."""
     img = np.asarray(img)
     assert img.dtype == np.uint8 and img.ndim == 3
     h, w, _ = img.shape
     if (h, w) == (dst_h, dst_w):
         return img.copy()
+    if w == 2 * dst_w and h == 2 * dst_h:
+        q = img.astype(np.int64)
+        return ((q[0::2, 0::2] + q[0::2, 1::2] + q[1::2, 0::2] + q[1::2, 1::2] + 2) >> 2).astype(np.uint8)
     x0, x1, ax0, ax1 = _resize_axis(w, dst_w)
     y0, y1, ay0, ay1 = _resize_axis(h, dst_h)
     src = img.astype(np.int64)
