@@ -50,5 +50,7 @@ for sym, (n, kb) in fetch.items():
     wkb = write.get(sym, (0, 0.0))[1]
     out[k] = {'launches_profiled': n, 'fetch_kb_raw': round(kb, 1), 'write_kb_raw': round(wkb, 1),
               'hbm_bytes_per_launch': int((2.0 * kb + wkb) * 1024)}
+out['_meta'] = {'commit': sys.argv[4] if len(sys.argv) > 4 else '', 'command': 'bench.py --steps 30 --min-seconds 0 --no-extras --no-xcorr --no-cpu-baseline',
+                'correction': 'hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (gfx950: FETCH_SIZE counts 128-byte requests at 64 B)'}
 json.dump(out, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -9,6 +9,7 @@
 // operand per 16x16x32 step, quad q of the wave owning k-chunk q.  k-tile = 64 bf16 (128 B
 // per row, XOR-swizzled in LDS), register-staged double buffering as in conv_igemm_f32.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <type_traits>
 #include "usot_hip.h"
@@ -34,6 +35,7 @@ struct ConvB {
     int b_gs;
     int out_f32;       // store the result as fp32 (the neck output that feeds the fp32 heads)
     int M, K, KT, cchunks, MT, NT, P;
+    int nfast;         // tile order: 1 = the N-tiles of one pixel tile are adjacent (same XCD, back to back)
 };
 
 __device__ __forceinline__ int xcd_remap_b(int b, int total)
@@ -111,7 +113,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
         if (p.bias) p.bias += (long)grp * p.b_gs;
         p.y = (uint16_t *)((char *)p.y + (long)grp * p.y_gs * (p.out_f32 ? 4 : 2));
     }
-    const int bn0 = (b / p.MT) * BN, bm0 = (b % p.MT) * BM;
+    // The activation panel of a pixel tile is the big operand (M x K, from HBM); the filter bank is small
+    // and L2-resident everywhere.  With the pixel tile as the slow index the NT tiles that share an
+    // activation panel run back to back on ONE XCD (one HBM read + NT-1 L2 hits) instead of on NT
+    // different XCDs (NT reads through the fabric).
+    const int bn0 = p.nfast ? (b % p.NT) * BN : (b / p.MT) * BN;
+    const int bm0 = p.nfast ? (b / p.NT) * BM : (b % p.MT) * BM;
 
     const int lr = tid >> 3;
     // D = 0 (LDS-DMA): the LDS position of a lane is fixed (wave base + lane * 16), so the swizzle
@@ -735,6 +742,7 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     const TileB &tc = kTilesB[tile - 1];
     p.MT = (p.M + tc.bm - 1) / tc.bm;
     p.NT = (d->Cout + tc.bn - 1) / tc.bn;
+    p.nfast = 1;
     const long blocks = (long)p.MT * p.NT * p.groups;
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
     size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * LDC * 16;
