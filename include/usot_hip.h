@@ -105,6 +105,25 @@ int usot_stem_pool_lp(void *stream, const float *x, const void *wfrag, const flo
 int usot_cvt_f32_to_bf16(void *stream, const float *src, void *dst, int64_t n);
 int usot_maxpool3x3s2_bf16(void *stream, const void *x, void *y, int N, int H, int W, int C, int OH, int OW);
 
+/* ---- fused pair of pointwise convolutions of the low-precision backbone: a bottleneck's conv3 + BN + residual +
+ * ReLU (modules.py:48-56) and the NEXT block's conv1 + BN + ReLU (modules.py:40-42; or the neck's 1x1, connect.py:
+ * 294-300) in one persistent launch — the 4x-wide map Y is written once and never read back, the next tile's reads fly
+ * under the second GEMM (csrc/pw_pair.hip).  All activations bf16|fp16 NHWC dense, fp32 accumulate, biases fp32:
+ *   Y[M][CO] = relu(t2[M][CM] . w3^T + b3 + res[M][CO]);   T[M][CN] = act2(Y . w1^T + b1)
+ * w3p and w1 are in the kernel's FRAGMENT order (every MFMA fragment load = one contiguous KiB): build them with
+ * usot_pw_pair_layout, which lists for each packed 16-byte chunk the source (row, first k); b3 and b1 natural order.
+ * Shapes: usot_pw_pair_supported(CM, CO, CN).  act2: USOT_ACT_NONE | USOT_ACT_RELU.  dtype 0 = bf16, 1 = fp16.     */
+typedef struct usot_pw_pair_desc {
+    const void *t2, *w3p, *res, *w1;
+    const float *b3, *b1;
+    void *y, *t;
+    int32_t M, CM, CO, CN, act2;
+} usot_pw_pair_desc;
+int usot_pw_pair_lp(void *stream, const usot_pw_pair_desc *d, int dtype);
+int usot_pw_pair_layout(int CM, int CO, int CN, int which, int32_t *row, int32_t *k0);   /* which: 0 = w3, 1 = w1 */
+int usot_pw_pair_supported(int CM, int CO, int CN);
+int usot_plan_add_pw_pair(void *plan, const usot_pw_pair_desc *d, int dtype);
+
 /* ---- stem: 7x7 / stride 2 / pad 0 conv, 3 -> 64 channels, + folded BN + ReLU ---------
  * modules.py:70-72,138-140.  x NCHW [N][3][H][W] (the API-edge crop, BGR 0..255),
  * w packed [147][64] with row = (ci*7 + kh)*7 + kw, y NHWC [N][OH][OW][64].            */

@@ -24,9 +24,9 @@ convs = iter(p['log'])
 tot = 0.0; fl = 0.0
 for kind, tile, ks, groups, ms in prof:
     tot += ms
-    if kind == 11:
+    if kind in (11, 18):
         name, M, N, K, g, macs = next(convs)
-        byts = 2.0 * (M * K / (9 if K % 9 == 0 and K > 1024 else 1) + M * N + N * K) * g
+        byts = 2.0 * (M * K / (9 if K % 9 == 0 and K > 1024 else 1) + M * N + N * K) * g  # (fused pairs: first conv only)
         fl += 2 * macs
         print('%-16s M=%7d N=%5d K=%5d tile %d  %8.1f us %7.1f TF/s %7.0f GB/s' % (name, M, N, K, tile, ms * 1e3, 2 * macs / ms / 1e9, byts / ms / 1e6))
     else:

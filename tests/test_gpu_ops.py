@@ -381,6 +381,39 @@ def test_conv_bf16(case, tile):
     assert rel_err(y.float().permute(0, 3, 1, 2).cpu().numpy(), ref_r.numpy()) < 6e-3
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('cm,co,cn,M', [(256, 1024, 256, 961 * 3), (128, 512, 128, 3969), (64, 256, 64, 15876 + 37),
+                                        (64, 256, 128, 4000), (128, 512, 256, 64 * 300), (256, 1024, 256, 50)])
+def test_pw_pair_fused_equals_the_two_convolutions(cm, co, cn, M, dtype):
+    """csrc/pw_pair.hip: conv3 + residual + ReLU fused with the next 1x1 conv.  Reference = the two unfused
+    low-precision launches on the same operands (themselves checked against torch in test_conv_bf16): the wide map
+    must be bit-identical (same fp32 accumulation order, one rounding), the narrow map within the storage type's
+    rounding of it; and both within tolerance of an fp32 torch evaluation of the rounded operands."""
+    g = torch.Generator().manual_seed(cm + co + cn + M)
+    lp = lambda a: a.to(dtype).to(DEV)
+    t2 = lp(torch.randn(M, cm, generator=g).relu())
+    res = lp(torch.randn(M, co, generator=g).relu())
+    w3 = lp(torch.randn(co, cm, generator=g) / np.sqrt(cm))
+    w1 = lp(torch.randn(cn, co, generator=g) / np.sqrt(co))
+    b3, b1 = torch.randn(co, generator=g).to(DEV), torch.randn(cn, generator=g).to(DEV)
+    for act2 in (hip.ACT_RELU, hip.ACT_NONE):
+        y, t = hip.pw_pair(t2, w3, b3, res, w1, b1, act2=act2)
+        y_ref = hip.conv2d_bf16(t2.view(1, 1, M, cm), w3, b3, KH=1, KW=1, res=res.view(1, 1, M, co), act=hip.ACT_RELU).view(M, co)
+        t_ref = hip.conv2d_bf16(y_ref.view(1, 1, M, co), w1, b1, KH=1, KW=1, act=act2).view(M, cn)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref), float((y.float() - y_ref.float()).abs().max())
+        ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        d = (t.float() - t_ref.float()).abs()
+        assert float((d / t_ref.float().abs().clamp_min(1.0)).max()) <= 2 * ulp
+        yt = torch.relu(t2.float() @ w3.float().t() + b3 + res.float())
+        assert rel_err(y.float().cpu().numpy(), yt.cpu().numpy()) < 4 * ulp
+        tt = y.float() @ w1.float().t() + b1
+        if act2 == hip.ACT_RELU:
+            tt = tt.relu()
+        assert rel_err(t.float().cpu().numpy(), tt.cpu().numpy()) < 4 * ulp
+    assert not hip.pw_pair_supported(256, 1024, 128) and hip.pw_pair_supported(128, 512, 256)
+
+
 @pytest.mark.parametrize('pos,win', [((240.3, 180.7), 255), ((10.2, 8.9), 255), ((470.0, 350.0), 301), ((200.5, 100.5), 188),
                                      ((5.0, 355.0), 127), ((240.0, 180.0), 271), ((100.0, 100.0), 612),
                                      ((240.0, 180.0), 510), ((30.0, 300.0), 510), ((240.0, 180.0), 509), ((240.0, 180.0), 511)])

@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -36,6 +36,7 @@ struct Op {
     int nconv;
     usot_groupdw_desc gdw[3];
     int ngdw;
+    usot_pw_pair_desc pw;
     const void *p[6];
     int i[8];
     int64_t l[8];
@@ -104,6 +105,7 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
                                      op.f[0], op.d[0], op.d[1], (const double *)op.p[5], (float *)op.l[0]);
             break;
         case K_CONVB: rc = usot_conv2d_lp(s, &op.conv, op.i[6], op.i[7]); break;
+        case K_PWPAIR: rc = usot_pw_pair_lp(s, &op.pw, op.i[6]); break;
         case K_CVTB:  rc = usot_cvt_f32_to_lp(s, (const float *)op.p[0], (void *)op.p[1], op.l[0], op.i[6]); break;
         case K_POOLB:
             rc = usot_maxpool3x3s2_lp(s, op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6]);
@@ -234,6 +236,16 @@ extern "C" int usot_plan_add_conv_lp(void *plan, const usot_conv_desc *d, int dt
 }
 
 extern "C" int usot_plan_add_conv_bf16(void *plan, const usot_conv_desc *d) { return usot_plan_add_conv_lp(plan, d, 0, 0); }
+
+extern "C" int usot_plan_add_pw_pair(void *plan, const usot_pw_pair_desc *d, int dtype)
+{
+    if (!d || !usot_pw_pair_supported(d->CM, d->CO, d->CN)) return USOT_EINVAL;
+    Op *op = push(plan, K_PWPAIR);
+    if (!op) return USOT_ESTATE;
+    op->pw = *d;
+    op->i[6] = dtype;
+    return USOT_OK;
+}
 
 extern "C" int usot_plan_add_cvt_lp(void *plan, const float *src, void *dst, int64_t n, int dtype)
 {

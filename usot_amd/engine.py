@@ -60,6 +60,14 @@ class PackedConv:
         ow = (w + 2 * self.pad[1] - self.dil[1] * (self.kw - 1) - 1) // self.stride + 1
         return oh, ow
 
+    def w_lp_pw_pair(self, dtype, cm, co, cn, which):
+        """Low-precision filter bank in the fragment order of the fused pointwise-pair kernel (hip.pw_pair_pack)."""
+        cache = self.__dict__.setdefault('_wlp_pp', {})
+        key = (dtype, cm, co, cn, which)
+        if key not in cache:
+            cache[key] = hip.pw_pair_pack(self.w_lp(dtype), cm, co, cn, which)
+        return cache[key]
+
     def w_lp(self, dtype=torch.bfloat16):
         """bf16 / fp16 copy of the folded filter bank (made on first use; fp32 stays the master)."""
         cache = self.__dict__.setdefault('_wlp', {})
@@ -383,6 +391,22 @@ class Builder:
         self.log.append((name, n * oh * ow, cout, k, groups, groups * n * oh * ow * cout * k))
         return y, oh, ow
 
+    def pw_pair(self, name, c3, nxt, t2, res, n, h, act2, dtype):
+        """conv3 + residual + ReLU of one bottleneck and the next 1x1 conv in ONE launch (csrc/pw_pair.hip).
+        Returns (y [n,h,h,c3.cout], t [n,h,h,nxt.cout])."""
+        m = n * h * h
+        y = self.buf(n, h, h, c3.cout, dtype=dtype)
+        t = self.buf(n, h, h, nxt.cout, dtype=dtype)
+        w3p = c3.w_lp_pw_pair(dtype, c3.cin, c3.cout, nxt.cout, 0)
+        w1 = nxt.w_lp_pw_pair(dtype, c3.cin, c3.cout, nxt.cout, 1)
+        d = hip.pw_pair_desc(t2.data_ptr(), w3p.data_ptr(), c3.b.data_ptr(), res.data_ptr(), y.data_ptr(), w1.data_ptr(),
+                             nxt.b.data_ptr(), t.data_ptr(), m, c3.cin, c3.cout, nxt.cout, act2)
+        hip.check(hip.lib().usot_plan_add_pw_pair(self.plan.h, C.byref(d), 1 if dtype == torch.float16 else 0),
+                  'plan_add_pw_pair ' + name)
+        self.plan.keep += [t2, res, w3p, w1, c3.b, nxt.b]
+        self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
+        return y, t
+
     def cvt_lp(self, src, dtype):
         dst = self.buf(*src.shape, dtype=dtype)
         hip.check(hip.lib().usot_plan_add_cvt_lp(self.plan.h, hip.ptr(src), hip.ptr(dst), src.numel(),
@@ -436,15 +460,30 @@ class Builder:
         self.plan.keep += [wf, wb]
         self.plan.keep += [x]
         cur, h = p0, ph
+        fuse = getattr(self, 'fuse_pointwise', True)
+        t1 = None                                    # the block's conv1 output when the previous launch made it
+        nb = len(W.blocks)
         for bi, (c1, c2, c3, ds) in enumerate(W.blocks):
             sc = cur
             if ds is not None:
                 sc, _, _ = self.conv_bf16('b%d.ds' % bi, ds, cur, n, h, h, dtype=dtype)
-            t1, _, _ = self.conv_bf16('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU, dtype=dtype)
+            if t1 is None:
+                t1, _, _ = self.conv_bf16('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU, dtype=dtype)
             t2, h2, _ = self.conv_bf16('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU, dtype=dtype)
-            cur, _, _ = self.conv_bf16('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc, dtype=dtype)
+            # conv3 + residual + ReLU shares a launch with the NEXT 1x1 conv (the following block's conv1, or the
+            # neck after the last block): the 4x-wide map is written once and not read back
+            last = bi + 1 == nb
+            nxt = (W.neck if not neck_f32 else None) if last else W.blocks[bi + 1][0]
+            if fuse and nxt is not None and (c3.cin, c3.cout, nxt.cout) in FUSED_POINTWISE:
+                cur, t1 = self.pw_pair('b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1)), c3, nxt, t2, sc, n, h2,
+                                       ACT_NONE if last else ACT_RELU, dtype)
+            else:
+                cur, _, _ = self.conv_bf16('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc, dtype=dtype)
+                t1 = None
             h = h2
         self.p3 = cur
+        if t1 is not None:
+            return t1, h                             # the neck rode along with the last conv3
         xf, _, _ = self.conv_bf16('neck', W.neck, cur, n, h, h, dtype=dtype, out_f32=neck_f32)
         return xf, h
 
@@ -571,6 +610,9 @@ def load_lp_tuning(path=None):
 
 
 LP_TUNING = load_lp_tuning()
+# (C_mid, C_out, C_next) of the conv3 -> next-conv1 pairs that run as ONE launch (csrc/pw_pair.hip) in the batched
+# low-precision backbone: the shapes where the fused kernel measured faster than the two launches at batch 64
+FUSED_POINTWISE = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
 
 
 class Engine:

@@ -29,6 +29,7 @@ EXPORTS = (
     'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
     'PrRoIPoolingForwardGpu', 'usot_groupdw_auto_variant',
+    'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair',
 )
 
 
@@ -60,6 +61,12 @@ class GroupDWDesc(C.Structure):
                 ('wsm', C.c_float * 3),
                 ('S', C.c_int32), ('x_rep', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
                 ('C', C.c_int32), ('cols_per_thread', C.c_int32)]
+
+
+class PwPairDesc(C.Structure):
+    _fields_ = [('t2', C.c_void_p), ('w3p', C.c_void_p), ('res', C.c_void_p), ('w1', C.c_void_p),
+                ('b3', C.c_void_p), ('b1', C.c_void_p), ('y', C.c_void_p), ('t', C.c_void_p),
+                ('M', C.c_int32), ('CM', C.c_int32), ('CO', C.c_int32), ('CN', C.c_int32), ('act2', C.c_int32)]
 
 
 _lib = None
@@ -100,6 +107,10 @@ def lib():
         L.usot_crop_resize_u8_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 9
         L.usot_plan_add_conv_bf16.argtypes = [C.c_void_p, C.c_void_p]
         L.usot_plan_add_conv_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.usot_pw_pair_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.usot_plan_add_pw_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.usot_pw_pair_layout.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int32)] * 2
+        L.usot_pw_pair_supported.argtypes = [C.c_int] * 3
         L.usot_plan_add_cvt_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.usot_plan_add_maxpool_lp.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 7
         L.usot_conv2d_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -401,6 +412,51 @@ def conv2d_bf16(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=Non
                   groups=groups, x_gs=N * H * W_ * Cin, w_gs=Cout * KH * KW * Cin, b_gs=Cout, y_gs=N * OH * OW * Cout)
     check(lib().usot_conv2d_lp(stream(), C.byref(d), 1 if lp == torch.float16 else 0, int(out_f32)), 'usot_conv2d_lp')
     return y
+
+
+def pw_pair_pack(w, cm, co, cn, which):
+    """Filter bank `w` ([CO,CM] for which = 0, [CN,CO] for which = 1) in the fragment order of the fused
+    pointwise-pair kernel (usot_pw_pair_layout)."""
+    n = w.numel() // 8
+    row, k0 = (C.c_int32 * n)(), (C.c_int32 * n)()
+    got = lib().usot_pw_pair_layout(int(cm), int(co), int(cn), int(which), row, k0)
+    if got != n:
+        raise HipError('usot_pw_pair_layout(%d, %d, %d, %d) = %d, expected %d chunks' % (cm, co, cn, which, got, n))
+    r = torch.tensor(list(row), dtype=torch.long, device=w.device)
+    k = torch.tensor(list(k0), dtype=torch.long, device=w.device)
+    cols = k[:, None] + torch.arange(8, device=w.device)[None, :]
+    return w[r[:, None], cols].contiguous().reshape(-1)
+
+
+def pw_pair_supported(cm, co, cn):
+    return bool(lib().usot_pw_pair_supported(int(cm), int(co), int(cn)))
+
+
+def pw_pair_desc(t2, w3p, b3, res, y, w1, b1, t, M, CM, CO, CN, act2):
+    d = PwPairDesc()
+    d.t2, d.w3p, d.res, d.w1, d.b3, d.b1, d.y, d.t = t2, w3p, res, w1, b3, b1, y, t
+    d.M, d.CM, d.CO, d.CN, d.act2 = M, CM, CO, CN, act2
+    return d
+
+
+def pw_pair(t2, w3, b3, res, w1, b1, act2=ACT_RELU):
+    """Fused conv3 + residual + ReLU -> next 1x1 conv (+ act2) on low-precision [M, C] maps.
+    t2 [M,CM], w3 [CO,CM] (natural rows), b3 fp32 [CO], res [M,CO], w1 [CN,CO], b1 fp32 [CN] -> (y [M,CO], t [M,CN])."""
+    lp = t2.dtype
+    if lp not in (torch.bfloat16, torch.float16):
+        raise HipError('pw_pair takes bf16 or fp16 tensors')
+    for a in (t2, w3, res, w1):
+        _dev(a, lp)
+    _dev(b3), _dev(b1)
+    M, CM = t2.shape
+    CO, CN = w3.shape[0], w1.shape[0]
+    w3p, w1 = pw_pair_pack(w3, CM, CO, CN, 0), pw_pair_pack(w1, CM, CO, CN, 1)
+    y = torch.empty((M, CO), device=t2.device, dtype=lp)
+    t = torch.empty((M, CN), device=t2.device, dtype=lp)
+    d = pw_pair_desc(t2.data_ptr(), w3p.data_ptr(), b3.data_ptr(), res.data_ptr(), y.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                     t.data_ptr(), M, CM, CO, CN, act2)
+    check(lib().usot_pw_pair_lp(stream(), C.byref(d), 1 if lp == torch.float16 else 0), 'usot_pw_pair_lp')
+    return y, t
 
 
 def crop_resize(frame_u8, out, x0, y0, win, fill):
