@@ -49,8 +49,10 @@ const char *usot_strerror(int code);
  *   (pointer strides *_gs in elements): the three head towers, connect.py:178-207.
  *   act applies to channels [0, act_split) and act2 to [act_split, Cout) (act_split >= Cout
  *   means act everywhere): lets conf_gen|value_gen run as one Cout=512 conv.
- *   ksplit > 1 splits the K loop over `ksplit` workgroups; partials go to `ws`
- *   ([ksplit][groups][M][Cout] floats) and a second launch applies the epilogue.
+ *   ksplit > 1 splits the K loop over `ksplit` workgroups; partials go to `ws` and the LAST slice of a
+ *   tile to arrive sums them (in slice order) and applies the epilogue inside the same launch.  `ws` holds
+ *   usot_conv_ws_floats(d) floats — the slabs [ksplit][groups][M][Cout] followed by one ticket word per tile —
+ *   and must be ZERO before its first use (the kernel leaves the tickets zero again).
  *   tile: 0 = heuristic, else one of USOT_TILE_* ids (see usot_conv_tile_count).
  */
 typedef struct usot_conv_desc {

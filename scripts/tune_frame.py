@@ -41,7 +41,7 @@ def frame_us():
     if a.session:
         import bench
         sess, crops, pp = bench.open_stream(m, torch.device('cuda:0'), seed=0, size=a.size)
-        bench.run_frames(sess, crops, pp, [0.9], 3)
+        bench.run_frames(sess, crops, pp, bench.Confidences(), 3)
         p = dict(plan=sess.plan, log=sess.log)
     else:
         e._track.clear()

@@ -446,7 +446,7 @@ def test_conv_batch_heterogeneous():
         wd, bd = pack_w(w).to(DEV), b.to(DEV)
         y = torch.empty(1, oh, ow, 128, device=DEV)
         ks = 3 if i == 1 else 1
-        ws = torch.empty(ks * oh * ow * 128, device=DEV) if ks > 1 else None
+        ws = torch.zeros(ks * oh * ow * 128 + ((oh * ow + 15) // 16) * 4, device=DEV) if ks > 1 else None   # slabs + tile tickets
         descs.append(hip.conv_desc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), N=1, H=31, W=31, Cin=256,
                                    OH=oh, OW=ow, Cout=128, KH=3, KW=3, dil=dil, act=hip.ACT_RELU, tile=31 if i == 0 else 0,
                                    ksplit=ks, ws=ws.data_ptr() if ws is not None else None))

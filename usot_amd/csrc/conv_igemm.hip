@@ -22,6 +22,7 @@
 // by padding up to a big tile — see DESIGN.md "filling 1024 SIMDs at M = 961".
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <type_traits>
 #include "usot_hip.h"
@@ -30,6 +31,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 struct ConvK {
     const float *x, *w, *bias, *res;
@@ -41,6 +43,7 @@ struct ConvK {
     int groups;
     long x_gs, w_gs, b_gs, y_gs, r_gs;
     int ksplit;
+    int combine;                        // split-K: 1 = last-arriver combine inside the launch, 0 = second launch
     int M, K, KT, cchunks, MT, NT, P;   // P = OH*OW
     int vec_store;
 };
@@ -62,6 +65,93 @@ __device__ __forceinline__ float apply_act(float v, int a)
     case USOT_ACT_EXP:  return expf(v);
     case USOT_ACT_CONF: return expf(fminf(fmaxf(v, 0.0f), 4.0f));
     default:            return v;
+    }
+}
+
+// write-through (sc1) slab accesses through a buffer descriptor: the partial tiles of a split-K launch bypass the
+// issuing CU's L1 and are not left dirty in its XCD's L2, so the hand-off needs NO release fence (buffer_wbl2 writes
+// back the whole L2 slice: 1.7-6.5 us) and the reader no acquire (cdna_hip_programming.md Guideline 16, recipe R1)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const ConvK &p)
+{
+    const long bytes = ((long)p.ksplit * p.groups * p.M * p.Cout) * 4;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p.ws, 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+}
+__device__ __forceinline__ void ws_store4(const ConvK &p, long elem, f32x4 v)
+{
+    if (p.combine) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws_rsrc(p), (int)(elem * 4), 0, 16);
+    else           *(f32x4 *)(p.ws + elem) = v;
+}
+__device__ __forceinline__ void ws_store1(const ConvK &p, long elem, float v)
+{
+    if (p.combine) __hip_atomic_store(p.ws + elem, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else           p.ws[elem] = v;
+}
+
+// In-launch split-K combine.  Every k-slice workgroup has stored its partial tile to the workspace slab
+// [ks][group][M][Cout]; the LAST slice to arrive (one ticket per tile) sums the slabs in slice order — the
+// same order, hence the same bits, whichever workgroup does it — and applies bias / residual / activation.
+// Replaces the separate reduction launch (4.8 us + a kernel boundary per split layer at batch 1).
+// Protocol (cdna_hip_programming.md, Guideline 16 recipe R1 / "in-launch split-K reduction"): write-through (sc1)
+// slab stores -> every wave drains vmcnt -> barrier -> ONE lane: relaxed agent-scope fetch_add -> last arriver:
+// barrier -> sc1 slab loads.  No fences (the release form, buffer_wbl2, measured 14 us per frame SLOWER than the
+// separate reduction launch it replaces).  Placement-independent.  The ticket words live
+// behind the slabs, are zero before the first launch (the engine zero-fills the workspace) and are reset by
+// the last arriver, so every launch — and every graph replay — finds them zero.
+template <int BM, int BN>
+__device__ __forceinline__ void splitk_combine(const ConvK &p, int g, int t0, int tiles, int bm0, int bn0, int tid, int *flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        int *cnt = (int *)(p.ws + (long)p.ksplit * p.groups * p.M * p.Cout) + (g * tiles + t0);
+        const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == p.ksplit - 1;
+        if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const float *__restrict__ bg = p.bias ? p.bias + (long)g * p.b_gs : nullptr;
+    const float *__restrict__ rg = p.res ? p.res + (long)g * p.r_gs : nullptr;
+    float *__restrict__ yg = p.y + (long)g * p.y_gs;
+    const long slab = (long)p.groups * p.M * p.Cout;
+    const float *ws0 = p.ws + (long)g * p.M * p.Cout;
+    const __amdgpu_buffer_rsrc_t rs = ws_rsrc(p);
+    if (p.vec_store && (p.Cout & 3) == 0) {
+        for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+            const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
+            const int m = bm0 + row, co = bn0 + c4;
+            if (m >= p.M || co >= p.Cout) continue;
+            const long el = (long)g * p.M * p.Cout + (long)m * p.Cout + co;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < p.ksplit; ++ks)
+                v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((el + ks * slab) * 4), 0, 16));
+            if (bg) v += *(const f32x4 *)(bg + co);
+            if (rg) v += *(const f32x4 *)(rg + (long)m * p.res_cstride + p.res_coff + co);
+            const int a = co < p.act_split ? p.act : p.act2;
+            if (a != USOT_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a);
+            }
+            *(f32x4 *)(yg + (long)m * p.y_cstride + p.y_coff + co) = v;
+        }
+        return;
+    }
+    for (int idx = tid; idx < BM * BN; idx += 256) {
+        const int row = idx / BN, cc = idx - row * BN;
+        const int m = bm0 + row, c = bn0 + cc;
+        if (m >= p.M || c >= p.Cout) continue;
+        float sum = 0.f;
+        for (int ks = 0; ks < p.ksplit; ++ks) sum += __hip_atomic_load(ws0 + ks * slab + (long)m * p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bg) sum += bg[c];
+        if (rg) sum += rg[(long)m * p.res_cstride + p.res_coff + c];
+        sum = apply_act(sum, c < p.act_split ? p.act : p.act2);
+        if (p.y_nchw) {
+            const int n = m / p.P, pix = m - n * p.P;
+            yg[((long)n * p.Cout + c) * p.P + pix] = sum;
+        } else {
+            yg[(long)m * p.y_cstride + p.y_coff + c] = sum;
+        }
     }
 }
 
@@ -208,7 +298,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvBatch bt)
 
     // ---- epilogue: lane holds channels co..co+3 (quad*4 + reg) of pixel m (l15)
     if (p.ksplit > 1) {
-        float *wsg = p.ws + ((long)(ks * p.groups + g) * p.M) * p.Cout;
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int m = bm0 + (wm * TM + j) * 16 + l15;
@@ -216,14 +305,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvBatch bt)
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+                const long el = ((long)(ks * p.groups + g) * p.M + m) * p.Cout + co;
                 if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
-                    *(f32x4 *)(wsg + (long)m * p.Cout + co) = acc[i][j];
+                    ws_store4(p, el, acc[i][j]);
                 } else {
                     for (int e = 0; e < 4; ++e)
-                        if (co + e < p.Cout) wsg[(long)m * p.Cout + co + e] = acc[i][j][e];
+                        if (co + e < p.Cout) ws_store1(p, el + e, acc[i][j][e]);
                 }
             }
         }
+        if (p.combine) splitk_combine<BM, BN>(p, g, t, tiles, bm0, bn0, tid, (int *)smem);
         return;
     }
     const float *__restrict__ bg = p.bias ? p.bias + (long)g * p.b_gs : nullptr;
@@ -496,7 +587,6 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
     }
     // ---- epilogue (same as v1)
     if (p.ksplit > 1) {
-        float *wsg = p.ws + ((long)(ks * p.groups + g) * p.M) * p.Cout;
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int m = bm0 + (wm * TM + j) * 16 + l15;
@@ -504,14 +594,16 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+                const long el = ((long)(ks * p.groups + g) * p.M + m) * p.Cout + co;
                 if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
-                    *(f32x4 *)(wsg + (long)m * p.Cout + co) = acc[i][j];
+                    ws_store4(p, el, acc[i][j]);
                 } else {
                     for (int e = 0; e < 4; ++e)
-                        if (co + e < p.Cout) wsg[(long)m * p.Cout + co + e] = acc[i][j][e];
+                        if (co + e < p.Cout) ws_store1(p, el + e, acc[i][j][e]);
                 }
             }
         }
+        if (p.combine) splitk_combine<BM, BN>(p, g, t0, tiles, bm0, bn0, tid, (int *)smem_all);
         return;
     }
     const float *__restrict__ bg = p.bias ? p.bias + (long)g * p.b_gs : nullptr;
@@ -814,7 +906,6 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
     if constexpr (TM * TN == 1) acc[0][0] += acc2;
 
     if (p.ksplit > 1) {
-        float *wsg = p.ws + ((long)(ks * p.groups + g) * p.M) * p.Cout;
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int m = bm0 + (wm * TM + j) * 16 + l15;
@@ -822,14 +913,16 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+                const long el = ((long)(ks * p.groups + g) * p.M + m) * p.Cout + co;
                 if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
-                    *(f32x4 *)(wsg + (long)m * p.Cout + co) = acc[i][j];
+                    ws_store4(p, el, acc[i][j]);
                 } else {
                     for (int e = 0; e < 4; ++e)
-                        if (co + e < p.Cout) wsg[(long)m * p.Cout + co + e] = acc[i][j][e];
+                        if (co + e < p.Cout) ws_store1(p, el + e, acc[i][j][e]);
                 }
             }
         }
+        if (p.combine) splitk_combine<BM, BN>(p, g, t0, tiles, bm0, bn0, tid, (int *)smem);
         return;
     }
     const float *__restrict__ bg = p.bias ? p.bias + (long)g * p.b_gs : nullptr;
@@ -1023,7 +1116,9 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d)
 extern "C" int64_t usot_conv_ws_floats(const usot_conv_desc *d)
 {
     if (!d || d->ksplit <= 1) return 0;
-    return (int64_t)d->ksplit * d->groups * d->N * d->OH * d->OW * d->Cout;
+    /* slabs + one ticket word per (group, tile) of the smallest tile shape (16 x 32) */
+    const int64_t m = (int64_t)d->N * d->OH * d->OW;
+    return (int64_t)d->ksplit * d->groups * m * d->Cout + (int64_t)d->groups * ((m + 15) / 16) * ((d->Cout + 31) / 32);
 }
 
 namespace {
@@ -1053,6 +1148,7 @@ int fill_params(const usot_conv_desc *d, ConvK &p)
     p.groups = d->groups;
     p.x_gs = d->x_gs; p.w_gs = d->w_gs; p.b_gs = d->b_gs; p.y_gs = d->y_gs; p.r_gs = d->r_gs;
     p.ksplit = ksplit;
+    { static const bool two = getenv("USOT_SPLITK_LAUNCH") != nullptr; p.combine = two ? 0 : 1; }
     p.P = d->OH * d->OW;
     p.M = d->N * p.P;
     p.K = d->KH * d->KW * d->Cin;
@@ -1111,9 +1207,9 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(tc.fn, dim3((unsigned)blocks), dim3(tc.threads), lds, s, bt);
     if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
-    long most = 0;                                // ONE reduction launch for every split problem of the batch
+    long most = 0;                                // probe path: ONE reduction launch for every split problem of the batch
     for (int i = 0; i < n; ++i)
-        if (bt.p[i].ksplit > 1) {
+        if (bt.p[i].ksplit > 1 && !bt.p[i].combine) {
             const long total = (long)bt.p[i].M * bt.p[i].Cout * bt.p[i].groups;
             if (total > most) most = total;
         }

@@ -254,8 +254,9 @@ class Builder:
             ksplit = 1 if tile != ttile else ksplit
             ttile = tile
         ws = None
-        if ksplit > 1:
-            ws = self.buf(ksplit * groups * m * cout)
+        if ksplit > 1:            # partial slabs + one ticket per tile (usot_conv_ws_floats), tickets zero before first use
+            ws = self.buf(ksplit * groups * m * cout + groups * ((m + 15) // 16) * ((cout + 31) // 32))
+            ws.zero_()
         d = hip.conv_desc(x.data_ptr(), pc.w.data_ptr() + row0 * k * 4, pc.b.data_ptr() + row0 * 4, y.data_ptr(),
                           N=n, H=h, W=w, Cin=pc.cin, OH=oh, OW=ow, Cout=cout, KH=pc.kh, KW=pc.kw,
                           stride=pc.stride, pad=pc.pad, dil=pc.dil,

@@ -219,8 +219,9 @@ def conv2d(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, ac
     shape = (N, Cout, OH, OW) if y_nchw else (N, OH, OW, Cout)
     y = torch.empty(shape, device=x.device, dtype=torch.float32)
     ws = None
-    if ksplit > 1:
-        ws = torch.empty(ksplit * N * OH * OW * Cout, device=x.device, dtype=torch.float32)
+    if ksplit > 1:        # slabs + tile tickets (usot_conv_ws_floats); the tickets must start at zero
+        ws = torch.zeros(ksplit * N * OH * OW * Cout + ((N * OH * OW + 15) // 16) * ((Cout + 31) // 32), device=x.device,
+                         dtype=torch.float32)
     d = conv_desc(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                   N=N, H=H, W=W_, Cin=Cin, OH=OH, OW=OW, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad,
                   dil=dil, res=res.data_ptr() if res is not None else None, act=act, tile=tile,
