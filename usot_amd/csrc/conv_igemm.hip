@@ -962,35 +962,6 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
     }
 }
 
-// split-K second pass: sum the partial slabs, then the same epilogue.
-__global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvBatch bt)
-{
-    // blockIdx.y = problem of the batched launch (problems that were not split have no work here)
-    const ConvK &p = bt.p[blockIdx.y];
-    if (p.ksplit <= 1) return;
-    const long per_g = (long)p.M * p.Cout;
-    const long total = per_g * p.groups;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(idx / per_g);
-        const long r = idx - (long)g * per_g;
-        const int m = (int)(r / p.Cout), c = (int)(r - (long)m * p.Cout);
-        float s = 0.f;
-        for (int ks = 0; ks < p.ksplit; ++ks)
-            s += p.ws[((long)(ks * p.groups + g) * p.M + m) * p.Cout + c];
-        if (p.bias) s += p.bias[(long)g * p.b_gs + c];
-        if (p.res) s += p.res[(long)g * p.r_gs + (long)m * p.res_cstride + p.res_coff + c];
-        s = apply_act(s, c < p.act_split ? p.act : p.act2);
-        float *yg = p.y + (long)g * p.y_gs;
-        if (p.y_nchw) {
-            const int n = m / p.P, pix = m - n * p.P;
-            yg[((long)n * p.Cout + c) * p.P + pix] = s;
-        } else {
-            yg[(long)m * p.y_cstride + p.y_coff + c] = s;
-        }
-    }
-}
-
 struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int threads; int depth; };
 
 #define TILE(bm, bn, wm, wn) { bm, bn, 32, 2, 1, conv_igemm_f32<bm, bn, wm, wn>, 256, 1 }
@@ -1148,7 +1119,7 @@ int fill_params(const usot_conv_desc *d, ConvK &p)
     p.groups = d->groups;
     p.x_gs = d->x_gs; p.w_gs = d->w_gs; p.b_gs = d->b_gs; p.y_gs = d->y_gs; p.r_gs = d->r_gs;
     p.ksplit = ksplit;
-    { static const bool two = getenv("USOT_SPLITK_LAUNCH") != nullptr; p.combine = two ? 0 : 1; }
+    p.combine = 1;
     p.P = d->OH * d->OW;
     p.M = d->N * p.P;
     p.K = d->KH * d->KW * d->Cin;
@@ -1207,17 +1178,6 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(tc.fn, dim3((unsigned)blocks), dim3(tc.threads), lds, s, bt);
     if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
-    long most = 0;                                // probe path: ONE reduction launch for every split problem of the batch
-    for (int i = 0; i < n; ++i)
-        if (bt.p[i].ksplit > 1 && !bt.p[i].combine) {
-            const long total = (long)bt.p[i].M * bt.p[i].Cout * bt.p[i].groups;
-            if (total > most) most = total;
-        }
-    if (most > 0) {
-        const int gb = (int)((most + 255) / 256 > 4096 ? 4096 : (most + 255) / 256);
-        hipLaunchKernelGGL(conv_splitk_epilogue, dim3(gb, n), dim3(256), 0, s, bt);
-        if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
-    }
     return USOT_OK;
 }
 
