@@ -18,6 +18,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -89,12 +90,16 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 // every DMA in flight); used by the 8-wavefront 256x128 tiles, which also need 25 % fewer L1/LDS
 // bytes per MFMA than 128x128 (a 128x128x64 step moves 32 KB per 512 MFMA cycles = 64 B/clk/CU,
 // the whole vector-L1 rate).
-template <int BM, int BN, int WM, int WN, bool F16, int D = 1, int ST = 2>   // D = 0: LDS-DMA staging (below)
+// MF = MFMA tile edge: 16 (v_mfma_f32_16x16x32) or 32 (v_mfma_f32_32x32x16: twice the FLOPs per instruction for the
+// same two 16-byte fragments, i.e. half the ds_read_b128 traffic per FLOP, and a higher issue ceiling — 2.38 vs
+// 2.08 PFLOP/s in the MFMA microbenchmarks of MI355X_MICROARCH.md)
+template <int BM, int BN, int WM, int WN, bool F16, int D = 1, int ST = 2, int MF = 16>   // D = 0: LDS-DMA staging (below)
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm_bf16(const ConvB pin)
 {
     ConvB p = pin;
     static_assert(WM * WN == 4 || WM * WN == 8 || WM * WN == 16, "4, 8 or 16 wavefronts");
     static_assert(ST == 2 || (ST == 3 && D == 0), "3 stages need the LDS-DMA path");
+    static_assert(MF == 16 || (MF == 32 && (BM / WM) % 32 == 0 && (BN / WN) % 32 == 0), "32x32 MFMA tiles");
     constexpr int NTHR = WM * WN * 64;
     constexpr int RPP = NTHR / 8;             // tile rows one staging pass covers
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -203,8 +208,65 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 32x32 MFMA form: the same TN x TM x 4 registers seen as (TN/2) x (TM/2) tiles of 16.  Tile (i, j), register
+    // group rg (4 consecutive registers) of lane (l31 = lane & 31, h = lane >> 5) = channels i*32 + rg*8 + h*4 .. +3
+    // of pixel j*32 + l31 (cdna_hip_programming.md section 3: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
+    constexpr int TN2 = MF == 32 ? TN / 2 : 1, TM2 = MF == 32 ? TM / 2 : 1;
+    f32x16 acc32[TN2][TM2];
+    if constexpr (MF == 32) {
+#pragma unroll
+        for (int i = 0; i < TN2; ++i)
+#pragma unroll
+            for (int j = 0; j < TM2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+    }
+    const int l31 = lane & 31, hh = lane >> 5;
+    // every 4-register piece of this wave's accumulators: f(pixel row in the wave's block, channel in the wave's block, value)
+    auto for_each_piece = [&](auto f) {
+        if constexpr (MF == 32) {
+#pragma unroll
+            for (int j = 0; j < TM2; ++j)
+#pragma unroll
+                for (int i = 0; i < TN2; ++i)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        f(j * 32 + l31, i * 32 + rg * 8 + hh * 4,
+                          f32x4{acc32[i][j][rg * 4], acc32[i][j][rg * 4 + 1], acc32[i][j][rg * 4 + 2], acc32[i][j][rg * 4 + 3]});
+        } else {
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int i = 0; i < TN; ++i) f(j * 16 + l15, i * 16 + quad * 4, acc[i][j]);
+        }
+    };
 
     auto mma_tile = [&](int cur) {
+        if constexpr (MF == 32) {
+            const u32x4 *cX = sX + (cur * BM + wm * TM * 16 + l31) * LDC;
+            const u32x4 *cW = sW + (cur * BN + wn * TN * 16 + l31) * LDC;
+            const int sq = swz(l31);                   // rows differ from l31 by multiples of 32
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {           // four 16-deep slices of the 64-deep k-tile
+                u32x4 wf[TN2], xf[TM2];
+#pragma unroll
+                for (int i = 0; i < TN2; ++i) wf[i] = cW[i * 32 * LDC + ((ks * 2 + hh) ^ sq)];
+#pragma unroll
+                for (int j = 0; j < TM2; ++j) xf[j] = cX[j * 32 * LDC + ((ks * 2 + hh) ^ sq)];
+#pragma unroll
+                for (int i = 0; i < TN2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM2; ++j) {
+                        if constexpr (F16)
+                            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[i]),
+                                                                                 __builtin_bit_cast(f16x8, xf[j]), acc32[i][j], 0, 0, 0);
+                        else
+                            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[i]),
+                                                                                  __builtin_bit_cast(bf16x8, xf[j]), acc32[i][j], 0, 0, 0);
+                    }
+            }
+            return;
+        }
         const u32x4 *cX = sX + (cur * BM + wm * TM * 16 + l15) * LDC;
         const u32x4 *cW = sW + (cur * BN + wn * TN * 16 + l15) * LDC;
         const int sq = swz(l15);                       // rows differ from l15 by multiples of 16
@@ -372,11 +434,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
             if (eh > 0) __syncthreads();             // the previous slice has been read out
             if ((wn * TN * 16) / BNH == eh) {
                 const int cl0 = wn * TN * 16 - eh * BNH;
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-#pragma unroll
-                    for (int i = 0; i < TN; ++i)
-                        *(f32x4 *)(sO + ((wm * TM + j) * 16 + l15) * OP + cl0 + i * 16 + quad * 4) = acc[i][j];
+                for_each_piece([&](int prow, int pch, f32x4 v) { *(f32x4 *)(sO + (wm * TM * 16 + prow) * OP + cl0 + pch) = v; });
             }
             __syncthreads();
             const int co = bn0 + eh * BNH + oc * 8;
@@ -424,36 +482,30 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
         return;
     }
 
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = bm0 + (wm * TM + j) * 16 + l15;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
-            if (co >= p.Cout) continue;
-            f32x4 v = acc[i][j];
-            if (p.bias) v += *(const f32x4 *)(p.bias + co);
-            if (p.res) {
-                const u32x2 r = *(const u32x2 *)(p.res + (long)m * p.Cout + co);
-                v[0] += unpack_lp<F16>(r[0] & 0xffffu); v[1] += unpack_lp<F16>(r[0] >> 16);
-                v[2] += unpack_lp<F16>(r[1] & 0xffffu); v[3] += unpack_lp<F16>(r[1] >> 16);
-            }
-            const int av = co < p.act_split ? p.act : p.act2;
-            if (av != USOT_ACT_NONE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_lp(v[e], av);
-            }
-            if (p.out_f32) {
-                *(f32x4 *)((float *)p.y + (long)m * p.Cout + co) = v;
-            } else {
-                u32x2 o;
-                o[0] = pack_lp<F16>(v[0]) | (pack_lp<F16>(v[1]) << 16);
-                o[1] = pack_lp<F16>(v[2]) | (pack_lp<F16>(v[3]) << 16);
-                *(u32x2 *)(p.y + (long)m * p.Cout + co) = o;
-            }
+    for_each_piece([&](int prow, int pch, f32x4 v) {
+        const int m = bm0 + wm * TM * 16 + prow;
+        const int co = bn0 + wn * TN * 16 + pch;
+        if (m >= p.M || co >= p.Cout) return;
+        if (p.bias) v += *(const f32x4 *)(p.bias + co);
+        if (p.res) {
+            const u32x2 r = *(const u32x2 *)(p.res + (long)m * p.Cout + co);
+            v[0] += unpack_lp<F16>(r[0] & 0xffffu); v[1] += unpack_lp<F16>(r[0] >> 16);
+            v[2] += unpack_lp<F16>(r[1] & 0xffffu); v[3] += unpack_lp<F16>(r[1] >> 16);
         }
-    }
+        const int av = co < p.act_split ? p.act : p.act2;
+        if (av != USOT_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_lp(v[e], av);
+        }
+        if (p.out_f32) {
+            *(f32x4 *)((float *)p.y + (long)m * p.Cout + co) = v;
+        } else {
+            u32x2 o;
+            o[0] = pack_lp<F16>(v[0]) | (pack_lp<F16>(v[1]) << 16);
+            o[1] = pack_lp<F16>(v[2]) | (pack_lp<F16>(v[3]) << 16);
+            *(u32x2 *)(p.y + (long)m * p.Cout + co) = o;
+        }
+    });
 }
 
 struct TileB { int bm, bn; void (*fn)(const ConvB); void (*fn16)(const ConvB); int threads, stages; };
@@ -461,6 +513,7 @@ struct TileB { int bm, bn; void (*fn)(const ConvB); void (*fn16)(const ConvB); i
 #define TB2(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 2>, conv_igemm_bf16<bm, bn, wm, wn, true, 2>, 256, 2 }
 #define TB0(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0>, conv_igemm_bf16<bm, bn, wm, wn, true, 0>, 256, 2 }
 #define TB08(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0>, conv_igemm_bf16<bm, bn, wm, wn, true, 0>, wm * wn * 64, 2 }
+#define TB32(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0, 2, 32>, conv_igemm_bf16<bm, bn, wm, wn, true, 0, 2, 32>, wm * wn * 64, 2 }
 #define TB3(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0, 3>, conv_igemm_bf16<bm, bn, wm, wn, true, 0, 3>, wm * wn * 64, 3 }
 const TileB kTilesB[] = {
     TB(128, 128, 2, 2),   // 1
@@ -488,6 +541,12 @@ const TileB kTilesB[] = {
     TB08(256, 128, 4, 4), // 23: 16 wavefronts x (64 x 32)
     TB08(128, 256, 2, 8), // 24: 16 wavefronts x (64 x 32)
     TB08(128, 128, 4, 4), // 25: 16 wavefronts x (32 x 32)
+    TB32(256, 256, 4, 4), // 26: as 21 on v_mfma_f32_32x32x16 (2 x 2 tiles of 32 per wave)
+    TB32(256, 256, 4, 2), // 27: 8 wavefronts x (64 pixels x 128 channels), 32x32 MFMA
+    TB32(256, 256, 2, 4), // 28: 8 wavefronts x (128 x 64)
+    TB32(128, 128, 4, 4), // 29: as 25 (one 32x32 tile per wave)
+    TB32(256, 128, 4, 2), // 30: 8 wavefronts x (64 x 64)
+    TB32(128, 256, 2, 4), // 31
 };
 constexpr int kNumTilesB = sizeof(kTilesB) / sizeof(kTilesB[0]);
 
