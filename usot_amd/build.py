@@ -12,7 +12,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, 
 # per-file flags.  xcorr.hip: hipcc's SLP vectoriser packs the depthwise FMAs into v_pk_fma_f32 pairs, which
 # on gfx950 run at the scalar-FMA rate but need operand pairs in adjacent registers: the LDS-DMA GroupDW
 # kernel goes from 109 VGPRs to 256 + spills with it
-FILE_FLAGS = {'xcorr.hip': ['-fno-slp-vectorize']}
+FILE_FLAGS = {'xcorr.hip': ['-fno-slp-vectorize'],
+              'conv_igemm.hip': ['-std=c++20']}      # templated lambda over the producer's register buffers
 
 
 def _hipcc():

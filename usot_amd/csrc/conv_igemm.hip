@@ -776,12 +776,13 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, D >= 2 ? 1 : 0>;
-        using I2 = std::integral_constant<int, D >= 3 ? 2 : 0>;
         // Every load below is unconditional (past the last tile the pointers stop advancing and the
         // last tile is simply fetched again, never stored): the compiler can then count exactly
         // how many younger loads are in flight and waits with vmcnt(N > 0) instead of draining.
         // tiles 0 and 1 go to stages 0 and 1 before the first barrier; tiles 2 .. D+1 stay in
-        // flight in register buffers 0 .. D-1 (tile t+2 lives in buffer t % D)
+        // flight in register buffers 0 .. D-1 (tile t+2 lives in buffer t % D).  D up to 6: at batch 1 both
+        // operands of a layer are cold (filters from the Infinity Cache / HBM once per frame, the activation
+        // map from the other XCDs' write-backs), a round trip is 2-3 k-steps long.
         int lt = 0;                                   // next tile to fetch
         auto load_next = [&](auto dc) { load_tile(dc, lt + 1 < nt); ++lt; };
         if constexpr (D == 1) {
@@ -793,9 +794,11 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
             store_tile(I0{}, 0);
             if (nt > 1) store_tile(I1{}, 1);
         }
-        load_next(I0{});
-        if constexpr (D >= 2) load_next(I1{});
-        if constexpr (D >= 3) load_next(I2{});
+        auto each_buffer = [&](auto f) {              // f(buffer index constant) for buffers 0 .. D-1, in order
+            [&]<int... Is>(std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+            (std::make_integer_sequence<int, D>{});
+        };
+        each_buffer([&](auto dc) { load_next(dc); });
         __syncthreads();
         int st2 = 2;                                  // stage that receives tile t+2
 #ifdef USOT_TRACE   // scripts/trace_kstep.py: s_memtime stamps of one producer wave into the (unused) split-K workspace
@@ -815,13 +818,10 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
             USOT_STAMP(7, t);
         };
         int t = 0;
-        for (; t + D <= nt; t += D) {
-            step(I0{}, t);
-            if constexpr (D >= 2) step(I1{}, t + 1);
-            if constexpr (D >= 3) step(I2{}, t + 2);
-        }
-        if constexpr (D >= 2) { if (t < nt) { step(I0{}, t); ++t; } }
-        if constexpr (D >= 3) { if (t < nt) { step(I1{}, t); ++t; } }
+        for (; t + D <= nt; t += D) each_buffer([&](auto dc) { step(dc, t + decltype(dc)::value); });
+        each_buffer([&](auto dc) {                    // tail: t is a multiple of D here, buffers continue 0, 1, ...
+            if (t < nt) { step(dc, t); ++t; }
+        });
         return;
     }
 
@@ -1031,6 +1031,8 @@ const TileCfg kTiles[] = {
     TILE10(64, 64, 2, 2, 32, 2, 8),   // 58
     TILE10(32, 128, 2, 2, 64, 2, 8),  // 59
     TILE10(64, 32, 2, 2, 64, 2, 8),   // 60
+    // (D = 4 and 6 variants of 53-60 were tried inside the frame graph, scripts/tune_frame.py: no layer got faster —
+    //  e.g. layer3's 3x3 908 us/frame at D = 2, 909 at D = 4 and 6 — so a batch-1 k-step is not waiting for loads)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1168,7 +1170,7 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
     const size_t lds = (size_t)tc.ksw * tc.stages * (tc.bm + tc.bn) * (tc.bk + 4) * sizeof(float);
     if (lds > 64 * 1024) {
-        static bool raised[64] = {false};
+        static bool raised[128] = {false};
         if (!raised[tile]) {
             if (hipFuncSetAttribute((const void *)tc.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return USOT_ELAUNCH;
