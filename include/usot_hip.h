@@ -273,6 +273,13 @@ int usot_stem_pool_f32(void *stream, const float *x, const float *wfrag, const f
                        int N, int H, int W, int OH, int OW, int PH, int PW);
 int usot_plan_add_stem_pool(void *plan, const float *x, const float *wfrag, const float *bias, float *y,
                             int N, int H, int W, int OH, int OW, int PH, int PW);
+/* the same with the crop's address taken from DEVICE memory at run time: xptr_dev[0..1] = low / high half of the
+ * address (0 = use x).  A captured frame can then read any resident crop without a copy into a baked input
+ * buffer; the session's first kernel stashes the address there from the host's control block. */
+int usot_stem_pool_ind_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
+                           int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev);
+int usot_plan_add_stem_pool_ind(void *plan, const float *x, const float *wfrag, const float *bias, float *y,
+                                int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev);
 int usot_plan_add_stem(void *plan, const float *x, const float *w, const float *bias, float *y,
                        int N, int H, int W, int OH, int OW);
 int usot_plan_add_maxpool(void *plan, const float *x, float *y, int N, int H, int W, int C,
@@ -290,7 +297,8 @@ int usot_plan_add_decode(void *plan, const float *cls, const float *cls_mem, con
                          const double *tsz_dev, float *roi_out);
 /* the same for up to four banks of different row length (one launch): the session's raw memory
  * features and their three cached encodings share the row indices.  stash_next (gather only, may
- * be NULL): idx_dev[n_rows] is copied to stash_next[0], so that a later scatter of the same frame
+ * be NULL): idx_dev[n_rows .. n_rows+2] are copied to stash_next[0..2] (the append row, and two free words the
+ * session uses for the crop address of usot_plan_add_stem_pool_ind), so that a later scatter of the same frame
  * can take its row from device memory while the host already rewrites the control block. */
 int usot_rows_copy_multi_f32(void *stream, int nseg, const float *const *src, const int32_t *idx_dev,
                              float *const *dst, int n_rows, const int32_t *row_len, int scatter,

@@ -227,3 +227,22 @@ def test_session_honours_mem_queue_size(net):
             with pytest.raises(hip.HipError):
                 sess.submit(crops[0], [0, 0, 0, 0, 0], (63.5, 63.5))
     assert out[5].shape == out[7].shape
+
+
+def test_resident_crop_is_read_in_place(net):
+    """A float32 crop already on the device is not copied into the session's input buffer: its address travels in
+    the control block and the frame graph's first convolution reads it in place.  Same results as the copying
+    paths (host tensor; non-contiguous device view), frame after frame, with the crop at odd byte offsets."""
+    picks = [[0, 0, 0, 0, 0], [0, 1, 0, 1, 0], [2, 1, 0, 2, 1]]
+    sess, crops = _open(net, 5)
+    want = [sess.frame(crops[i].cpu(), picks[i], (63.5, 63.5)) for i in range(3)]          # host -> pinned -> copy
+    sess, crops = _open(net, 5)
+    sentinel = float(sess.x.abs().sum())
+    got = [sess.frame(crops[i], picks[i], (63.5, 63.5)) for i in range(3)]                  # in place (slices of a batch)
+    assert float(sess.x.abs().sum()) == sentinel          # the session's own buffer was never written
+    sess, crops = _open(net, 5)
+    wide = torch.zeros(4, 3, 255, 300, device=crops.device)
+    wide[..., :255] = crops
+    view = [sess.frame(wide[i, :, :, :255], picks[i], (63.5, 63.5)) for i in range(3)]      # strided view -> copy
+    np.testing.assert_array_equal(np.array(got), np.array(want))
+    np.testing.assert_array_equal(np.array(view), np.array(want))

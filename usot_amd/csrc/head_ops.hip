@@ -228,12 +228,12 @@ struct RowsK {
     float *dst[4];
     int row_len4[4];
     int nseg, n_rows, scatter;
-    int *stash;        // gather only: idx[n_rows] is copied here (see usot_hip.h)
+    int *stash;        // gather only: idx[n_rows .. n_rows+2] are copied here (see usot_hip.h)
 };
 __global__ __launch_bounds__(256) void rows_copy_multi_kernel(const RowsK k, const int *__restrict__ idx)
 {
     const int sgm = blockIdx.y;
-    if (k.stash && blockIdx.x == 0 && sgm == 0 && threadIdx.x == 0) k.stash[0] = idx[k.n_rows];
+    if (k.stash && blockIdx.x == 0 && sgm == 0 && threadIdx.x < 3) k.stash[threadIdx.x] = idx[k.n_rows + threadIdx.x];
     const int rl = k.row_len4[sgm];
     const f32x4 *__restrict__ src = (const f32x4 *)k.src[sgm];
     f32x4 *__restrict__ dst = (f32x4 *)k.dst[sgm];

@@ -111,8 +111,8 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
             rc = usot_maxpool3x3s2_lp(s, op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6]);
             break;
         case K_STEMP:
-            rc = usot_stem_pool_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], (float *)op.p[3],
-                                    op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6]);
+            rc = usot_stem_pool_ind_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], (float *)op.p[3],
+                                        op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], (const int32_t *)op.p[4]);
             break;
         case K_THIN: {
             usot_conv_desc tmp[4];
@@ -258,9 +258,15 @@ extern "C" int usot_plan_add_cvt_lp(void *plan, const float *src, void *dst, int
 extern "C" int usot_plan_add_stem_pool(void *plan, const float *x, const float *wfrag, const float *bias, float *y,
                                        int N, int H, int W, int OH, int OW, int PH, int PW)
 {
+    return usot_plan_add_stem_pool_ind(plan, x, wfrag, bias, y, N, H, W, OH, OW, PH, PW, nullptr);
+}
+
+extern "C" int usot_plan_add_stem_pool_ind(void *plan, const float *x, const float *wfrag, const float *bias, float *y,
+                                           int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev)
+{
     Op *op = push(plan, K_STEMP);
     if (!op) return USOT_ESTATE;
-    op->p[0] = x; op->p[1] = wfrag; op->p[2] = bias; op->p[3] = y;
+    op->p[0] = x; op->p[1] = wfrag; op->p[2] = bias; op->p[3] = y; op->p[4] = xptr_dev;
     op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = OH; op->i[4] = OW; op->i[5] = PH; op->i[6] = PW;
     return USOT_OK;
 }

@@ -157,8 +157,15 @@ constexpr int FP_OP = 64 + 4;                        // stem-tile LDS row pitch 
 
 __global__ __launch_bounds__(256) void stem_pool_f32_kernel(
     const float *__restrict__ x, const float *__restrict__ wfrag, const float *__restrict__ bias,
-    float *__restrict__ y, int H, int W, int OH, int OW, int PH, int PW)
+    float *__restrict__ y, int H, int W, int OH, int OW, int PH, int PW, const int *__restrict__ xptr)
 {
+    // xptr != NULL: the crop's address comes from DEVICE memory (two ints: low / high half), written earlier in the
+    // same graph from the host's control block — a captured frame can then read ANY resident crop, no copy into a
+    // baked input buffer (a null address keeps the baked `x`)
+    if (xptr) {
+        const unsigned long long a = ((unsigned long long)(unsigned)xptr[1] << 32) | (unsigned)xptr[0];
+        if (a) x = (const float *)a;
+    }
     __shared__ float patch[3 * FP_I * FP_IP + 8];
     __shared__ __attribute__((aligned(16))) float stile[FP_NBLK * 16 * FP_OP];
     const int n = blockIdx.z;
@@ -268,15 +275,25 @@ extern "C" int usot_maxpool3x3s2_f32(void *stream, const float *x, float *y,
 /* Fused fp32 stem + max-pool (frame plans: the stem map itself is not needed).  wfrag = the BN-folded
  * filter bank as MFMA A operands [4 channel blocks][48 k-steps][64 lanes] (usot_amd/engine.py:
  * pack_stem_f32), bias fp32[64], y NHWC [N][PH][PW][64]. */
+extern "C" int usot_stem_pool_ind_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
+                                      int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev);
+
 extern "C" int usot_stem_pool_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
                                   int N, int H, int W, int OH, int OW, int PH, int PW)
+{
+    return usot_stem_pool_ind_f32(stream, x, wfrag, bias, y, N, H, W, OH, OW, PH, PW, nullptr);
+}
+
+extern "C" int usot_stem_pool_ind_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
+                                      int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev)
 {
     if (!x || !wfrag || !bias || !y || N <= 0 || N > 65535 || H < 7 || W < 7) return USOT_EINVAL;
     if (OH != (H - 7) / 2 + 1 || OW != (W - 7) / 2 + 1) return USOT_EINVAL;
     if (PH != (OH + 2 - 3) / 2 + 1 || PW != (OW + 2 - 3) / 2 + 1) return USOT_EINVAL;
     if (((uintptr_t)y % 16) || ((uintptr_t)bias % 16)) return USOT_EINVAL;
     dim3 grid(usot_cdiv(PW, FP_P), usot_cdiv(PH, FP_P), N);
-    hipLaunchKernelGGL(stem_pool_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, wfrag, bias, y, H, W, OH, OW, PH, PW);
+    hipLaunchKernelGGL(stem_pool_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, wfrag, bias, y, H, W, OH, OW, PH, PW,
+                       (const int *)xptr_dev);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }

@@ -318,7 +318,7 @@ class Builder:
         return outs
 
     # ---- a1-a4: backbone + neck: x NCHW [n,3,s,s] -> xf NHWC [n,hf,wf,256]
-    def backbone(self, x, n, size, need_stem=True):
+    def backbone(self, x, n, size, need_stem=True, xptr_dev=None):
         """need_stem=False (frame plans): stem + max-pool in one MFMA kernel, the stem map is never stored;
         feature_extractor() (modules.py:137-151 returns it as x_) keeps the two-kernel form."""
         W, L = self.W, hip.lib()
@@ -333,8 +333,11 @@ class Builder:
             hip.check(L.usot_plan_add_maxpool(self.plan.h, hip.ptr(s0), hip.ptr(p0), n, oh, oh, 64, ph, ph), 'plan_add_maxpool')
         else:
             wf = W.stem_f32()
-            hip.check(L.usot_plan_add_stem_pool(self.plan.h, hip.ptr(x), hip.ptr(wf), hip.ptr(W.stem_b), hip.ptr(p0),
-                                                n, size, size, oh, oh, ph, ph), 'plan_add_stem_pool')
+            # xptr_dev (device int32[2], optional): the crop's address is read from device memory at run time
+            hip.check(L.usot_plan_add_stem_pool_ind(self.plan.h, hip.ptr(x), hip.ptr(wf), hip.ptr(W.stem_b), hip.ptr(p0),
+                                                    n, size, size, oh, oh, ph, ph,
+                                                    C.c_void_p(xptr_dev.data_ptr()) if xptr_dev is not None else None),
+                      'plan_add_stem_pool')
             self.plan.keep += [wf]
         self.plan.keep += [x]
         cur, h = p0, ph
@@ -844,11 +847,11 @@ class Session:
         # kernels address directly: the 64-byte per-frame upload/download needs no copy
         # kernels at all — the host writes ctl, launches the graph, synchronises, reads out.
         # layout: [0:16] target size (2 doubles), [48:56] frame tag (double), [64:] N_q gather rows +
-        # 1 scatter row (int32)
+        # 1 scatter row + the crop's device address as two int32 (0 = the session's own input buffer)
         self.nq = int(getattr(p, 'mem_queue_size', 7))
         if self.nq < 4:
             raise hip.HipError('mem_queue_size must be >= 4 (init, flip, >= 1 sampled, last); got %d' % self.nq)
-        self.ctl = torch.zeros(64 + 4 * (self.nq + 1 + (self.nq + 1) % 2), dtype=torch.uint8).pin_memory()
+        self.ctl = torch.zeros(64 + 4 * (self.nq + 3 + (self.nq + 3) % 2), dtype=torch.uint8).pin_memory()
         self.out8 = torch.zeros(16, dtype=torch.float64).pin_memory()   # 8 results + completion tag
         self.x_host = torch.zeros(1, 3, self.size, self.size).pin_memory()
         self._x_host_np = self.x_host.numpy()
@@ -863,7 +866,7 @@ class Session:
         self.x.zero_()                      # the warm-up replay below reads it (torch.empty memory may decode as NaN)
         self.mem_in = bld.buf(1)            # heads() only asks whether there is a memory branch
         tsz_dev = self.ctl[0:56].view(torch.float64)          # [0:2] target size, [6] frame tag
-        idx_dev = self.ctl[64:64 + 4 * (nq + 1)].view(torch.int32)   # N_q gather rows + 1 scatter row
+        idx_dev = self.ctl[64:64 + 4 * (nq + 3)].view(torch.int32)   # N_q gather rows + 1 scatter row + crop address (lo, hi)
         self._ctl_f64 = tsz_dev.numpy()
         self._ctl_i32 = idx_dev.numpy()
         self._out_np = self.out8.numpy()
@@ -874,7 +877,9 @@ class Session:
         # already writing the next frame's control block
         self.slot_dev = torch.zeros(4, dtype=torch.int32, device=e.device)
         self._rows_multi(pl, self.bank_enc, idx_dev, mk, nq, scatter=0, stash=self.slot_dev)
-        xf, hf = bld.backbone(self.x, 1, self.size, need_stem=False)
+        # slot_dev[0] = the append row, slot_dev[1:3] = the crop's address: both stashed from the control block by the
+        # gather above (the first kernel of the frame)
+        xf, hf = bld.backbone(self.x, 1, self.size, need_stem=False, xptr_dev=self.slot_dev[1:3])
         bbox, cls2, S = bld.heads(xf, 1, hf, self.zk, self.mem_in, nq, mk=mk, mem_lane=2)
         assert S == self.S
         self.roi = bld.buf(5)
@@ -919,13 +924,14 @@ class Session:
             self.bank_enc[g][lo:hi].copy_(enc[g])
         torch.cuda.current_stream().synchronize()
 
-    def _set_ctl(self, rows, slot, tsz):
+    def _set_ctl(self, rows, slot, tsz, xaddr=0):
         self._ctl_f64[0] = float(tsz[0])
         self._ctl_f64[1] = float(tsz[1])
         rows = list(rows)
         if len(rows) != self.nq:
             raise hip.HipError('%d memory rows for a session built for mem_queue_size = %d' % (len(rows), self.nq))
-        self._ctl_i32[:] = rows + [slot]
+        lo, hi = int(xaddr) & 0xffffffff, (int(xaddr) >> 32) & 0xffffffff
+        self._ctl_i32[:] = rows + [slot, lo - (1 << 32) if lo >= (1 << 31) else lo, hi - (1 << 32) if hi >= (1 << 31) else hi]
 
     def _ensure_capacity(self):
         """Grow BEFORE anything is written into the plan's input buffer: growing rebuilds the
@@ -946,13 +952,19 @@ class Session:
         """Enqueue one frame on the CURRENT stream and return immediately (several sessions on
         separate streams overlap on the GPU).  Pair with collect()."""
         self._ensure_capacity()
+        xaddr = 0                                   # 0: the frame reads the session's own input buffer
         if not resident:
             if x_crop.is_cuda:
-                self.x.copy_(x_crop.reshape(self.x.shape))
+                if x_crop.dtype == torch.float32 and x_crop.is_contiguous() and x_crop.numel() == self.x.numel():
+                    # a resident crop is read in place: its address travels in the control block (no device copy);
+                    # the caller's tensor must stay alive and unchanged until collect()
+                    xaddr, self._x_ref = x_crop.data_ptr(), x_crop
+                else:
+                    self.x.copy_(x_crop.reshape(self.x.shape))
             else:
                 np.copyto(self._x_host_np, x_crop.numpy().reshape(self._x_host_np.shape))
                 self.x.copy_(self.x_host, non_blocking=True)
-        self._set_ctl([0, 1] + [2 + int(i) for i in picks], 2 + self.n, tsz_scaled)
+        self._set_ctl([0, 1] + [2 + int(i) for i in picks], 2 + self.n, tsz_scaled, xaddr)
         self._tag = float(self.n)
         self._ctl_f64[6] = self._tag
         self._stream = torch.cuda.current_stream()

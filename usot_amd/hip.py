@@ -29,7 +29,7 @@ EXPORTS = (
     'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
     'PrRoIPoolingForwardGpu', 'usot_groupdw_auto_variant',
-    'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair',
+    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair',
 )
 
 
@@ -101,6 +101,8 @@ def lib():
         L.usot_thin_conv3x3_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_stem_pool_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7
         L.usot_plan_add_stem_pool.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7
+        L.usot_plan_add_stem_pool_ind.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]
+        L.usot_stem_pool_ind_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]
         L.usot_plan_add_thin_conv.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_rows_copy_multi_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.usot_plan_add_rows_copy_multi.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
