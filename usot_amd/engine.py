@@ -869,6 +869,9 @@ class Session:
         idx_dev = self.ctl[64:64 + 4 * (nq + 3)].view(torch.int32)   # N_q gather rows + 1 scatter row + crop address (lo, hi)
         self._ctl_f64 = tsz_dev.numpy()
         self._ctl_i32 = idx_dev.numpy()
+        self._ctl_u32 = self._ctl_i32.view(np.uint32)
+        self._rows = np.zeros(nq, np.int32)
+        self._rows[1] = 1
         self._out_np = self.out8.numpy()
         # the 7 picked memory kernels: their cached encodings, three banks in one gather
         mk = [bld.buf(nq, hk, wk, 256) for hk, wk in KGEO]
@@ -925,13 +928,15 @@ class Session:
         torch.cuda.current_stream().synchronize()
 
     def _set_ctl(self, rows, slot, tsz, xaddr=0):
-        self._ctl_f64[0] = float(tsz[0])
-        self._ctl_f64[1] = float(tsz[1])
-        rows = list(rows)
         if len(rows) != self.nq:
             raise hip.HipError('%d memory rows for a session built for mem_queue_size = %d' % (len(rows), self.nq))
-        lo, hi = int(xaddr) & 0xffffffff, (int(xaddr) >> 32) & 0xffffffff
-        self._ctl_i32[:] = rows + [slot, lo - (1 << 32) if lo >= (1 << 31) else lo, hi - (1 << 32) if hi >= (1 << 31) else hi]
+        f, c, nq = self._ctl_f64, self._ctl_i32, self.nq
+        f[0] = tsz[0]
+        f[1] = tsz[1]
+        c[:nq] = rows
+        c[nq] = slot
+        self._ctl_u32[nq + 1] = xaddr & 0xffffffff          # the crop's device address, low / high half (0 = own buffer)
+        self._ctl_u32[nq + 2] = xaddr >> 32
 
     def _ensure_capacity(self):
         """Grow BEFORE anything is written into the plan's input buffer: growing rebuilds the
@@ -964,7 +969,12 @@ class Session:
             else:
                 np.copyto(self._x_host_np, x_crop.numpy().reshape(self._x_host_np.shape))
                 self.x.copy_(self.x_host, non_blocking=True)
-        self._set_ctl([0, 1] + [2 + int(i) for i in picks], 2 + self.n, tsz_scaled, xaddr)
+        if len(picks) != self.nq - 2:
+            raise hip.HipError('%d sampled memory slots for a session built for mem_queue_size = %d' % (len(picks), self.nq))
+        rows = self._rows
+        rows[2:] = picks
+        rows[2:] += 2                               # bank rows 0 / 1 = init feature and its flip, 2 + i = memory i
+        self._set_ctl(rows, 2 + self.n, tsz_scaled, xaddr)
         self._tag = float(self.n)
         self._ctl_f64[6] = self._tag
         self._stream = torch.cuda.current_stream()
