@@ -103,6 +103,35 @@ __global__ __launch_bounds__(64) void k_dma_pix(const f4 *x, float *sink, long n
     if (acc == 123.456f) sink[0] = acc;
 }
 
+// Epilogue access patterns of the 1x1 expansion convs: a 64-row x 2 KB tile per 512-thread block, read R + write Y.
+// FRAG: the MFMA accumulator layout (a wave owns a 256-byte column band; one instruction = 16 rows x four 16-byte
+// pieces at a 32-byte stride); else one instruction = 1 KiB contiguous (half a row).
+template <bool FRAG>
+__global__ __launch_bounds__(512) void k_epi(const f4 *r, f4 *y, long ntiles)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long base = t * 64 * 128;            // f4 units: 64 rows x 128 f4 (2 KB)
+        if (FRAG) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const long o = base + (long)(j * 16 + l15) * 128 + wave * 16 + ps * 8 + q * 2 + k;
+                        y[o] = r[o] + f4{1.f, 1.f, 1.f, 1.f};
+                    }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long o = base + i * 512 + tid;
+                y[o] = r[o] + f4{1.f, 1.f, 1.f, 1.f};
+            }
+        }
+    }
+}
+
 template <typename F> float timeit(F f, int it = 20)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -137,6 +166,15 @@ int main()
             float ms2 = timeit([&] { hipLaunchKernelGGL(k_mix_span<true>, dim3(blocks), dim3(256), 0, 0, x, y, n4 / 4, span); });
             printf("mixspan blocks %5d span %6ld f4: %7.1f GB/s   nt: %7.1f GB/s\n", blocks, span, (bytes + bytes / 4) / ms / 1e6, (bytes + bytes / 4) / ms2 / 1e6);
         }
+    {
+        const long ntiles = (bytes / 2) / (64 * 2048);      // R and Y of 512 MiB each
+        for (int blocks : {256, 512, 1024}) {
+            float a = timeit([&] { hipLaunchKernelGGL((k_epi<true>), dim3(blocks), dim3(512), 0, 0, x, y, ntiles); });
+            float b = timeit([&] { hipLaunchKernelGGL((k_epi<false>), dim3(blocks), dim3(512), 0, 0, x, y, ntiles); });
+            printf("epilogue pattern R+Y, %4d blocks: accumulator-layout pieces %7.1f GB/s   contiguous KiB %7.1f GB/s (read+write)\n",
+                   blocks, bytes / a / 1e6, bytes / b / 1e6);
+        }
+    }
     {
         const long npix = bytes / 1024;           // 1 KB pixels
         for (int blocks : {256, 512, 1024}) {

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One GPU-box pass that produces everything profiles/<tag>_* holds: smoke, the gpu test suite, the default bench
+# line, the kernel table of the headline workload under rocprofv3, and the two PMC passes behind roofline.traffic.
+#   gpurun --timeout 1500 -- 'bash scripts/round_snapshot.sh round2_c <commit>'
+# Results land in gpurun_out/<tag>/ (scratch); copy what is to be judged into profiles/.
+tag=${1:-snapshot}; commit=${2:-}
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+out=$root/gpurun_out/$tag
+mkdir -p "$out"; cd "$root"
+export TMPDIR=/tmp
+hl="--min-seconds 0 --no-extras --no-xcorr --no-cpu-baseline"
+db() { find "$1" -name '*.db' | head -1; }
+
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$out/smoke.log" 2>&1
+timeout 1500 python -m pytest tests -m gpu -q > "$out/pytest.log" 2>&1; tail -3 "$out/pytest.log"
+timeout 600 python bench.py > "$out/bench.json" 2> "$out/bench.err"
+timeout 300 python bench.py --streams-per-gpu 4 --no-extras --no-xcorr --no-cpu-baseline > "$out/streams4_bench.json" 2>> "$out/bench.err"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$out/prof" -- python "$root/bench.py" --steps 100 --warmup 10 $hl > "$out/profiled_bench.json" 2> "$out/prof.err")
+python scripts/rocpd_stats.py "$(db "$out/prof")" > "$out/kernel_stats.txt"
+for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$out/pmc_$c" -- python "$root/bench.py" --steps 30 $hl > /dev/null 2>> "$out/prof.err")
+    python scripts/rocpd_pmc.py "$(db "$out/pmc_$c")" > "$out/pmc_${c,,}_kb.txt"
+done
+python scripts/pmc_to_traffic.py "$(db "$out/pmc_FETCH_SIZE")" "$(db "$out/pmc_WRITE_SIZE")" "$out/pmc_traffic.json" "$commit" > /dev/null
+rm -rf "$out/prof" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE"
+cat "$out/smoke.log" | tail -2; head -c 600 "$out/bench.json"; echo; head -12 "$out/kernel_stats.txt"
