@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """Where a batch-1 k-step goes: builds the library with -DUSOT_TRACE (s_memtime stamps in one workgroup's
-consumer wave 0 and producer wave 0 of conv_igemm_f32_v3, written to the split-K workspace), runs layer3's
+consumer wave 0 and producer wave 0 of conv_igemm_f32_v3 / v4, written to the split-K workspace), runs layer3's
 3x3 dilated conv (M = 961, N = 256, K = 2304) on the given tiles and prints the median phase lengths in
 shader-clock cycles.   python scripts/trace_kstep.py 41 53 54"""
 import ctypes as C, glob, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-trace_lib = os.path.join(ROOT, 'gpurun_out', 'libusot_hip_trace.so')
-os.makedirs(os.path.dirname(trace_lib), exist_ok=True)
-srcs = sorted(glob.glob(os.path.join(ROOT, 'usot_amd', 'csrc', '*.hip')))
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DUSOT_TRACE',
-                       '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'usot_amd', 'csrc'), '-o', trace_lib] + srcs)
+# USOT_TRACE_LIB: a library already built with -DUSOT_TRACE (conv_igemm.hip is the only file that reads the macro)
+trace_lib = os.environ.get('USOT_TRACE_LIB') or os.path.join(ROOT, 'gpurun_out', 'libusot_hip_trace.so')
+if not os.environ.get('USOT_TRACE_LIB'):
+    os.makedirs(os.path.dirname(trace_lib), exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(ROOT, 'usot_amd', 'csrc', '*.hip')))
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++20', '-fPIC', '-shared', '-DUSOT_TRACE',
+                           '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'usot_amd', 'csrc'), '-o', trace_lib] + srcs)
 os.environ['USOT_HIP_LIB'] = trace_lib
 import torch
 from usot_amd import hip

@@ -14,8 +14,10 @@ from usot_amd.model import USOT
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--table', required=True, help='isolated table (tune_conv.py --out)')
-ap.add_argument('--candidates', required=True, help='tune_conv.py --candidates')
+ap.add_argument('--candidates', default='', help='tune_conv.py --candidates')
+ap.add_argument('--extra-tiles', default='', help='comma list of tile ids tried on every shape with the incumbent split-K (and neighbours)')
 ap.add_argument('--out', required=True)
+ap.add_argument('--ks-neighbours', action='store_true')
 ap.add_argument('--size', type=int, default=255)
 ap.add_argument('--reps', type=int, default=40)
 ap.add_argument("--passes", type=int, default=1)
@@ -32,8 +34,17 @@ e = m.engine
 key = lambda k: tuple(int(v) for v in k.split(','))
 with open(a.table) as f:
     table = {key(k): tuple(v) for k, v in json.load(f).items()}
-with open(a.candidates) as f:
-    cands = {key(k): [(c[0], c[1]) for c in v] for k, v in json.load(f).items()}
+cands = {}
+if a.candidates:
+    with open(a.candidates) as f:
+        cands = {key(k): [(c[0], c[1]) for c in v] for k, v in json.load(f).items()}
+extra = [int(v) for v in a.extra_tiles.split(',') if v]
+if extra:                                   # incumbent first, then the extra tiles at the incumbent's split-K and its neighbours
+    for k, cur in table.items():
+        ks = cur[1]
+        splits = sorted({ks, max(1, ks - 1), ks + 1, max(1, ks // 2), ks * 2}, key=lambda s: abs(s - ks)) if a.ks_neighbours else [ks]
+        alts = [(tl, s) for s in splits for tl in extra]
+        cands[k] = [tuple(cur)] + alts + [c for c in cands.get(k, []) if tuple(c) != tuple(cur)]
 e.tuning = dict(table)
 
 

@@ -750,12 +750,20 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
                 // unconditional load (padding taps read pixel 0 of the tensor and are zeroed at the
                 // LDS store): a branch around the load makes the compiler's vmcnt bookkeeping
                 // conservative and every buffer's last store then drains ALL loads in flight
+#ifdef USOT_ABL_NOLOAD     // scripts/ablate_kstep.py: timing builds with parts of the kernel removed
+                xr[d][i] = f32x4{1.f, 1.f, 1.f, 1.f};
+#else
                 xr[d][i] = *(const f32x4 *)(xin[i] ? xp[i] + c0 : xg + kc * 4);
+#endif
                 xz[d][i] = xin[i];
             }
 #pragma unroll
             for (int i = 0; i < WI; ++i) {
+#ifdef USOT_ABL_NOLOAD
+                wr[d][i] = f32x4{1.f, 1.f, 1.f, 1.f};
+#else
                 wr[d][i] = *(const f32x4 *)wp[i];
+#endif
                 wp[i] += advance ? BK : 0;
             }
             if (advance && ++cur_cc == cch) {
@@ -766,6 +774,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
         auto store_tile = [&](auto dc, int st) {
             constexpr int d = decltype(dc)::value;
             float *sX = smem + st * STAGE, *sW = sX + BM * LD;
+#ifdef USOT_ABL_NOSTORE
+            return;
+#endif
 #pragma unroll
             for (int i = 0; i < XI; ++i)
                 if (BM % RPP == 0 || lr + RPP * i < BM)
@@ -833,6 +844,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
     const int fw_off = BM * LD + (wn * TN * 16 + l15) * LD + quad * 4;
     f32x4 fw[2][TN], fx[2][TM];
     auto read_frags = [&](int st, int r, int slot) {
+#ifdef USOT_ABL_NOREAD
+        return;
+#endif
         const float *base = smem + st * STAGE + r * 16;
 #pragma unroll
         for (int i = 0; i < TN; ++i) fw[slot][i] = *(const f32x4 *)(base + fw_off + i * 16 * LD);
@@ -849,6 +863,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
     // (even / odd k-slots) and adds them at the end.
     f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
     auto mma = [&](int slot) {
+#ifdef USOT_ABL_NOMMA
+        return;
+#endif
         if constexpr (TM * TN == 1) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][0], fx[slot][0][0], acc[0][0], 0, 0, 0);
             acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][1], fx[slot][0][1], acc2, 0, 0, 0);
