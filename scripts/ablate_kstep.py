@@ -2,7 +2,7 @@
 """What bounds a batch-1 k-step of conv_igemm_f32_v3: times layer3's 3x3 dilated conv (M = 961, N = 256, K = 2304)
 alone, back to back, on libraries built with parts of the kernel removed (-DUSOT_ABL_NOMMA: no MFMAs,
 -DUSOT_ABL_NOREAD: no fragment reads, -DUSOT_ABL_NOLOAD: producers fetch nothing, -DUSOT_ABL_NOSTORE: producers
-write nothing to LDS).  Results are wrong by construction; only the durations matter.
+write nothing to LDS, -DUSOT_ABL_NOBARRIER: no per-k-step barrier, both halves free-running).  Results are wrong by construction; only the durations matter.
     python scripts/ablate_kstep.py <lib.so> [tile ...]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

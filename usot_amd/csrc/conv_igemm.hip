@@ -825,7 +825,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
             load_next(dc);
             USOT_STAMP(6, t);
             st2 = st2 == 2 ? 0 : st2 + 1;
+#ifndef USOT_ABL_NOBARRIER      // timing only: producers and consumers free-running (results are garbage)
             __syncthreads();
+#endif
             USOT_STAMP(7, t);
         };
         int t = 0;
@@ -916,7 +918,9 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
         }
         st = st1;
         USOT_STAMP(1, t);
+#ifndef USOT_ABL_NOBARRIER
         __syncthreads();
+#endif
         USOT_STAMP(2, t);
     }
 #undef USOT_STAMP
