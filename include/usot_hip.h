@@ -202,6 +202,31 @@ void PrRoIPoolingForwardGpu(hipStream_t stream, const float *bottom_data, const 
                             const int pooled_height_, const int pooled_width_,
                             const float spatial_scale_, const int top_count);
 
+/* ---- gradients of Precise RoI Pooling: what the reference's binding exposes for training
+ * (prroi_pooling_gpu.c:46-113).  Contiguous NCHW features [B][C][H][W], rois [R][5], top_data / top_diff
+ * [R][C][PH][PW].  Both zero-fill their output on the stream first (as .cu:415,436).
+ *   backward:       bottom_diff [B][C][H][W] += top_diff / bin area * (weight of the pixel in the bin integral)
+ *   coor_backward:  rois_diff [R][5] = d sum(top_diff * out) / d (batch, x1, y1, x2, y2); column 0 is 0.
+ *                   A RoI whose batch index is outside [0, B) contributes nothing.                              */
+int usot_prroi_pool_backward_f32(void *stream, const float *rois, const float *top_diff, float *bottom_diff,
+                                 int R, int B, int C, int H, int W, int PH, int PW, float scale);
+int usot_prroi_pool_coor_backward_f32(void *stream, const float *feat, const float *rois, const float *top_data,
+                                      const float *top_diff, float *rois_diff,
+                                      int R, int B, int C, int H, int W, int PH, int PW, float scale);
+
+/* the reference's symbols for them, exact signatures (prroi_pooling_gpu_impl.cuh:30-54; launchers .cu:404-440);
+ * on a bad argument or a failed launch: one line on stderr and return, never exit(-1) */
+void PrRoIPoolingBackwardGpu(hipStream_t stream, const float *bottom_data, const float *bottom_rois,
+                             const float *top_data, const float *top_diff, float *bottom_diff,
+                             const int channels_, const int height_, const int width_,
+                             const int pooled_height_, const int pooled_width_, const float spatial_scale_,
+                             const int top_count, const int bottom_count);
+void PrRoIPoolingCoorBackwardGpu(hipStream_t stream, const float *bottom_data, const float *bottom_rois,
+                                 const float *top_data, const float *top_diff, float *bottom_diff,
+                                 const int channels_, const int height_, const int width_,
+                                 const int pooled_height_, const int pooled_width_, const float spatial_scale_,
+                                 const int top_count, const int bottom_count);
+
 /* ---- layout changes at the API edge: generic 4-D strided copy ----------------------
  * dst[n][a][b][c] (dense) = src[n*s0 + a*s1 + b*s2 + c*s3]                              */
 int usot_permute4_f32(void *stream, const float *src, float *dst,

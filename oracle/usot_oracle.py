@@ -186,12 +186,17 @@ def _load_prlib():
     global _prlib
     if _prlib is None:
         path = os.path.join(_HERE, 'libprroi_ref.so')
-        if not os.path.exists(path):
+        src = os.path.join(_HERE, 'prroi_pool_ref.c')
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             import subprocess
             subprocess.check_call(['make', '-C', _HERE, 'libprroi_ref.so'])
         _prlib = ctypes.CDLL(path)
         _prlib.prroi_pool_forward_ref.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_float]
         _prlib.prroi_pool_forward_ref.restype = None
+        _prlib.prroi_pool_backward_ref.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 7 + [ctypes.c_float]
+        _prlib.prroi_pool_backward_ref.restype = None
+        _prlib.prroi_pool_coor_backward_ref.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_float]
+        _prlib.prroi_pool_coor_backward_ref.restype = None
     return _prlib
 
 
@@ -205,6 +210,32 @@ def prroi_pool(features, rois, ph=7, pw=7, scale=1.0):
     if r.shape[0]:
         lib.prroi_pool_forward_ref(f.ctypes.data, r.ctypes.data, out.ctypes.data,
                                    r.shape[0], c, h, w, ph, pw, ctypes.c_float(scale))
+    return torch.from_numpy(out)
+
+
+def _f32(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, dtype=np.float32)
+
+
+def prroi_pool_backward(feature_shape, rois, top_diff, ph=7, pw=7, scale=1.0):
+    """Feature gradient [B,C,H,W] of sum(top_diff * prroi_pool(features, rois)); C restatement of
+    prroi_pooling_gpu_impl.cu:214-272 (sequential sums where the kernel uses atomicAdd)."""
+    lib = _load_prlib()
+    b, c, h, w = feature_shape
+    r, g = _f32(rois), _f32(top_diff)
+    out = np.zeros((b, c, h, w), np.float32)
+    lib.prroi_pool_backward_ref(r.ctypes.data, g.ctypes.data, out.ctypes.data, r.shape[0], b, c, h, w, ph, pw, ctypes.c_float(scale))
+    return torch.from_numpy(out)
+
+
+def prroi_pool_coor_backward(features, rois, top_data, top_diff, ph=7, pw=7, scale=1.0):
+    """RoI gradient [R,5] (column 0 zero); C restatement of prroi_pooling_gpu_impl.cu:274-380."""
+    lib = _load_prlib()
+    f, r, t, g = _f32(features), _f32(rois), _f32(top_data), _f32(top_diff)
+    b, c, h, w = f.shape
+    out = np.zeros((r.shape[0], 5), np.float32)
+    lib.prroi_pool_coor_backward_ref(f.ctypes.data, r.ctypes.data, t.ctypes.data, g.ctypes.data, out.ctypes.data,
+                                     r.shape[0], c, h, w, ph, pw, ctypes.c_float(scale))
     return torch.from_numpy(out)
 
 

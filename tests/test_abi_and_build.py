@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol(libpath):
     for s in syms:
         assert hasattr(L, s), s
     assert set(hip.EXPORTS) <= set(syms)
-    assert 'PrRoIPoolingForwardGpu' in syms     # the reference's own native symbol (prroi_pooling_gpu_impl.cuh:20-28)
+    # the reference's own native symbols (prroi_pooling_gpu_impl.cuh:20-54)
+    assert {'PrRoIPoolingForwardGpu', 'PrRoIPoolingBackwardGpu', 'PrRoIPoolingCoorBackwardGpu'} <= set(syms)
     L.usot_abi_version.restype = ctypes.c_int
     assert L.usot_abi_version() == 1
     L.usot_strerror.restype = ctypes.c_char_p

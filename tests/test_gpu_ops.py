@@ -243,6 +243,115 @@ def test_prroi_pool_vs_independent_float64_oracle(layout):
         assert not (d2 > 2 * _prroi_tol(rois)).any()
 
 
+def _prroi_grad_case(seed, shape, n):
+    from prroi_cases import random_rois
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(seed)
+    f = torch.randn(B, C, H, W, generator=g)
+    rois = random_rois(seed, n, B, H, W)
+    top_diff = torch.randn(n, C, 7, 7, generator=g)
+    return f, rois, top_diff
+
+
+@pytest.mark.parametrize('seed,shape,n', [(11, (2, 32, 15, 17), 96), (12, (1, 16, 31, 31), 60)])
+def test_prroi_feature_gradient_vs_oracles(seed, shape, n):
+    """prroi_backward_kernel (one atomic per touched pixel, separable weights) against the float64 adjoint oracle
+    (oracle/prroi_exact.py) and the float32 restatement of the reference's kernel (prroi_pooling_gpu_impl.cu:214-272).
+    Measured (scripts/prroi_grad_errors.py): 1e-6 .. 9e-6 of the largest gradient for bins of at least 0.05 pixel,
+    3e-5 .. 5e-5 with the sub-pixel boxes (float32 corner weights divided by a tiny area, in the restatement alike)."""
+    import prroi_exact as ex
+    f, rois, g = _prroi_grad_case(seed, shape, n)
+    rd = torch.from_numpy(rois).to(DEV)
+    got = hip.prroi_pool_backward(f.shape, rd, g.to(DEV), 7, 7, 1.0).cpu().numpy()
+    want = ex.prroi_pool_exact_backward(f.shape, rois, g.numpy(), 7, 7, 1.0)
+    ref = orc.prroi_pool_backward(f.shape, rois, g, 7, 7, 1.0).numpy()
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.isfinite(got).all()
+    assert np.max(np.abs(got - want)) < 1.5e-4 * scale
+    assert np.max(np.abs(got - ref)) < 1e-5 * scale                     # the two float32 forms agree everywhere
+    wide = torch.from_numpy(np.minimum(rois[:, 3] - rois[:, 1], rois[:, 4] - rois[:, 2]) / 7 >= 0.05)
+    gw = hip.prroi_pool_backward(f.shape, rd[wide.to(DEV)], g[wide].to(DEV), 7, 7, 1.0).cpu().numpy()
+    ww = ex.prroi_pool_exact_backward(f.shape, rois[wide.numpy()], g.numpy()[wide.numpy()], 7, 7, 1.0)
+    assert np.max(np.abs(gw - ww)) < 2.5e-5 * max(1.0, float(np.abs(ww).max()))
+    # an empty RoI list gives a zero gradient of the right shape
+    z = hip.prroi_pool_backward(f.shape, torch.zeros(0, 5, device=DEV), torch.zeros(0, shape[1], 7, 7, device=DEV), 7, 7, 1.0)
+    assert tuple(z.shape) == tuple(f.shape) and not z.any()
+
+
+@pytest.mark.parametrize('seed,shape,n', [(13, (2, 32, 15, 17), 96), (14, (1, 16, 31, 31), 60)])
+def test_prroi_roi_gradient_vs_oracles(seed, shape, n):
+    """prroi_coor_backward_kernel against the float64 Leibniz oracle and the float32 restatement (.cu:274-380).
+    d out / d edge carries 1 / area on top of the forward's 1 / area: measured 5e-6 of the RoI's largest component for
+    bins of at least 0.2 pixel, 3e-5 from 0.05, 1e-2 for sub-pixel boxes (restatement and kernel alike)."""
+    import prroi_exact as ex
+    f, rois, g = _prroi_grad_case(seed, shape, n)
+    fd, rd = f.to(DEV), torch.from_numpy(rois).to(DEV)
+    top = hip.prroi_pool(fd, rd, 7, 7, 1.0)
+    got = hip.prroi_pool_coor_backward(fd, rd, top, g.to(DEV), 7, 7, 1.0).cpu().numpy()
+    want = ex.prroi_pool_exact_coor_backward(f.numpy(), rois, g.numpy(), 7, 7, 1.0)
+    ref = orc.prroi_pool_coor_backward(f, rois, top.cpu(), g, 7, 7, 1.0).numpy()
+    assert np.all(got[:, 0] == 0) and np.isfinite(got).all()
+    bins = np.minimum(rois[:, 3] - rois[:, 1], rois[:, 4] - rois[:, 2]) / 7
+    mag = np.maximum(1.0, np.abs(want).max(1))
+    e_exact, e_ref = np.abs(got - want).max(1) / mag, np.abs(got - ref).max(1) / mag
+    assert np.all(e_exact[bins >= 0.2] <= 3e-5) and np.all(e_ref[bins >= 0.2] <= 3e-5), (e_exact[bins >= 0.2].max(), e_ref[bins >= 0.2].max())
+    assert np.all(e_exact[bins >= 0.05] <= 1.5e-4) and np.all(e_ref[bins >= 0.05] <= 1.5e-4)
+    assert np.all(e_exact <= 5e-2)
+    assert not got[~(bins > 0)].any()                                     # zero / negative extent: no gradient
+
+
+def test_prroi_autograd_function_matches_the_oracles():
+    """lib.models.prroi_pool.functional.prroi_pool2d as the reference's training code calls it
+    (functional.py:41-84): autograd gradients of features and RoIs."""
+    import prroi_exact as ex
+    from lib.models.prroi_pool.functional import prroi_pool2d
+    f, rois, g = _prroi_grad_case(21, (2, 8, 13, 12), 12)
+    rois = rois[np.minimum(rois[:, 3] - rois[:, 1], rois[:, 4] - rois[:, 2]) > 2.0]
+    g = g[:len(rois)]
+    fd = f.to(DEV).requires_grad_(True)
+    rd = torch.from_numpy(rois).to(DEV).requires_grad_(True)
+    out = prroi_pool2d(fd, rd, 7, 7, 0.5)
+    (out * g.to(DEV)).sum().backward()
+    want_f = ex.prroi_pool_exact_backward(f.shape, rois, g.numpy(), 7, 7, 0.5)
+    want_r = ex.prroi_pool_exact_coor_backward(f.numpy(), rois, g.numpy(), 7, 7, 0.5)
+    assert np.max(np.abs(fd.grad.cpu().numpy() - want_f)) < 1e-5 * max(1.0, np.abs(want_f).max())
+    assert np.max(np.abs(rd.grad.cpu().numpy() - want_r)) < 3e-5 * max(1.0, np.abs(want_r).max())
+    # features only: the RoI gradient is not computed
+    fd2 = f.to(DEV).requires_grad_(True)
+    prroi_pool2d(fd2, torch.from_numpy(rois).to(DEV), 7, 7, 0.5).sum().backward()
+    assert fd2.grad is not None
+
+
+def test_prroi_gradient_reference_symbols_exact_signature():
+    """PrRoIPoolingBackwardGpu / PrRoIPoolingCoorBackwardGpu with the reference's signatures
+    (prroi_pooling_gpu_impl.cuh:30-54) as prroi_pooling_gpu.c:46-113 calls them; both zero their output first."""
+    import ctypes as C
+    f, rois, g = _prroi_grad_case(31, (2, 24, 15, 17), 10)
+    rois = rois[np.minimum(rois[:, 3] - rois[:, 1], rois[:, 4] - rois[:, 2]) > 1.0]
+    g = g[:len(rois)].contiguous()
+    n = len(rois)
+    fd, rd, gd = f.to(DEV), torch.from_numpy(rois).to(DEV), g.to(DEV)
+    top = hip.prroi_pool(fd, rd, 7, 7, 1.0)
+    L = hip.lib()
+    gin = torch.full(f.shape, 3.0, device=DEV)                               # must be overwritten, not accumulated into
+    L.PrRoIPoolingBackwardGpu(hip.stream(), hip.ptr(fd), hip.ptr(rd), hip.ptr(top), hip.ptr(gd), hip.ptr(gin),
+                              24, 15, 17, 7, 7, C.c_float(1.0), top.numel(), gin.numel())
+    gr = torch.full((n, 5), 3.0, device=DEV)
+    L.PrRoIPoolingCoorBackwardGpu(hip.stream(), hip.ptr(fd), hip.ptr(rd), hip.ptr(top), hip.ptr(gd), hip.ptr(gr),
+                                  24, 15, 17, 7, 7, C.c_float(1.0), top.numel(), gr.numel())
+    torch.cuda.synchronize()
+    ref_f = orc.prroi_pool_backward(f.shape, rois, g, 7, 7, 1.0).numpy()
+    ref_r = orc.prroi_pool_coor_backward(f, rois, top.cpu(), g, 7, 7, 1.0).numpy()
+    assert np.max(np.abs(gin.cpu().numpy() - ref_f)) < 1e-5 * max(1.0, float(np.abs(ref_f).max()))
+    assert np.max(np.abs(gr.cpu().numpy() - ref_r)) < 3e-5 * max(1.0, float(np.abs(ref_r).max()))
+    # inconsistent counts are refused: a line on stderr, nothing written, no exit
+    keep = torch.full((n, 5), 9.0, device=DEV)
+    L.PrRoIPoolingCoorBackwardGpu(hip.stream(), hip.ptr(fd), hip.ptr(rd), hip.ptr(top), hip.ptr(gd), hip.ptr(keep),
+                                  24, 15, 17, 7, 7, C.c_float(1.0), top.numel(), keep.numel() - 5)
+    torch.cuda.synchronize()
+    assert float(keep.min()) == 9.0
+
+
 def test_prroi_reference_symbol_exact_signature():
     """PrRoIPoolingForwardGpu(stream, bottom_data, bottom_rois, top_data, C, H, W, PH, PW, scale,
     top_count) — the reference's own extern "C" symbol (prroi_pooling_gpu_impl.cuh:20-28) as a

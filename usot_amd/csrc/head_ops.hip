@@ -107,6 +107,141 @@ __global__ __launch_bounds__(256) void prroi_forward_kernel(const PrK p)
     }
 }
 
+// ---- Precise RoI Pooling gradients (training side of the operator; prroi_pooling_gpu_impl.cu:214-380) ---------
+// out = (1/A) * hy^T W hx with hx[i] = int_bin hat(x - i) dx: separable.  pr_axis_weight() is that integral for one
+// pixel in float32, assembled from the same two corner pieces (pr_hat) the forward uses per unit cell: the piece of
+// the cell on the pixel's left, where the pixel is the far corner, and of the cell on its right, where it is the
+// near one.  Contiguous NCHW as the reference's ABI.
+struct PrGradK {
+    const float *feat, *rois, *top, *gout;
+    float *gin;                              // feature gradient [B][C][H][W]  or  RoI gradient [R][5]
+    int R, B, C, H, W, PH, PW;
+    float scale;
+};
+
+__device__ __forceinline__ float pr_axis_weight(int i, float lo, float hi, int s, int e)
+{
+    float w = 0.f;
+    if (i > s) w += pr_hat((float)i - fminf(hi, (float)i), (float)i - fmaxf(lo, (float)(i - 1)));       // cell i-1, far corner
+    if (i < e) w += pr_hat(fmaxf(lo, (float)i) - (float)i, fminf(hi, (float)(i + 1)) - (float)i);         // cell i, near corner
+    return w;
+}
+
+struct PrBin { int b; float x0, y0, x1, y1, area; int s_w, e_w, s_h, e_h; };
+
+__device__ __forceinline__ PrBin pr_bin(const float *roi, float scale, int PH, int PW, int ph, int pw)
+{
+    PrBin q;
+    q.b = (int)roi[0];
+    const float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
+    const float bh = fmaxf(reh - rsh, 0.f) / (float)PH, bw = fmaxf(rew - rsw, 0.f) / (float)PW;
+    q.area = fmaxf(0.f, bw * bh);
+    q.x0 = rsw + bw * pw; q.y0 = rsh + bh * ph;
+    q.x1 = q.x0 + bw;     q.y1 = q.y0 + bh;
+    q.s_w = (int)floorf(q.x0); q.e_w = (int)ceilf(q.x1);
+    q.s_h = (int)floorf(q.y0); q.e_h = (int)ceilf(q.y1);
+    return q;
+}
+
+// Feature gradient: one thread per pooled element (pw fastest: coalesced top_diff), ONE atomic per touched pixel
+// (the reference issues one per cell corner, up to four per pixel): gin[b][c][y][x] += g / A * hy[y] * hx[x].
+__global__ __launch_bounds__(256) void prroi_backward_kernel(const PrGradK p)
+{
+    const long total = (long)p.R * p.C * p.PH * p.PW;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int pw = (int)(idx % p.PW);
+        long r = idx / p.PW;
+        const int ph = (int)(r % p.PH); r /= p.PH;
+        const int c = (int)(r % p.C);
+        const int n = (int)(r / p.C);
+        const PrBin q = pr_bin(p.rois + (long)n * 5, p.scale, p.PH, p.PW, ph, pw);
+        if (q.area == 0.f || q.b < 0 || q.b >= p.B) continue;
+        const float share = p.gout[idx] / q.area;
+        if (share == 0.f) continue;
+        float *d = p.gin + ((long)q.b * p.C + c) * p.H * p.W;
+        const int y_lo = q.s_h < 0 ? 0 : q.s_h, y_hi = q.e_h >= p.H ? p.H - 1 : q.e_h;
+        const int x_lo = q.s_w < 0 ? 0 : q.s_w, x_hi = q.e_w >= p.W ? p.W - 1 : q.e_w;
+        for (int y = y_lo; y <= y_hi; ++y) {
+            const float wy = share * pr_axis_weight(y, q.y0, q.y1, q.s_h, q.e_h);
+            if (wy == 0.f) continue;
+            for (int x = x_lo; x <= x_hi; ++x) {
+                const float v = wy * pr_axis_weight(x, q.x0, q.x1, q.s_w, q.e_w);
+                if (v != 0.f) atomicAdd(d + y * p.W + x, v);
+            }
+        }
+    }
+}
+
+// zero-extended bilinear surface along one axis: value at (row y, real x) and (real y, column x)
+__device__ __forceinline__ float pr_lerp_x(const float *d, int y, float x, int H, int W)
+{
+    if (y < 0 || y >= H) return 0.f;
+    const int x0 = (int)floorf(x);
+    const float a = x - (float)x0;
+    const float v0 = (x0 >= 0 && x0 < W) ? d[y * W + x0] : 0.f, v1 = (x0 + 1 >= 0 && x0 + 1 < W) ? d[y * W + x0 + 1] : 0.f;
+    return (1.f - a) * v0 + a * v1;
+}
+__device__ __forceinline__ float pr_lerp_y(const float *d, float y, int x, int H, int W)
+{
+    if (x < 0 || x >= W) return 0.f;
+    const int y0 = (int)floorf(y);
+    const float a = y - (float)y0;
+    const float v0 = (y0 >= 0 && y0 < H) ? d[y0 * W + x] : 0.f, v1 = (y0 + 1 >= 0 && y0 + 1 < H) ? d[(y0 + 1) * W + x] : 0.f;
+    return (1.f - a) * v0 + a * v1;
+}
+
+// RoI gradient.  Leibniz: moving a bin edge changes the integral by the line integral of the surface along that edge,
+// L_x(x) = sum_y hy[y] * f(x, y); d out / d xs = (-L_x(xs) + (ye - ys) out) / A, d out / d xe = (L_x(xe) - (ye - ys) out) / A
+// (same in y), and the edges are affine in the RoI corners.  blockIdx.y = RoI, so a wavefront reduces its four partial
+// sums with shuffles and issues four atomics (the reference: four per pooled element onto the same four words).
+__global__ __launch_bounds__(256) void prroi_coor_backward_kernel(const PrGradK p)
+{
+    const int n = blockIdx.y;
+    const int per_roi = p.C * p.PH * p.PW;
+    float g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < per_roi; e += gridDim.x * 256) {
+        const int pw = e % p.PW, ph = (e / p.PW) % p.PH, c = e / (p.PW * p.PH);
+        const PrBin q = pr_bin(p.rois + (long)n * 5, p.scale, p.PH, p.PW, ph, pw);
+        if (q.area == 0.f || q.b < 0 || q.b >= p.B) continue;
+        const long idx = (long)n * per_roi + e;
+        const float g = p.gout[idx];
+        if (g == 0.f) continue;                                       // .cu:315-317
+        const float top = p.top[idx];
+        const float *d = p.feat + ((long)q.b * p.C + c) * p.H * p.W;
+        float lx0 = 0.f, lx1 = 0.f, ly0 = 0.f, ly1 = 0.f;
+        for (int y = q.s_h; y <= q.e_h; ++y) {
+            const float wy = pr_axis_weight(y, q.y0, q.y1, q.s_h, q.e_h);
+            lx0 += wy * pr_lerp_x(d, y, q.x0, p.H, p.W);
+            lx1 += wy * pr_lerp_x(d, y, q.x1, p.H, p.W);
+        }
+        for (int x = q.s_w; x <= q.e_w; ++x) {
+            const float wx = pr_axis_weight(x, q.x0, q.x1, q.s_w, q.e_w);
+            ly0 += wx * pr_lerp_y(d, q.y0, x, p.H, p.W);
+            ly1 += wx * pr_lerp_y(d, q.y1, x, p.H, p.W);
+        }
+        const float k = p.scale / q.area * g;
+        const float dxs = (-lx0 + (q.y1 - q.y0) * top) * k, dxe = (lx1 - (q.y1 - q.y0) * top) * k;
+        const float dys = (-ly0 + (q.x1 - q.x0) * top) * k, dye = (ly1 - (q.x1 - q.x0) * top) * k;
+        const float fx0 = (float)pw / (float)p.PW, fx1 = (float)(pw + 1) / (float)p.PW;
+        const float fy0 = (float)ph / (float)p.PH, fy1 = (float)(ph + 1) / (float)p.PH;
+        g1 += dxs * (1.f - fx0) + dxe * (1.f - fx1);
+        g2 += dys * (1.f - fy0) + dye * (1.f - fy1);
+        g3 += dxs * fx0 + dxe * fx1;
+        g4 += dys * fy0 + dye * fy1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        g1 += __shfl_xor(g1, o); g2 += __shfl_xor(g2, o); g3 += __shfl_xor(g3, o); g4 += __shfl_xor(g4, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        float *gr = p.gin + (long)n * 5;
+        if (g1 != 0.f) atomicAdd(gr + 1, g1);
+        if (g2 != 0.f) atomicAdd(gr + 2, g2);
+        if (g3 != 0.f) atomicAdd(gr + 3, g3);
+        if (g4 != 0.f) atomicAdd(gr + 4, g4);
+    }
+}
+
 // ---- generic 4-D permute: dst dense [D0][D1][D2][D3] <- strided src ------------------------
 __global__ __launch_bounds__(256) void permute4_kernel(
     const float *__restrict__ src, float *__restrict__ dst, int D1, int D2, int D3, long total,
@@ -469,6 +604,77 @@ extern "C" void PrRoIPoolingForwardGpu(hipStream_t stream, const float *bottom_d
                                                pooled_height_, pooled_width_, spatial_scale_,
                                                channels_ * HW, HW, width_, 1, channels_ * PP, PP, pooled_width_, 1);
     if (rc != USOT_OK) fprintf(stderr, "PrRoIPoolingForwardGpu: %s\n", usot_strerror(rc));
+}
+
+/* ---- the gradients of the same operator.  The reference's binding exposes them for training
+ * (prroi_pooling_gpu.c:46-113 -> PrRoIPoolingBackwardGpu / PrRoIPoolingCoorBackwardGpu, .cu:404-440); contiguous
+ * NCHW as there.  Both zero their output first, as the reference's launchers do (cudaMemsetAsync, .cu:415,436). */
+extern "C" int usot_prroi_pool_backward_f32(void *stream, const float *rois, const float *top_diff, float *bottom_diff,
+                                            int R, int B, int C, int H, int W, int PH, int PW, float scale)
+{
+    if (R < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || !bottom_diff) return USOT_EINVAL;
+    if (hipMemsetAsync(bottom_diff, 0, sizeof(float) * (size_t)B * C * H * W, (hipStream_t)stream) != hipSuccess) return USOT_ELAUNCH;
+    if (R == 0) return USOT_OK;
+    if (!rois || !top_diff) return USOT_EINVAL;
+    PrGradK p{nullptr, rois, nullptr, top_diff, bottom_diff, R, B, C, H, W, PH, PW, scale};
+    const long total = (long)R * C * PH * PW;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(prroi_backward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+extern "C" int usot_prroi_pool_coor_backward_f32(void *stream, const float *feat, const float *rois, const float *top_data,
+                                                 const float *top_diff, float *rois_diff,
+                                                 int R, int B, int C, int H, int W, int PH, int PW, float scale)
+{
+    if (R < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0) return USOT_EINVAL;
+    if (R == 0) return USOT_OK;
+    if (!feat || !rois || !top_data || !top_diff || !rois_diff || R > 65535) return USOT_EINVAL;
+    if (hipMemsetAsync(rois_diff, 0, sizeof(float) * (size_t)R * 5, (hipStream_t)stream) != hipSuccess) return USOT_ELAUNCH;
+    PrGradK p{feat, rois, top_data, top_diff, rois_diff, R, B, C, H, W, PH, PW, scale};
+    const int per_roi = C * PH * PW;
+    const int bx = (per_roi + 255) / 256 > 64 ? 64 : (per_roi + 255) / 256;
+    hipLaunchKernelGGL(prroi_coor_backward_kernel, dim3(bx, R), dim3(256), 0, (hipStream_t)stream, p);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+/* exact signatures of prroi_pooling_gpu_impl.cuh:30-54; stderr + return instead of exit(-1), like the forward shim */
+extern "C" void PrRoIPoolingBackwardGpu(hipStream_t stream, const float *bottom_data, const float *bottom_rois,
+                                        const float *top_data, const float *top_diff, float *bottom_diff,
+                                        const int channels_, const int height_, const int width_,
+                                        const int pooled_height_, const int pooled_width_, const float spatial_scale_,
+                                        const int top_count, const int bottom_count)
+{
+    (void)bottom_data; (void)top_data;                      /* unused by the feature gradient, there as here (.cu:416-418) */
+    const long per_roi = (long)channels_ * pooled_height_ * pooled_width_, per_img = (long)channels_ * height_ * width_;
+    if (per_roi <= 0 || per_img <= 0 || top_count < 0 || top_count % per_roi || bottom_count <= 0 || bottom_count % per_img) {
+        fprintf(stderr, "PrRoIPoolingBackwardGpu: invalid argument (top_count %d, bottom_count %d)\n", top_count, bottom_count);
+        return;
+    }
+    const int rc = usot_prroi_pool_backward_f32((void *)stream, bottom_rois, top_diff, bottom_diff, (int)(top_count / per_roi),
+                                                (int)(bottom_count / per_img), channels_, height_, width_,
+                                                pooled_height_, pooled_width_, spatial_scale_);
+    if (rc != USOT_OK) fprintf(stderr, "PrRoIPoolingBackwardGpu: %s\n", usot_strerror(rc));
+}
+
+extern "C" void PrRoIPoolingCoorBackwardGpu(hipStream_t stream, const float *bottom_data, const float *bottom_rois,
+                                            const float *top_data, const float *top_diff, float *bottom_diff,
+                                            const int channels_, const int height_, const int width_,
+                                            const int pooled_height_, const int pooled_width_, const float spatial_scale_,
+                                            const int top_count, const int bottom_count)
+{
+    const long per_roi = (long)channels_ * pooled_height_ * pooled_width_;
+    if (per_roi <= 0 || top_count < 0 || top_count % per_roi || bottom_count != (top_count / per_roi) * 5) {
+        fprintf(stderr, "PrRoIPoolingCoorBackwardGpu: invalid argument (top_count %d, bottom_count %d)\n", top_count, bottom_count);
+        return;
+    }
+    /* the signature carries no batch size (the reference never checks a RoI's batch index): accept any index >= 0 */
+    const int rc = usot_prroi_pool_coor_backward_f32((void *)stream, bottom_data, bottom_rois, top_data, top_diff, bottom_diff,
+                                                     (int)(top_count / per_roi), 0x7fffffff, channels_, height_, width_,
+                                                     pooled_height_, pooled_width_, spatial_scale_);
+    if (rc != USOT_OK) fprintf(stderr, "PrRoIPoolingCoorBackwardGpu: %s\n", usot_strerror(rc));
 }
 
 extern "C" int usot_permute4_f32(void *stream, const float *src, float *dst,

@@ -17,7 +17,7 @@ EXPORTS = (
     'usot_abi_version', 'usot_strerror', 'usot_conv2d_f32', 'usot_conv_tile_count',
     'usot_conv_tile_info', 'usot_conv_tile_name', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
     'usot_xcorr_depthwise_f32', 'usot_groupdw_f32', 'usot_conf_fusion_reduce_f32',
-    'usot_prroi_pool_forward_f32', 'usot_permute4_f32', 'usot_decode_f32',
+    'usot_prroi_pool_forward_f32', 'usot_prroi_pool_backward_f32', 'usot_prroi_pool_coor_backward_f32', 'usot_permute4_f32', 'usot_decode_f32',
     'usot_plan_create', 'usot_plan_destroy', 'usot_plan_add_conv', 'usot_plan_add_stem',
     'usot_plan_add_maxpool', 'usot_plan_add_groupdw', 'usot_plan_add_conf_reduce',
     'usot_plan_add_prroi', 'usot_plan_add_permute', 'usot_plan_add_decode', 'usot_plan_run',
@@ -144,6 +144,11 @@ def lib():
                                                   + [C.c_int64] * 8)
         L.PrRoIPoolingForwardGpu.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_int]
         L.PrRoIPoolingForwardGpu.restype = None
+        L.usot_prroi_pool_backward_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_float]
+        L.usot_prroi_pool_coor_backward_f32.argtypes = [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_float]
+        for name in ('PrRoIPoolingBackwardGpu', 'PrRoIPoolingCoorBackwardGpu'):
+            getattr(L, name).argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int]
+            getattr(L, name).restype = None
         L.usot_permute4_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_int64] * 4
         L.usot_decode_f32.argtypes = ([C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_float]
                                       + [C.c_double] * 4)
@@ -357,6 +362,30 @@ def prroi_pool(features, rois, ph=7, pw=7, scale=1.0, out_nhwc=False):
     check(lib().usot_prroi_pool_forward_f32(stream(), ptr(features), ptr(rois), ptr(out), R, Cc, H, W_, ph, pw,
                                             float(scale), fs[0], fs[1], fs[2], fs[3],
                                             os_[0], os_[1], os_[2], os_[3]), 'usot_prroi_pool_forward_f32')
+    return out
+
+
+def prroi_pool_backward(feature_shape, rois, top_diff, ph=7, pw=7, scale=1.0):
+    """Feature gradient of Precise RoI Pooling (functional.py:71-73 -> prroi_pooling_gpu.c:46-77): dense NCHW
+    [B,C,H,W] for top_diff [R,C,ph,pw]."""
+    _dev(rois), _dev(top_diff)
+    B, Cc, H, W_ = (int(v) for v in feature_shape)
+    rois, top_diff = rois.contiguous(), top_diff.contiguous()
+    out = torch.empty((B, Cc, H, W_), device=rois.device, dtype=torch.float32)        # zero-filled by the entry point
+    check(lib().usot_prroi_pool_backward_f32(stream(), ptr(rois), ptr(top_diff), ptr(out), rois.shape[0], B, Cc, H, W_,
+                                             ph, pw, float(scale)), 'usot_prroi_pool_backward_f32')
+    return out
+
+
+def prroi_pool_coor_backward(features, rois, top_data, top_diff, ph=7, pw=7, scale=1.0):
+    """RoI gradient [R,5] (functional.py:74-76 -> prroi_pooling_gpu.c:79-113); column 0 (batch index) is zero."""
+    _dev(features), _dev(rois)
+    B, Cc, H, W_ = features.shape
+    features, rois, top_data, top_diff = features.contiguous(), rois.contiguous(), top_data.contiguous(), top_diff.contiguous()
+    out = torch.zeros((rois.shape[0], 5), device=rois.device, dtype=torch.float32)
+    check(lib().usot_prroi_pool_coor_backward_f32(stream(), ptr(features), ptr(rois), ptr(top_data), ptr(top_diff), ptr(out),
+                                                  rois.shape[0], B, Cc, H, W_, ph, pw, float(scale)),
+          'usot_prroi_pool_coor_backward_f32')
     return out
 
 
