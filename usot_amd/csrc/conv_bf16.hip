@@ -242,6 +242,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
     };
 
     auto mma_tile = [&](int cur) {
+#ifdef USOT_LPABL_NOMMA      // scripts/ablate_lp.py: timing builds with parts of the kernel removed
+        return;
+#endif
         if constexpr (MF == 32) {
             const u32x4 *cX = sX + (cur * BM + wm * TM * 16 + l31) * LDC;
             const u32x4 *cW = sW + (cur * BN + wn * TN * 16 + l31) * LDC;
@@ -296,6 +299,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
     // stores alone were ~180 us of b7.ds's 690.  The DMA writes wave-base + lane*16, i.e. 8 rows x
     // 8 chunks per instruction in exactly this tile's row-major layout.
     auto issue_tile = [&](int buf, bool advance) {
+#ifdef USOT_LPABL_NOLOAD
+        return;
+#endif
         const int c0 = cur_cc * BKB;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
@@ -323,6 +329,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
     // asm LDS-DMA: invisible to the compiler's waitcnt bookkeeping (no vmcnt(0) before the next
     // ds_read or barrier); completion is counted by hand below
     auto dma16 = [&](const uint16_t *src, const u32x4 *dst) {
+#ifdef USOT_LPABL_NOLOAD
+        return;
+#endif
         const uint32_t lds = __builtin_amdgcn_readfirstlane(
             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)dst);
         unsigned keep;
@@ -448,7 +457,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
                 for (int q = 0; q < CH; ++q) {
                     const int r = orow + (q0 + q) * RPASS, m = bm0 + r;
                     rr[q] = u32x4{0u, 0u, 0u, 0u};
+#ifndef USOT_LPABL_NORES
                     if (p.res && cok && r < BM && m < p.M) rr[q] = *(const u32x4 *)(p.res + (long)m * p.Cout + co);
+#endif
                 }
 #pragma unroll
                 for (int q = 0; q < CH; ++q) {
@@ -475,6 +486,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
                     o[1] = pack_lp<F16>(v0[2]) | (pack_lp<F16>(v0[3]) << 16);
                     o[2] = pack_lp<F16>(v1[0]) | (pack_lp<F16>(v1[1]) << 16);
                     o[3] = pack_lp<F16>(v1[2]) | (pack_lp<F16>(v1[3]) << 16);
+#ifdef USOT_LPABL_NOSTORE
+                    if (o[0] == 0x12345678u)           // keeps the value live, never true in practice
+#endif
                     *(u32x4 *)(p.y + (long)m * p.Cout + co) = o;
                 }
             }
@@ -547,6 +561,9 @@ const TileB kTilesB[] = {
     TB32(128, 128, 4, 4), // 29: as 25 (one 32x32 tile per wave)
     TB32(256, 128, 4, 2), // 30: 8 wavefronts x (64 x 64)
     TB32(128, 256, 2, 4), // 31
+    // (4 wavefronts x (128 x 128) on a 256 x 256 tile - a quarter of tile 21's LDS fragment bytes per MFMA, accumulators in
+    //  AGPRs - measured 648 TFLOP/s on layer3's shortcut conv against 1 082-1 186 for tiles 21 / 22, 981 on the 32x32x16 MFMA:
+    //  one wave per SIMD under hipcc's schedule, 512 registers and spills.  Not kept.)
 };
 constexpr int kNumTilesB = sizeof(kTilesB) / sizeof(kTilesB[0]);
 
