@@ -104,6 +104,9 @@ def run_frames_multi(group, n):
             conf.append(float(sess.collect()[1]))
 
 
+K_PWPAIR = 18          # plan op kind of the fused pointwise pair (csrc/plan.hip)
+
+
 def roofline(sess, frames):
     """Dominant kernel = the conv_igemm_f32 tile instance with the largest total time."""
     prof = sess.plan.profile(frames=frames, reps=1)      # every op once per pass, in frame order (cold operands, as in a replay)
@@ -112,15 +115,17 @@ def roofline(sess, frames):
     agg, total_ms, conv_ms, conv_flops = {}, 0.0, 0.0, 0.0
     for kind, tile, ks, groups, ms in prof:
         total_ms += ms
-        if kind != 0:
+        if kind not in (0, K_PWPAIR):
             continue
         name, M, N, K, g, macs = next(convs)
+        conv_ms += ms
+        conv_flops += 2.0 * macs
+        if kind == K_PWPAIR:                      # fused conv3 + next conv1 (csrc/pw_pair_f32.hip): counted in all_convs,
+            continue                              # not a tile instance of the conv_igemm family
         a = agg.setdefault(tile, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += ms
         a[2] += 2.0 * macs
-        conv_ms += ms
-        conv_flops += 2.0 * macs
     tile, (n, ms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
     ach = fl / (ms * 1e-3) / 1e12
     # HBM bytes per launch cannot be counted from inside this process: they come from the committed

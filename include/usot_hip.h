@@ -120,11 +120,23 @@ typedef struct usot_pw_pair_desc {
     const float *b3, *b1;
     void *y, *t;
     int32_t M, CM, CO, CN, act2;
+    void *ws;             /* fp32 form only: usot_pw_pair_f32_ws_floats() zero-initialised floats, or NULL */
 } usot_pw_pair_desc;
 int usot_pw_pair_lp(void *stream, const usot_pw_pair_desc *d, int dtype);
 int usot_pw_pair_layout(int CM, int CO, int CN, int which, int32_t *row, int32_t *k0);   /* which: 0 = w3, 1 = w1 */
 int usot_pw_pair_supported(int CM, int CO, int CN);
-int usot_plan_add_pw_pair(void *plan, const usot_pw_pair_desc *d, int dtype);
+int usot_plan_add_pw_pair(void *plan, const usot_pw_pair_desc *d, int dtype);   /* dtype 2: the fp32 form below */
+
+/* the same pair in fp32 for the batch-1 frame (csrc/pw_pair_f32.hip; v_mfma_f32_16x16x4_f32, 16 pixels per workgroup):
+ * every pointer of the descriptor is float32.  w3p / w1 in fragment order: the float at
+ * [((cb * (K / 16) + r) * 64 + lane) * 4 + c] is W[cb * 16 + (lane & 15)][16 * r + 4 * (lane >> 4) + c]
+ * (W = the [rows][K] filter bank: K = CM for w3p, CO for w1).  Shapes: usot_pw_pair_f32_supported.
+ * With few pixel tiles (layer2 at batch 1-2) S = 4 workgroups share a tile, each owning a quarter of CO, and meet in
+ * d->ws (write-through slabs + a ticket per tile, as the in-launch split-K of the conv kernels): size from
+ * usot_pw_pair_f32_ws_floats (0 = not needed), zero before the first launch, owned by the caller; NULL = unsliced. */
+int usot_pw_pair_f32(void *stream, const usot_pw_pair_desc *d);
+int usot_pw_pair_f32_supported(int CM, int CO, int CN);
+int64_t usot_pw_pair_f32_ws_floats(int M, int CM, int CO, int CN);
 
 /* ---- stem: 7x7 / stride 2 / pad 0 conv, 3 -> 64 channels, + folded BN + ReLU ---------
  * modules.py:70-72,138-140.  x NCHW [N][3][H][W] (the API-edge crop, BGR 0..255),

@@ -10,7 +10,7 @@ model, _ = bench.build_model(0, 1, dev)
 sess, crops, p = bench.open_stream(model, dev, seed=0)
 conf = bench.Confidences()
 bench.run_frames(sess, crops, p, conf, 20)
-KINDS = {0: 'conv', 1: 'stem', 2: 'maxpool', 3: 'groupdw', 4: 'conf_reduce', 5: 'prroi', 6: 'permute', 7: 'decode', 10: 'rows', 15: 'rows_multi', 16: 'thin_conv (bbox_pred + cls_preds)', 17: 'stem_pool (fused)'}
+KINDS = {18: 'pw_pair (fused conv3 + next conv1)', 0: 'conv', 1: 'stem', 2: 'maxpool', 3: 'groupdw', 4: 'conf_reduce', 5: 'prroi', 6: 'permute', 7: 'decode', 10: 'rows', 15: 'rows_multi', 16: 'thin_conv (bbox_pred + cls_preds)', 17: 'stem_pool (fused)'}
 prof = sess.plan.profile(20)
 convs = iter(sess.log)
 tot = 0.0
@@ -20,6 +20,9 @@ for kind, tile, ks, groups, ms in prof:
     if kind == 0:
         nm, M, N, K, g, macs = next(convs)
         name = '%s M=%d N=%d K=%d g=%d tile=%s ks=%d' % (nm, M, N, K, g, hip.tile_name(tile) if tile else '?', ks)
+    elif kind == 18:
+        nm, M, N, K, g, macs = next(convs)
+        name = '%s M=%d (fused pair, %.2f GFLOP)' % (nm, M, 2e-9 * macs)
     print('%8.1f us  %s' % (ms * 1e3, name))
 print('sum %.1f us' % (tot * 1e3))
 torch.cuda.synchronize(); t0 = time.perf_counter()

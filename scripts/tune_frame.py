@@ -75,6 +75,8 @@ prof = p['plan'].profile(10)
 spans = {}
 convs = iter(p['log'])
 for kind, tile, ks, groups, ms in prof:
+    if kind == 18:                                            # fused pointwise pair: a log entry, no tile to choose
+        next(convs)
     if kind == 0:
         nm, M, N, K, g, macs = next(convs)
         k4 = (M, N, K, 1) if '+' in nm else (M, N, K, g)      # a batched launch runs on its lead problem's tile

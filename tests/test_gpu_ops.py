@@ -243,6 +243,37 @@ def test_prroi_pool_vs_independent_float64_oracle(layout):
         assert not (d2 > 2 * _prroi_tol(rois)).any()
 
 
+@pytest.mark.parametrize('cm,co,cn,M', [(64, 256, 64, 3969), (64, 256, 128, 3969), (128, 512, 128, 961), (128, 512, 256, 961),
+                                        (64, 256, 64, 7), (128, 512, 128, 2 * 961)])
+def test_pw_pair_f32_equals_the_two_convolutions(cm, co, cn, M):
+    """csrc/pw_pair_f32.hip: conv3 + residual + ReLU and the next block's conv1 + ReLU in one launch (fp32, batch-1
+    frame) against the two conv launches it replaces and against torch in float64."""
+    g = torch.Generator().manual_seed(cm + cn + M)
+    t2 = torch.randn(M, cm, generator=g)
+    w3 = torch.randn(co, cm, generator=g) / np.sqrt(cm)
+    b3 = torch.randn(co, generator=g)
+    res = torch.randn(M, co, generator=g)
+    w1 = torch.randn(cn, co, generator=g) / np.sqrt(co)
+    b1 = torch.randn(cn, generator=g)
+    y64 = F.relu(t2.double() @ w3.double().t() + b3.double() + res.double())
+    t64 = F.relu(y64 @ w1.double().t() + b1.double())
+    d = lambda t: t.to(DEV)
+    y, t = hip.pw_pair_f32(d(t2).reshape(1, 1, M, cm), d(w3), d(b3), d(res).reshape(1, 1, M, co), d(w1), d(b1))
+    e_y, e_t = rel_err(y.reshape(M, co).cpu().numpy(), y64.numpy()), rel_err(t.reshape(M, cn).cpu().numpy(), t64.numpy())
+    assert e_y < 1e-5 and e_t < 1e-5, (e_y, e_t)
+    # the two launches of the unfused path
+    y2 = hip.conv2d(d(t2).reshape(1, 1, M, cm), d(w3), d(b3), KH=1, KW=1, res=d(res).reshape(1, 1, M, co), act=hip.ACT_RELU)
+    t2b = hip.conv2d(y2, d(w1), d(b1), KH=1, KW=1, act=hip.ACT_RELU)
+    e_y, e_t = rel_err(y.cpu().numpy(), y2.cpu().numpy()), rel_err(t.cpu().numpy(), t2b.cpu().numpy())
+    assert e_y < 1e-5 and e_t < 1e-5, (e_y, e_t)
+    # the unsliced form of the same shape (the engine's default; the sliced one ran above when the shape has few pixel tiles)
+    y3, t3 = hip.pw_pair_f32(d(t2).reshape(1, 1, M, cm), d(w3), d(b3), d(res).reshape(1, 1, M, co), d(w1), d(b1), sliced=False)
+    assert torch.equal(y3, y) and rel_err(t3.cpu().numpy(), t.cpu().numpy()) < 1e-5
+    # no activation on the second conv (the neck form)
+    _, tn = hip.pw_pair_f32(d(t2).reshape(1, 1, M, cm), d(w3), d(b3), d(res).reshape(1, 1, M, co), d(w1), d(b1), act2=hip.ACT_NONE)
+    assert rel_err(tn.reshape(M, cn).cpu().numpy(), (y64 @ w1.double().t() + b1.double()).numpy()) < 1e-5
+
+
 def _prroi_grad_case(seed, shape, n):
     from prroi_cases import random_rois
     B, C, H, W = shape

@@ -105,7 +105,7 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
                                      op.f[0], op.d[0], op.d[1], (const double *)op.p[5], (float *)op.l[0]);
             break;
         case K_CONVB: rc = usot_conv2d_lp(s, &op.conv, op.i[6], op.i[7]); break;
-        case K_PWPAIR: rc = usot_pw_pair_lp(s, &op.pw, op.i[6]); break;
+        case K_PWPAIR: rc = op.i[6] == 2 ? usot_pw_pair_f32(s, &op.pw) : usot_pw_pair_lp(s, &op.pw, op.i[6]); break;
         case K_CVTB:  rc = usot_cvt_f32_to_lp(s, (const float *)op.p[0], (void *)op.p[1], op.l[0], op.i[6]); break;
         case K_POOLB:
             rc = usot_maxpool3x3s2_lp(s, op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6]);
@@ -239,7 +239,7 @@ extern "C" int usot_plan_add_conv_bf16(void *plan, const usot_conv_desc *d) { re
 
 extern "C" int usot_plan_add_pw_pair(void *plan, const usot_pw_pair_desc *d, int dtype)
 {
-    if (!d || !usot_pw_pair_supported(d->CM, d->CO, d->CN)) return USOT_EINVAL;
+    if (!d || !(dtype == 2 ? usot_pw_pair_f32_supported(d->CM, d->CO, d->CN) : usot_pw_pair_supported(d->CM, d->CO, d->CN))) return USOT_EINVAL;
     Op *op = push(plan, K_PWPAIR);
     if (!op) return USOT_ESTATE;
     op->pw = *d;

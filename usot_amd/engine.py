@@ -68,6 +68,12 @@ class PackedConv:
             cache[key] = hip.pw_pair_pack(self.w_lp(dtype), cm, co, cn, which)
         return cache[key]
 
+    def w_pw_pair_f32(self):
+        """fp32 filter bank in the fragment order of the fused fp32 pointwise-pair kernel (hip.pw_pair_f32_pack)."""
+        if '_wpp32' not in self.__dict__:
+            self._wpp32 = hip.pw_pair_f32_pack(self.w)
+        return self._wpp32
+
     def w_lp(self, dtype=torch.bfloat16):
         """bf16 / fp16 copy of the folded filter bank (made on first use; fp32 stays the master)."""
         cache = self.__dict__.setdefault('_wlp', {})
@@ -342,9 +348,16 @@ class Builder:
         self.plan.keep += [x]
         cur, h = p0, ph
         stages = [s0]
+        t1_fused = None                               # conv1 output of this block when the previous conv3 produced it
         for bi, (c1, c2, c3, ds) in enumerate(W.blocks):
             sc = cur
-            if ds is not None and self.lanes < 3:   # shortcut conv shares conv1's launch
+            if t1_fused is not None:
+                t1, t1_fused = t1_fused, None
+                if ds is not None:
+                    sc, hs, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
+                t2, h2, _ = self.conv('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
+                assert ds is None or hs == h2
+            elif ds is not None and self.lanes < 3:   # shortcut conv shares conv1's launch
                 (sc, hs, _), (t1, _, _) = self.conv_batch([('b%d.ds' % bi, ds, cur, n, h, h, {}),
                                                            ('b%d.conv1' % bi, c1, cur, n, h, h, dict(act=ACT_RELU))])
                 t2, h2, _ = self.conv('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
@@ -359,7 +372,12 @@ class Builder:
                 if ds is not None:
                     assert hs == h2
                     self.join(1)
-            cur, _, _ = self.conv('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc)
+            nxt = W.blocks[bi + 1][0] if bi + 1 < len(W.blocks) else None
+            if (nxt is not None and self.lanes == 0 and (c3.cin, c3.cout, nxt.cout) in FUSED_POINTWISE_F32
+                    and n * h2 * h2 <= FUSED_POINTWISE_F32_MAX_M):
+                cur, t1_fused = self.pw_pair_f32('b%d.conv3+b%d.conv1' % (bi, bi + 1), c3, nxt, t2, sc, n, h2)
+            else:
+                cur, _, _ = self.conv('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc)
             h = h2
             if bi in (2, 6, 12):                      # ends of layer1 / layer2 / layer3
                 stages.append(cur)
@@ -408,6 +426,25 @@ class Builder:
         hip.check(hip.lib().usot_plan_add_pw_pair(self.plan.h, C.byref(d), 1 if dtype == torch.float16 else 0),
                   'plan_add_pw_pair ' + name)
         self.plan.keep += [t2, res, w3p, w1, c3.b, nxt.b]
+        self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
+        return y, t
+
+    def pw_pair_f32(self, name, c3, nxt, t2, res, n, h, act2=ACT_RELU):
+        """fp32: conv3 + residual + ReLU and the next block's conv1 in ONE launch (csrc/pw_pair_f32.hip).
+        Returns (y [n,h,h,c3.cout], t [n,h,h,nxt.cout])."""
+        m = n * h * h
+        y = self.buf(n, h, h, c3.cout)
+        t = self.buf(n, h, h, nxt.cout)
+        w3p, w1p = c3.w_pw_pair_f32(), nxt.w_pw_pair_f32()
+        # channel-sliced form (four workgroups per pixel tile when there are few tiles): 13.6 -> 8.7 us per layer2 pair, but
+        # its k-sliced second GEMM moved ONE end-to-end golden output from 9.3e-5 to 1.011e-4 of the 1e-4 bar
+        # (scripts/golden_margins.py; rounding noise, every variant sits at 8-9.5e-5) - off unless asked for
+        ws = hip.pw_pair_f32_ws(m, c3.cin, c3.cout, nxt.cout, self.dev) if FUSED_POINTWISE_F32_SLICED else None
+        d = hip.pw_pair_desc(t2.data_ptr(), w3p.data_ptr(), c3.b.data_ptr(), res.data_ptr(), y.data_ptr(), w1p.data_ptr(),
+                             nxt.b.data_ptr(), t.data_ptr(), m, c3.cin, c3.cout, nxt.cout, act2,
+                             ws.data_ptr() if ws is not None else None)
+        hip.check(hip.lib().usot_plan_add_pw_pair(self.plan.h, C.byref(d), 2), 'plan_add_pw_pair(f32) ' + name)
+        self.plan.keep += [t2, res, w3p, w1p, c3.b, nxt.b, ws]
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
         return y, t
 
@@ -617,6 +654,12 @@ LP_TUNING = load_lp_tuning()
 # (C_mid, C_out, C_next) of the conv3 -> next-conv1 pairs that run as ONE launch (csrc/pw_pair.hip) in the batched
 # low-precision backbone: the shapes where the fused kernel measured faster than the two launches at batch 64
 FUSED_POINTWISE = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
+# the same fusion in the fp32 frame (csrc/pw_pair_f32.hip, 16 pixels per workgroup): at batch 1 these 1x1 layers are
+# launch-bound (two launches 20-23 us, fused 6-14: scripts/pw_pair_f32_probe.py).  Not (128, 512, 256): layer3.0's conv1
+# already rides in the shortcut conv's launch.  Above MAX_M pixels the tiled conv kernels fill the chip and win.
+FUSED_POINTWISE_F32 = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
+FUSED_POINTWISE_F32_MAX_M = 4 * 3969
+FUSED_POINTWISE_F32_SLICED = False
 
 
 class Engine:

@@ -29,7 +29,7 @@ EXPORTS = (
     'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
     'PrRoIPoolingForwardGpu', 'usot_groupdw_auto_variant',
-    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair',
+    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats',
 )
 
 
@@ -66,7 +66,8 @@ class GroupDWDesc(C.Structure):
 class PwPairDesc(C.Structure):
     _fields_ = [('t2', C.c_void_p), ('w3p', C.c_void_p), ('res', C.c_void_p), ('w1', C.c_void_p),
                 ('b3', C.c_void_p), ('b1', C.c_void_p), ('y', C.c_void_p), ('t', C.c_void_p),
-                ('M', C.c_int32), ('CM', C.c_int32), ('CO', C.c_int32), ('CN', C.c_int32), ('act2', C.c_int32)]
+                ('M', C.c_int32), ('CM', C.c_int32), ('CO', C.c_int32), ('CN', C.c_int32), ('act2', C.c_int32),
+                ('ws', C.c_void_p)]
 
 
 _lib = None
@@ -113,6 +114,10 @@ def lib():
         L.usot_plan_add_pw_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_pw_pair_layout.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int32)] * 2
         L.usot_pw_pair_supported.argtypes = [C.c_int] * 3
+        L.usot_pw_pair_f32.argtypes = [C.c_void_p, C.c_void_p]
+        L.usot_pw_pair_f32_supported.argtypes = [C.c_int] * 3
+        L.usot_pw_pair_f32_ws_floats.argtypes = [C.c_int] * 4
+        L.usot_pw_pair_f32_ws_floats.restype = C.c_int64
         L.usot_plan_add_cvt_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.usot_plan_add_maxpool_lp.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 7
         L.usot_conv2d_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -460,15 +465,51 @@ def pw_pair_pack(w, cm, co, cn, which):
     return w[r[:, None], cols].contiguous().reshape(-1)
 
 
+def pw_pair_f32_pack(w):
+    """fp32 filter bank [rows, K] -> the fragment order of usot_pw_pair_f32: (column block, round, quad, row in block, 4 k)."""
+    rows, k = w.shape
+    return w.reshape(rows // 16, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+
+def pw_pair_f32_supported(cm, co, cn):
+    return bool(lib().usot_pw_pair_f32_supported(int(cm), int(co), int(cn)))
+
+
+def pw_pair_f32(t2, w3, b3, res, w1, b1, act2=ACT_RELU, sliced=True):
+    """fp32 NHWC: Y = relu(t2 . w3^T + b3 + res), T = act2(Y . w1^T + b1); w3 [CO,CM], w1 [CN,CO] in natural order
+    (packed here).  Returns (Y, T)."""
+    for t in (t2, w3, b3, res, w1, b1):
+        _dev(t)
+    CM, (CO, CN) = t2.shape[-1], (w3.shape[0], w1.shape[0])
+    M = t2.numel() // CM
+    y = torch.empty(tuple(t2.shape[:-1]) + (CO,), device=t2.device, dtype=torch.float32)
+    t = torch.empty(tuple(t2.shape[:-1]) + (CN,), device=t2.device, dtype=torch.float32)
+    w3p, w1p = pw_pair_f32_pack(w3), pw_pair_f32_pack(w1)
+    ws = pw_pair_f32_ws(M, CM, CO, CN, t2.device) if sliced else None
+    d = pw_pair_desc(t2.data_ptr(), w3p.data_ptr(), b3.data_ptr(), res.data_ptr(), y.data_ptr(), w1p.data_ptr(), b1.data_ptr(),
+                     t.data_ptr(), M, CM, CO, CN, act2, ws.data_ptr() if ws is not None else None)
+    check(lib().usot_pw_pair_f32(stream(), C.byref(d)), 'usot_pw_pair_f32')
+    if ws is not None:
+        check(lib().usot_pw_pair_f32(stream(), C.byref(d)), 'usot_pw_pair_f32')      # a second launch finds the tickets reset
+    return y, t
+
+
 def pw_pair_supported(cm, co, cn):
     return bool(lib().usot_pw_pair_supported(int(cm), int(co), int(cn)))
 
 
-def pw_pair_desc(t2, w3p, b3, res, y, w1, b1, t, M, CM, CO, CN, act2):
+def pw_pair_desc(t2, w3p, b3, res, y, w1, b1, t, M, CM, CO, CN, act2, ws=None):
     d = PwPairDesc()
     d.t2, d.w3p, d.res, d.w1, d.b3, d.b1, d.y, d.t = t2, w3p, res, w1, b3, b1, y, t
     d.M, d.CM, d.CO, d.CN, d.act2 = M, CM, CO, CN, act2
+    d.ws = ws
     return d
+
+
+def pw_pair_f32_ws(M, CM, CO, CN, device):
+    """Zero-initialised workspace of the channel-sliced form of usot_pw_pair_f32, or None when the shape runs unsliced."""
+    n = lib().usot_pw_pair_f32_ws_floats(int(M), int(CM), int(CO), int(CN))
+    return torch.zeros(n, device=device, dtype=torch.float32) if n > 0 else None
 
 
 def pw_pair(t2, w3, b3, res, w1, b1, act2=ACT_RELU):
