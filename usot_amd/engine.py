@@ -13,6 +13,7 @@ returned cls/bbox maps).  reference call graph: lib/models/models.py:173-206,
 lib/models/connect.py:221-281, lib/models/modules.py:137-151.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -372,16 +373,26 @@ class Builder:
                 if ds is not None:
                     assert hs == h2
                     self.join(1)
-            nxt = W.blocks[bi + 1][0] if bi + 1 < len(W.blocks) else None
-            if (nxt is not None and self.lanes == 0 and (c3.cin, c3.cout, nxt.cout) in FUSED_POINTWISE_F32
-                    and n * h2 * h2 <= FUSED_POINTWISE_F32_MAX_M):
-                cur, t1_fused = self.pw_pair_f32('b%d.conv3+b%d.conv1' % (bi, bi + 1), c3, nxt, t2, sc, n, h2)
+            last = bi + 1 == len(W.blocks)
+            nxt = W.neck if last else W.blocks[bi + 1][0]
+            shape = (c3.cin, c3.cout, nxt.cout)
+            m2 = n * h2 * h2
+            fuse = self.lanes == 0 and nxt.kh == 1 and (
+                (shape in FUSED_POINTWISE_F32 and m2 <= FUSED_POINTWISE_F32_MAX_M) or
+                (FUSED_POINTWISE_F32_SLICED and shape in FUSED_POINTWISE_F32_SLICED_ONLY
+                 and hip.lib().usot_pw_pair_f32_ws_floats(m2, *shape) > 0))
+            if fuse:
+                cur, t1_fused = self.pw_pair_f32('b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1)), c3, nxt, t2, sc,
+                                                 n, h2, act2=ACT_NONE if last else ACT_RELU)
             else:
                 cur, _, _ = self.conv('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc)
             h = h2
             if bi in (2, 6, 12):                      # ends of layer1 / layer2 / layer3
                 stages.append(cur)
-        xf, _, _ = self.conv('neck', W.neck, cur, n, h, h)
+        if t1_fused is not None:                       # the neck rode in layer3's last conv3 launch
+            xf, t1_fused = t1_fused, None
+        else:
+            xf, _, _ = self.conv('neck', W.neck, cur, n, h, h)
         self.stages = stages
         return xf, h
 
@@ -659,7 +670,11 @@ FUSED_POINTWISE = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
 # already rides in the shortcut conv's launch.  Above MAX_M pixels the tiled conv kernels fill the chip and win.
 FUSED_POINTWISE_F32 = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
 FUSED_POINTWISE_F32_MAX_M = 4 * 3969
-FUSED_POINTWISE_F32_SLICED = False
+FUSED_POINTWISE_F32_SLICED = os.environ.get('USOT_FUSED_F32_SLICED', '0') == '1'
+# layer3's pairs (and conv3 + neck) exist in the channel-sliced form only (an unsliced 16 x 1024 Y tile does not fit) and
+# bought nothing inside the frame: 22-25 us per pair against 28 for the two launches in per-op spans, the graph replay
+# unchanged at 877 us (every pixel tile re-streams 2 MB of cold filters).  Kept for experiments with the switch above.
+FUSED_POINTWISE_F32_SLICED_ONLY = {(256, 1024, 256)}
 
 
 class Engine:
