@@ -138,6 +138,15 @@ int usot_pw_pair_f32(void *stream, const usot_pw_pair_desc *d);
 int usot_pw_pair_f32_supported(int CM, int CO, int CN);
 int64_t usot_pw_pair_f32_ws_floats(int M, int CM, int CO, int CN);
 
+/* one pointwise convolution of the fp32 frame in the same style (16 pixels per workgroup, the pixel tile in LDS, filters
+ * streamed from L2 in the fragment order above; several workgroups per pixel tile, each owning output channels):
+ * y[M][N] = act(x[M][K] . W^T + b (+ res)), all float32 dense, act USOT_ACT_NONE | USOT_ACT_RELU, res may be NULL.   */
+int usot_pw_single_f32(void *stream, const float *x, const float *wp, const float *b, const float *res, float *y,
+                       int M, int K, int N, int act);
+int usot_pw_single_f32_supported(int K, int N);
+int usot_plan_add_pw_single(void *plan, const float *x, const float *wp, const float *b, const float *res, float *y,
+                            int M, int K, int N, int act);
+
 /* ---- stem: 7x7 / stride 2 / pad 0 conv, 3 -> 64 channels, + folded BN + ReLU ---------
  * modules.py:70-72,138-140.  x NCHW [N][3][H][W] (the API-edge crop, BGR 0..255),
  * w packed [147][64] with row = (ci*7 + kh)*7 + kw, y NHWC [N][OH][OW][64].            */

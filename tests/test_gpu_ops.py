@@ -275,6 +275,26 @@ def test_pw_pair_f32_equals_the_two_convolutions(cm, co, cn, M):
     assert rel_err(tn.reshape(M, cn).cpu().numpy(), (y64 @ w1.double().t() + b1.double()).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('K,N,M,res', [(256, 1024, 961, True), (128, 512, 961, True), (1024, 256, 961, False), (512, 128, 1089, False),
+                                       (256, 1024, 5, True)])
+def test_pw_single_f32_streaming_conv(K, N, M, res):
+    """csrc/pw_pair_f32.hip: pw_single_f32_kernel (small-M 1x1 conv, filters streamed in fragment order) against float64
+    and against the tiled conv kernel it replaces for layer3's expansion convs at batch 1."""
+    g = torch.Generator().manual_seed(K + N + M)
+    x = torch.randn(1, 1, M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(1, 1, M, N, generator=g) if res else None
+    ref = F.relu(x.double().reshape(M, K) @ w.double().t() + b.double() + (r.double().reshape(M, N) if res else 0)).numpy()
+    d = lambda t: t.to(DEV) if t is not None else None
+    y = hip.pw_single_f32(d(x), d(w), d(b), d(r), hip.ACT_RELU)
+    assert rel_err(y.reshape(M, N).cpu().numpy(), ref) < 1e-5
+    y2 = hip.conv2d(d(x), d(w), d(b), KH=1, KW=1, res=d(r), act=hip.ACT_RELU)
+    assert rel_err(y.cpu().numpy(), y2.cpu().numpy()) < 1e-5
+    y3 = hip.pw_single_f32(d(x), d(w), d(b), None, hip.ACT_NONE)
+    assert rel_err(y3.reshape(M, N).cpu().numpy(), (x.double().reshape(M, K) @ w.double().t() + b.double()).numpy()) < 1e-5
+
+
 def _prroi_grad_case(seed, shape, n):
     from prroi_cases import random_rois
     B, C, H, W = shape

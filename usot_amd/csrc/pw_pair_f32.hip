@@ -40,24 +40,43 @@ struct PwF {
 
 // acc[u] (u < CBW) = sum over rounds [r0, r0 + RS) of W fragment (cb0 + u, r) x the B operand rows in LDS.
 // wf: the bank's fragment (cb, r) at wf[(cb * RT + r) * 64] (lane offset already applied); bs: this lane's LDS row.
+// A ring of PF filter fragments (1 KiB per wave each) stays in flight; gemm_prefetch fills it (callable before the B
+// operand is ready: in front of the barrier that publishes it), gemm_run consumes and refills it.
+template <int CBW, int RS, int RT, int PF>
+struct GemmRing {
+    static constexpr int N = CBW * RS;
+    static_assert(PF <= N, "ring deeper than the work");
+    f32x4 ring[PF];
+    __device__ __forceinline__ f32x4 frag(const f32x4 *__restrict__ wf, int cb0, int r0, int n) const
+    {
+        return wf[((cb0 + n / RS) * RT + r0 + n % RS) * 64];
+    }
+    __device__ __forceinline__ void prefetch(const f32x4 *__restrict__ wf, int cb0, int r0)
+    {
+#pragma unroll
+        for (int n = 0; n < PF; ++n) ring[n] = frag(wf, cb0, r0, n);
+    }
+    __device__ __forceinline__ void run(const f32x4 *__restrict__ wf, const float *bs, int cb0, int r0, f32x4 (&acc)[CBW])
+    {
+#pragma unroll
+        for (int u = 0; u < CBW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const f32x4 b = *(const f32x4 *)(bs + (r0 + n % RS) * 16);
+            const f32x4 a = ring[n % PF];
+            if (n + PF < N) ring[n % PF] = frag(wf, cb0, r0, n + PF);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[n / RS] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], acc[n / RS], 0, 0, 0);
+        }
+    }
+};
+
 template <int CBW, int RS, int RT>
 __device__ __forceinline__ void gemm_blocks(const f32x4 *__restrict__ wf, const float *bs, int cb0, int r0, f32x4 (&acc)[CBW])
 {
-    constexpr int N = CBW * RS, PF = N < 8 ? N : 8;
-    f32x4 ring[PF];
-    auto frag = [&](int n) { return wf[((cb0 + n / RS) * RT + r0 + n % RS) * 64]; };
-#pragma unroll
-    for (int n = 0; n < PF; ++n) ring[n] = frag(n);
-#pragma unroll
-    for (int u = 0; u < CBW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        const f32x4 b = *(const f32x4 *)(bs + (r0 + n % RS) * 16);
-        const f32x4 a = ring[n % PF];
-        if (n + PF < N) ring[n % PF] = frag(n + PF);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[n / RS] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], acc[n / RS], 0, 0, 0);
-    }
+    GemmRing<CBW, RS, RT, (CBW * RS < 8 ? CBW * RS : 8)> g;
+    g.prefetch(wf, cb0, r0);
+    g.run(wf, bs, cb0, r0, acc);
 }
 
 template <int CM, int COT, int CN, int S = 1>
@@ -187,6 +206,88 @@ int slices(int M, int CM, int CN)
     return 1;
 }
 
+// ---- one pointwise convolution in the same style, for layer3's 1x1 layers at batch 1 (M = 961: 61 pixel tiles): the
+// 16 x K pixel tile in LDS, N / 16 / S column blocks per workgroup (S workgroups per pixel tile, no exchange: each owns
+// its output channels), filters streamed in fragment order.  When a workgroup has fewer column blocks than waves the k
+// range is split over wave groups meeting in LDS.  Y = act(X . W^T + b (+ R)).
+struct Pw1 {
+    const float *x, *wp, *b, *res;
+    float *y;
+    int M, act;
+};
+
+template <int K, int N, int S, int PFD = 8>
+__global__ __launch_bounds__(512) void pw_single_f32_kernel(const Pw1 p)
+{
+    constexpr int NW = 8, BM = 16;
+    constexpr int RT = K / 16, NB = N / 16 / S;           // rounds, column blocks of this workgroup
+    constexpr int KS = NB >= NW ? 1 : NW / NB, CBW = NB >= NW ? NB / NW : 1, RS = RT / KS;
+    static_assert((NB % NW == 0 || NW % NB == 0) && RT % KS == 0, "shape");
+    constexpr int XP = K + 4, PP = NB * 16 + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds1[];
+    float *Xs = lds1;                                     // [BM][XP]
+    float *Ps = lds1 + BM * XP;                           // [(KS - 1)][BM][PP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int pt = (int)blockIdx.x / S, sl = (int)blockIdx.x % S;
+    const int bm0 = pt * BM, m = bm0 + l15;
+    const bool mok = m < p.M;
+    const int ksl = KS > 1 ? wave / NB : 0;
+    const int cb0 = KS > 1 ? wave % NB : wave * CBW;      // within the slice
+    const f32x4 *wf = (const f32x4 *)p.wp + lane + (long)sl * NB * RT * 64;
+    GemmRing<CBW, RS, RT, (CBW * RS < PFD ? CBW * RS : PFD)> g;
+    g.prefetch(wf, cb0, ksl * RS);                        // the filter stream starts before the pixel tile arrives
+    for (int i = tid; i < BM * (K / 4); i += NW * 64) {
+        const int row = i / (K / 4), c4 = i - row * (K / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (bm0 + row < p.M) v = *(const f32x4 *)(p.x + (long)(bm0 + row) * K + c4 * 4);
+        *(f32x4 *)(Xs + row * XP + c4 * 4) = v;
+    }
+    f32x4 rr[CBW], bb[CBW];
+#pragma unroll
+    for (int u = 0; u < CBW; ++u) {
+        const int n = (sl * NB + cb0 + u) * 16 + quad * 4;
+        rr[u] = (mok && p.res && ksl == 0) ? *(const f32x4 *)(p.res + (long)m * N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bb[u] = *(const f32x4 *)(p.b + n);
+    }
+    __syncthreads();
+    f32x4 acc[CBW];
+    g.run(wf, Xs + l15 * XP + quad * 4, cb0, ksl * RS, acc);
+    if constexpr (KS > 1) {
+        if (ksl > 0) *(f32x4 *)(Ps + ((ksl - 1) * BM + l15) * PP + cb0 * 16 + quad * 4) = acc[0];
+        __syncthreads();
+        if (ksl > 0) return;
+#pragma unroll
+        for (int s2 = 1; s2 < KS; ++s2) acc[0] += *(const f32x4 *)(Ps + ((s2 - 1) * BM + l15) * PP + cb0 * 16 + quad * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < CBW; ++u) {
+        f32x4 v = acc[u] + bb[u] + rr[u];
+        if (p.act == USOT_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (mok) *(f32x4 *)(p.y + (long)m * N + (sl * NB + cb0 + u) * 16 + quad * 4) = v;
+    }
+}
+
+template <int K, int N, int S> int launch1(hipStream_t s, const Pw1 &p)
+{
+    constexpr int NB = N / 16 / S, KS = NB >= 8 ? 1 : 8 / NB;
+    const size_t lds = (size_t)(16 * (K + 4) + (KS > 1 ? (KS - 1) * 16 * (NB * 16 + 4) : 0)) * sizeof(float);
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute((const void *)pw_single_f32_kernel<K, N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return USOT_ELAUNCH;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((pw_single_f32_kernel<K, N, S>), dim3(((p.M + 15) / 16) * S), dim3(512), lds, s, p);
+    return hipGetLastError() == hipSuccess ? USOT_OK : USOT_ELAUNCH;
+}
+
 }  // namespace
 
 extern "C" int usot_pw_pair_f32_supported(int CM, int CO, int CN)
@@ -220,5 +321,26 @@ extern "C" int usot_pw_pair_f32(void *stream, const usot_pw_pair_desc *d)
     if (d->CM == 128 && d->CO == 512 && d->CN == 128) return sliced ? launch<128, 512, 128, 4>(s, p) : launch<128, 512, 128>(s, p);
     if (d->CM == 128 && d->CO == 512 && d->CN == 256) return launch<128, 512, 256>(s, p);
     if (d->CM == 256 && d->CO == 1024 && d->CN == 256 && sliced) return launch<256, 1024, 256, 4>(s, p);   /* sliced only: an unsliced Y tile (64 KB) does not fit */
+    return USOT_EINVAL;
+}
+
+/* one pointwise convolution, small M: y[M][N] = act(x[M][K] . W^T + b (+ res)); wp = W in the fragment order above.
+ * Shapes (K, N): (1024, 256), (256, 1024), (512, 128), (128, 512). */
+extern "C" int usot_pw_single_f32_supported(int K, int N)
+{
+    return (K == 1024 && N == 256) || (K == 256 && N == 1024) || (K == 512 && N == 128) || (K == 128 && N == 512);
+}
+
+extern "C" int usot_pw_single_f32(void *stream, const float *x, const float *wp, const float *b, const float *res, float *y,
+                                  int M, int K, int N, int act)
+{
+    if (!x || !wp || !b || !y || M <= 0 || (act != USOT_ACT_NONE && act != USOT_ACT_RELU)) return USOT_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)b | (uintptr_t)res | (uintptr_t)y) & 15) return USOT_EINVAL;
+    const Pw1 p{x, wp, b, res, y, M, act};
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 1024 && N == 256) return launch1<1024, 256, 4>(s, p);
+    if (K == 256 && N == 1024) return launch1<256, 1024, 8>(s, p);
+    if (K == 512 && N == 128) return launch1<512, 128, 2>(s, p);
+    if (K == 128 && N == 512) return launch1<128, 512, 4>(s, p);
     return USOT_EINVAL;
 }

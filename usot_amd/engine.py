@@ -368,7 +368,7 @@ class Builder:
                     self.fork(1)
                     sc, hs, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
                     self.fork(0)
-                t1, _, _ = self.conv('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU)
+                t1, _, _ = self.conv1x1('b%d.conv1' % bi, c1, cur, n, h, act=ACT_RELU)
                 t2, h2, _ = self.conv('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
                 if ds is not None:
                     assert hs == h2
@@ -385,14 +385,14 @@ class Builder:
                 cur, t1_fused = self.pw_pair_f32('b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1)), c3, nxt, t2, sc,
                                                  n, h2, act2=ACT_NONE if last else ACT_RELU)
             else:
-                cur, _, _ = self.conv('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc)
+                cur, _, _ = self.conv1x1('b%d.conv3' % bi, c3, t2, n, h2, act=ACT_RELU, res=sc)
             h = h2
             if bi in (2, 6, 12):                      # ends of layer1 / layer2 / layer3
                 stages.append(cur)
         if t1_fused is not None:                       # the neck rode in layer3's last conv3 launch
             xf, t1_fused = t1_fused, None
         else:
-            xf, _, _ = self.conv('neck', W.neck, cur, n, h, h)
+            xf, _, _ = self.conv1x1('neck', W.neck, cur, n, h)
         self.stages = stages
         return xf, h
 
@@ -458,6 +458,25 @@ class Builder:
         self.plan.keep += [t2, res, w3p, w1p, c3.b, nxt.b, ws]
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
         return y, t
+
+    def pw_single(self, name, pc, x, n, h, act=ACT_NONE, res=None):
+        """fp32 1x1 convolution on the small-M streaming kernel (csrc/pw_pair_f32.hip: pw_single_f32_kernel)."""
+        m = n * h * h
+        y = self.buf(n, h, h, pc.cout)
+        wp = pc.w_pw_pair_f32()
+        hip.check(hip.lib().usot_plan_add_pw_single(self.plan.h, hip.ptr(x), hip.ptr(wp), hip.ptr(pc.b),
+                                                    hip.ptr(res) if res is not None else None, hip.ptr(y), m, pc.cin, pc.cout, act),
+                  'plan_add_pw_single ' + name)
+        self.plan.keep += [x, wp, pc.b, res]
+        self.log.append((name, m, pc.cout, pc.cin, 1, m * pc.cout * pc.cin))
+        return y, h, h
+
+    def conv1x1(self, name, pc, x, n, h, act=ACT_NONE, res=None):
+        """A backbone 1x1 convolution: the streaming kernel when the layer has few pixels (batch 1), else the tiled one."""
+        if (STREAM_1X1 and self.lanes == 0 and pc.kh == 1 and pc.stride == 1 and n * h * h <= STREAM_1X1_MAX_M
+                and (pc.cin, pc.cout) in STREAM_1X1_SHAPES and hip.lib().usot_pw_single_f32_supported(pc.cin, pc.cout)):
+            return self.pw_single(name, pc, x, n, h, act=act, res=res)
+        return self.conv(name, pc, x, n, h, h, act=act, res=res)
 
     def cvt_lp(self, src, dtype):
         dst = self.buf(*src.shape, dtype=dtype)
@@ -670,6 +689,12 @@ FUSED_POINTWISE = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
 # already rides in the shortcut conv's launch.  Above MAX_M pixels the tiled conv kernels fill the chip and win.
 FUSED_POINTWISE_F32 = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
 FUSED_POINTWISE_F32_MAX_M = 4 * 3969
+# the unfused 1x1 EXPANSION convolutions (conv3 of layer3's blocks and of layer2's last) on the small-M streaming kernel
+# up to this many pixels: graph replay 896.6 -> 878 us.  The 1024 -> 256 reductions gain nothing there (898 us with them
+# alone, 877-881 with everything): (Cin, Cout) pairs, overridable for experiments.
+STREAM_1X1 = os.environ.get('USOT_STREAM_1X1', '1') == '1'
+STREAM_1X1_MAX_M = 1200
+STREAM_1X1_SHAPES = {tuple(int(v) for v in t.split('x')) for t in os.environ.get('USOT_STREAM_1X1_SHAPES', '256x1024,128x512').split(',')}
 FUSED_POINTWISE_F32_SLICED = os.environ.get('USOT_FUSED_F32_SLICED', '0') == '1'
 # layer3's pairs (and conv3 + neck) exist in the channel-sliced form only (an unsliced 16 x 1024 Y tile does not fit) and
 # bought nothing inside the frame: 22-25 us per pair against 28 for the two launches in per-op spans, the graph replay

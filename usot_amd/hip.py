@@ -29,7 +29,7 @@ EXPORTS = (
     'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
     'PrRoIPoolingForwardGpu', 'usot_groupdw_auto_variant',
-    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats',
+    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single',
 )
 
 
@@ -118,6 +118,9 @@ def lib():
         L.usot_pw_pair_f32_supported.argtypes = [C.c_int] * 3
         L.usot_pw_pair_f32_ws_floats.argtypes = [C.c_int] * 4
         L.usot_pw_pair_f32_ws_floats.restype = C.c_int64
+        L.usot_pw_single_f32.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4
+        L.usot_pw_single_f32_supported.argtypes = [C.c_int] * 2
+        L.usot_plan_add_pw_single.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4
         L.usot_plan_add_cvt_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.usot_plan_add_maxpool_lp.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 7
         L.usot_conv2d_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -492,6 +495,18 @@ def pw_pair_f32(t2, w3, b3, res, w1, b1, act2=ACT_RELU, sliced=True):
     if ws is not None:
         check(lib().usot_pw_pair_f32(stream(), C.byref(d)), 'usot_pw_pair_f32')      # a second launch finds the tickets reset
     return y, t
+
+
+def pw_single_f32(x, w, b, res=None, act=ACT_NONE):
+    """fp32 NHWC pointwise convolution on the small-M streaming kernel: y = act(x . w^T + b (+ res)); w [N,K] natural order."""
+    _dev(x), _dev(w), _dev(b)
+    K, N = x.shape[-1], w.shape[0]
+    M = x.numel() // K
+    y = torch.empty(tuple(x.shape[:-1]) + (N,), device=x.device, dtype=torch.float32)
+    wp = pw_pair_f32_pack(w)
+    check(lib().usot_pw_single_f32(stream(), ptr(x), ptr(wp), ptr(b), ptr(res) if res is not None else None, ptr(y), M, K, N, act),
+          'usot_pw_single_f32')
+    return y
 
 
 def pw_pair_supported(cm, co, cn):
