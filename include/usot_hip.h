@@ -144,6 +144,15 @@ int64_t usot_pw_pair_f32_ws_floats(int M, int CM, int CO, int CN);
 int usot_pw_single_f32(void *stream, const float *x, const float *wp, const float *b, const float *res, float *y,
                        int M, int K, int N, int act);
 int usot_pw_single_f32_supported(int K, int N);
+/* 3x3 / stride-1 convolution in that form (the pixel tile is the 16 x 9 Cin im2col image, zeros for padding taps):
+ * x NHWC [Nb][H][W][Cin] dense, wp the packed bank [N][9 Cin] in fragment order, y [Nb * OH * OW][N] (+ res of that shape). */
+int usot_stream_conv3x3_f32(void *stream, const float *x, const float *wp, const float *b, const float *res, float *y,
+                            int Nb, int H, int W, int Cin, int OH, int OW, int N, int pad_h, int pad_w, int dil_h, int dil_w,
+                            int act);
+int usot_stream_conv3x3_f32_supported(int Cin, int N);
+int usot_plan_add_stream_conv3x3(void *plan, const float *x, const float *wp, const float *b, const float *res, float *y,
+                                 int Nb, int H, int W, int Cin, int OH, int OW, int N, int pad_h, int pad_w, int dil_h, int dil_w,
+                                 int act);
 int usot_plan_add_pw_single(void *plan, const float *x, const float *wp, const float *b, const float *res, float *y,
                             int M, int K, int N, int act);
 

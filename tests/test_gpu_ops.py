@@ -295,6 +295,23 @@ def test_pw_single_f32_streaming_conv(K, N, M, res):
     assert rel_err(y3.reshape(M, N).cpu().numpy(), (x.double().reshape(M, K) @ w.double().t() + b.double()).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('cin,n,nb,h,w,pad,dil', [(128, 128, 1, 31, 31, 1, 1), (256, 256, 1, 31, 31, 2, 2), (256, 256, 1, 15, 15, 1, 1),
+                                                  (128, 128, 2, 9, 11, 2, 2), (128, 128, 1, 7, 5, 0, 1)])
+def test_stream_conv3x3_f32(cin, n, nb, h, w, pad, dil):
+    """csrc/pw_pair_f32.hip: stream_conv3x3_f32_kernel (3x3 / stride 1 at small M: im2col pixel tile in LDS, filters streamed
+    in fragment order) against torch in float64 and against the tiled kernel."""
+    g = torch.Generator().manual_seed(cin + h * w + pad)
+    x = torch.randn(nb, cin, h, w, generator=g)
+    w4 = torch.randn(n, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    b = torch.randn(n, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w4.double(), b.double(), 1, pad, dil)).numpy()
+    xd, wd, bd = x.permute(0, 2, 3, 1).contiguous().to(DEV), pack_w(w4).to(DEV), b.to(DEV)
+    y = hip.stream_conv3x3_f32(xd, wd, bd, (pad, pad), (dil, dil), None, hip.ACT_RELU)
+    assert rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), ref) < 1e-5
+    y2 = hip.conv2d(xd, wd, bd, KH=3, KW=3, pad=(pad, pad), dil=(dil, dil), act=hip.ACT_RELU)
+    assert rel_err(y.cpu().numpy(), y2.cpu().numpy()) < 2e-5          # two float32 sums of up to 2304 products, each < 1e-5 from float64
+
+
 def _prroi_grad_case(seed, shape, n):
     from prroi_cases import random_rois
     B, C, H, W = shape

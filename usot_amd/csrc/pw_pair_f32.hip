@@ -288,6 +288,102 @@ template <int K, int N, int S> int launch1(hipStream_t s, const Pw1 &p)
     return hipGetLastError() == hipSuccess ? USOT_OK : USOT_ELAUNCH;
 }
 
+// ---- the same streaming form for 3x3 convolutions at small M (layer3 / layer2's conv2 at batch 1): the 16-pixel tile is
+// the im2col image of the pixels (16 x 9 Cin floats: 147 KB for Cin = 256, one workgroup per CU), built once from the
+// NHWC map with zeros for padding taps; k = (kh, kw, ci) as in the packed filter bank.  Stride 1.
+struct PwC {
+    const float *x, *wp, *b, *res;
+    float *y;
+    int M, H, W, OH, OW, pad_h, pad_w, dil_h, dil_w, act;
+};
+
+template <int CIN, int N, int S>
+__global__ __launch_bounds__(512) void stream_conv3x3_f32_kernel(const PwC p)
+{
+    constexpr int NW = 8, BM = 16, TAPS = 9, K = TAPS * CIN;
+    constexpr int RT = K / 16, NB = N / 16 / S;
+    constexpr int KS = NB >= NW ? 1 : NW / NB, CBW = NB >= NW ? NB / NW : 1, RS = RT / KS;
+    static_assert((NB % NW == 0 || NW % NB == 0) && RT % KS == 0, "shape");
+    constexpr int XP = K + 4, PP = NB * 16 + 4;
+    extern __shared__ __attribute__((aligned(16))) float ldsc[];
+    float *Xs = ldsc;                                     // [BM][XP]
+    float *Ps = ldsc + BM * XP;                           // [(KS - 1)][BM][PP]
+    __shared__ int pix[BM][3];                            // (row base of the image, oh - pad, ow - pad) per pixel, -1 = past M
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int pt = (int)blockIdx.x / S, sl = (int)blockIdx.x % S;
+    const int bm0 = pt * BM, m = bm0 + l15;
+    const bool mok = m < p.M;
+    const int ksl = KS > 1 ? wave / NB : 0;
+    const int cb0 = KS > 1 ? wave % NB : wave * CBW;
+    const f32x4 *wf = (const f32x4 *)p.wp + lane + (long)sl * NB * RT * 64;
+    GemmRing<CBW, RS, RT, 8> g;
+    g.prefetch(wf, cb0, ksl * RS);
+    if (tid < BM) {
+        const int mm = bm0 + tid;
+        if (mm < p.M) {
+            const int P = p.OH * p.OW, n = mm / P, r = mm - n * P, oh = r / p.OW;
+            pix[tid][0] = n * p.H;
+            pix[tid][1] = oh - p.pad_h;
+            pix[tid][2] = (r - oh * p.OW) - p.pad_w;
+        } else {
+            pix[tid][0] = -1;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < BM * TAPS * (CIN / 4); i += NW * 64) {
+        const int c4 = i % (CIN / 4), t = (i / (CIN / 4)) % TAPS, row = i / (TAPS * (CIN / 4));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pix[row][0] >= 0) {
+            const int ih = pix[row][1] + (t / 3) * p.dil_h, iw = pix[row][2] + (t % 3) * p.dil_w;
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                v = *(const f32x4 *)(p.x + ((long)(pix[row][0] + ih) * p.W + iw) * CIN + c4 * 4);
+        }
+        *(f32x4 *)(Xs + row * XP + t * CIN + c4 * 4) = v;
+    }
+    f32x4 rr[CBW], bb[CBW];
+#pragma unroll
+    for (int u = 0; u < CBW; ++u) {
+        const int n = (sl * NB + cb0 + u) * 16 + quad * 4;
+        rr[u] = (mok && p.res && ksl == 0) ? *(const f32x4 *)(p.res + (long)m * N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bb[u] = *(const f32x4 *)(p.b + n);
+    }
+    __syncthreads();
+    f32x4 acc[CBW];
+    g.run(wf, Xs + l15 * XP + quad * 4, cb0, ksl * RS, acc);
+    if constexpr (KS > 1) {
+        if (ksl > 0) *(f32x4 *)(Ps + ((ksl - 1) * BM + l15) * PP + cb0 * 16 + quad * 4) = acc[0];
+        __syncthreads();
+        if (ksl > 0) return;
+#pragma unroll
+        for (int s2 = 1; s2 < KS; ++s2) acc[0] += *(const f32x4 *)(Ps + ((s2 - 1) * BM + l15) * PP + cb0 * 16 + quad * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < CBW; ++u) {
+        f32x4 v = acc[u] + bb[u] + rr[u];
+        if (p.act == USOT_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (mok) *(f32x4 *)(p.y + (long)m * N + (sl * NB + cb0 + u) * 16 + quad * 4) = v;
+    }
+}
+
+template <int CIN, int N, int S> int launch3(hipStream_t s, const PwC &p)
+{
+    constexpr int K = 9 * CIN, NB = N / 16 / S, KS = NB >= 8 ? 1 : 8 / NB;
+    const size_t lds = (size_t)(16 * (K + 4) + (KS > 1 ? (KS - 1) * 16 * (NB * 16 + 4) : 0)) * sizeof(float);
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        if (hipFuncSetAttribute((const void *)stream_conv3x3_f32_kernel<CIN, N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return USOT_ELAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((stream_conv3x3_f32_kernel<CIN, N, S>), dim3(((p.M + 15) / 16) * S), dim3(512), lds, s, p);
+    return hipGetLastError() == hipSuccess ? USOT_OK : USOT_ELAUNCH;
+}
+
 }  // namespace
 
 extern "C" int usot_pw_pair_f32_supported(int CM, int CO, int CN)
@@ -342,5 +438,23 @@ extern "C" int usot_pw_single_f32(void *stream, const float *x, const float *wp,
     if (K == 256 && N == 1024) return launch1<256, 1024, 8>(s, p);
     if (K == 512 && N == 128) return launch1<512, 128, 2>(s, p);
     if (K == 128 && N == 512) return launch1<128, 512, 4>(s, p);
+    return USOT_EINVAL;
+}
+
+/* 3x3 / stride 1 convolution, small M, same streaming form: x NHWC [Nb][H][W][Cin] dense, wp = the packed bank
+ * [N][9 * Cin] ((kh, kw, ci) order) in fragment order, y [M = Nb * OH * OW][N].  Shapes (Cin, N): (256, 256), (128, 128). */
+extern "C" int usot_stream_conv3x3_f32_supported(int Cin, int N) { return (Cin == 256 && N == 256) || (Cin == 128 && N == 128); }
+
+extern "C" int usot_stream_conv3x3_f32(void *stream, const float *x, const float *wp, const float *b, const float *res, float *y,
+                                       int Nb, int H, int W, int Cin, int OH, int OW, int N, int pad_h, int pad_w, int dil_h, int dil_w,
+                                       int act)
+{
+    if (!x || !wp || !b || !y || Nb <= 0 || (act != USOT_ACT_NONE && act != USOT_ACT_RELU)) return USOT_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)b | (uintptr_t)res | (uintptr_t)y) & 15) return USOT_EINVAL;
+    if (OH != H + 2 * pad_h - 2 * dil_h || OW != W + 2 * pad_w - 2 * dil_w || OH <= 0 || OW <= 0) return USOT_EINVAL;
+    const PwC p{x, wp, b, res, y, Nb * OH * OW, H, W, OH, OW, pad_h, pad_w, dil_h, dil_w, act};
+    hipStream_t s = (hipStream_t)stream;
+    if (Cin == 256 && N == 256) return launch3<256, 256, 4>(s, p);
+    if (Cin == 128 && N == 128) return launch3<128, 128, 4>(s, p);
     return USOT_EINVAL;
 }

@@ -356,12 +356,12 @@ class Builder:
                 t1, t1_fused = t1_fused, None
                 if ds is not None:
                     sc, hs, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
-                t2, h2, _ = self.conv('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
+                t2, h2, _ = self.conv3x3('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
                 assert ds is None or hs == h2
             elif ds is not None and self.lanes < 3:   # shortcut conv shares conv1's launch
                 (sc, hs, _), (t1, _, _) = self.conv_batch([('b%d.ds' % bi, ds, cur, n, h, h, {}),
                                                            ('b%d.conv1' % bi, c1, cur, n, h, h, dict(act=ACT_RELU))])
-                t2, h2, _ = self.conv('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
+                t2, h2, _ = self.conv3x3('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
                 assert hs == h2
             else:
                 if ds is not None:                # shortcut conv on its own lane beside conv1 -> conv2
@@ -369,7 +369,7 @@ class Builder:
                     sc, hs, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
                     self.fork(0)
                 t1, _, _ = self.conv1x1('b%d.conv1' % bi, c1, cur, n, h, act=ACT_RELU)
-                t2, h2, _ = self.conv('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
+                t2, h2, _ = self.conv3x3('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
                 if ds is not None:
                     assert hs == h2
                     self.join(1)
@@ -470,6 +470,27 @@ class Builder:
         self.plan.keep += [x, wp, pc.b, res]
         self.log.append((name, m, pc.cout, pc.cin, 1, m * pc.cout * pc.cin))
         return y, h, h
+
+    def stream3x3(self, name, pc, x, n, h, w, act=ACT_NONE):
+        """fp32 3x3 / stride-1 convolution on the small-M streaming kernel (stream_conv3x3_f32_kernel)."""
+        oh, ow = pc.out_hw(h, w)
+        y = self.buf(n, oh, ow, pc.cout)
+        wp = pc.w_pw_pair_f32()
+        hip.check(hip.lib().usot_plan_add_stream_conv3x3(self.plan.h, hip.ptr(x), hip.ptr(wp), hip.ptr(pc.b), None, hip.ptr(y),
+                                                         n, h, w, pc.cin, oh, ow, pc.cout, pc.pad[0], pc.pad[1], pc.dil[0], pc.dil[1], act),
+                  'plan_add_stream_conv3x3 ' + name)
+        self.plan.keep += [x, wp, pc.b]
+        self.log.append((name, n * oh * ow, pc.cout, 9 * pc.cin, 1, n * oh * ow * pc.cout * 9 * pc.cin))
+        return y, oh, ow
+
+    def conv3x3(self, name, pc, x, n, h, w, act=ACT_NONE):
+        """A backbone 3x3 convolution: the streaming kernel for the shapes / sizes where it wins at batch 1, else tiled."""
+        oh, ow = pc.out_hw(h, w)
+        tiles = (n * oh * ow + 15) // 16
+        if (STREAM_3X3 and self.lanes == 0 and pc.kh == 3 and pc.stride == 1 and (pc.cin, pc.cout) in STREAM_3X3_SHAPES
+                and tiles * 4 <= 256 and hip.lib().usot_stream_conv3x3_f32_supported(pc.cin, pc.cout)):
+            return self.stream3x3(name, pc, x, n, h, w, act=act)
+        return self.conv(name, pc, x, n, h, w, act=act)
 
     def conv1x1(self, name, pc, x, n, h, act=ACT_NONE, res=None):
         """A backbone 1x1 convolution: the streaming kernel when the layer has few pixels (batch 1), else the tiled one."""
@@ -694,6 +715,12 @@ FUSED_POINTWISE_F32_MAX_M = 4 * 3969
 # alone, 877-881 with everything): (Cin, Cout) pairs, overridable for experiments.
 STREAM_1X1 = os.environ.get('USOT_STREAM_1X1', '1') == '1'
 STREAM_1X1_MAX_M = 1200
+# conv2 (3x3, stride 1) on the streaming form when its pixel tiles x 4 channel slices fit one wave of workgroups (255-pixel
+# crops at batch 1: 61 tiles): (Cin, Cout) pairs.  layer2's (128 -> 128, K = 1152): 10.9 -> 7.4 us isolated, graph replay
+# 881.7 -> 875.0 us.  layer3's (256 -> 256, K = 2304) streams 144 MB of filters per layer from L2 - 20.3 -> 18.6 us isolated
+# but 878 -> 892 us in the frame - and stays on the tiled kernel.
+STREAM_3X3 = os.environ.get('USOT_STREAM_3X3', '1') == '1'
+STREAM_3X3_SHAPES = {tuple(int(v) for v in t.split('x')) for t in os.environ.get('USOT_STREAM_3X3_SHAPES', '128x128').split(',')}
 STREAM_1X1_SHAPES = {tuple(int(v) for v in t.split('x')) for t in os.environ.get('USOT_STREAM_1X1_SHAPES', '256x1024,128x512').split(',')}
 FUSED_POINTWISE_F32_SLICED = os.environ.get('USOT_FUSED_F32_SLICED', '0') == '1'
 # layer3's pairs (and conv3 + neck) exist in the channel-sliced form only (an unsliced 16 x 1024 Y tile does not fit) and

@@ -29,7 +29,7 @@ EXPORTS = (
     'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
     'PrRoIPoolingForwardGpu', 'usot_groupdw_auto_variant',
-    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single',
+    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single', 'usot_stream_conv3x3_f32', 'usot_stream_conv3x3_f32_supported', 'usot_plan_add_stream_conv3x3',
 )
 
 
@@ -121,6 +121,9 @@ def lib():
         L.usot_pw_single_f32.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4
         L.usot_pw_single_f32_supported.argtypes = [C.c_int] * 2
         L.usot_plan_add_pw_single.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4
+        L.usot_stream_conv3x3_f32.argtypes = [C.c_void_p] * 6 + [C.c_int] * 12
+        L.usot_plan_add_stream_conv3x3.argtypes = [C.c_void_p] * 6 + [C.c_int] * 12
+        L.usot_stream_conv3x3_f32_supported.argtypes = [C.c_int] * 2
         L.usot_plan_add_cvt_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.usot_plan_add_maxpool_lp.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 7
         L.usot_conv2d_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -506,6 +509,19 @@ def pw_single_f32(x, w, b, res=None, act=ACT_NONE):
     wp = pw_pair_f32_pack(w)
     check(lib().usot_pw_single_f32(stream(), ptr(x), ptr(wp), ptr(b), ptr(res) if res is not None else None, ptr(y), M, K, N, act),
           'usot_pw_single_f32')
+    return y
+
+
+def stream_conv3x3_f32(x, w, b, pad, dil, res=None, act=ACT_NONE):
+    """fp32 NHWC 3x3 / stride-1 convolution on the small-M streaming kernel; w packed [N, 9*Cin] in (kh, kw, ci) order."""
+    _dev(x), _dev(w), _dev(b)
+    Nb, H, W_, Cin = x.shape
+    N = w.shape[0]
+    OH, OW = H + 2 * pad[0] - 2 * dil[0], W_ + 2 * pad[1] - 2 * dil[1]
+    y = torch.empty((Nb, OH, OW, N), device=x.device, dtype=torch.float32)
+    wp = pw_pair_f32_pack(w)
+    check(lib().usot_stream_conv3x3_f32(stream(), ptr(x), ptr(wp), ptr(b), ptr(res) if res is not None else None, ptr(y),
+                                        Nb, H, W_, Cin, OH, OW, N, pad[0], pad[1], dil[0], dil[1], act), 'usot_stream_conv3x3_f32')
     return y
 
 
