@@ -104,7 +104,7 @@ def run_frames_multi(group, n):
             conf.append(float(sess.collect()[1]))
 
 
-K_PWPAIR, K_PW1, K_SC3 = 18, 19, 20          # plan op kinds of the fused pointwise pair / the streaming 1x1 and 3x3 convs (csrc/plan.hip)
+K_PWPAIR, K_PW1, K_SC3, K_PW3 = 18, 19, 20, 21          # plan op kinds of the fused pointwise pair / the streaming 1x1 and 3x3 convs (csrc/plan.hip)
 
 
 def roofline(sess, frames):
@@ -115,12 +115,12 @@ def roofline(sess, frames):
     agg, total_ms, conv_ms, conv_flops = {}, 0.0, 0.0, 0.0
     for kind, tile, ks, groups, ms in prof:
         total_ms += ms
-        if kind not in (0, K_PWPAIR, K_PW1, K_SC3):
+        if kind not in (0, K_PWPAIR, K_PW1, K_SC3, K_PW3):
             continue
         name, M, N, K, g, macs = next(convs)
         conv_ms += ms
         conv_flops += 2.0 * macs
-        if kind in (K_PWPAIR, K_PW1, K_SC3):      # csrc/pw_pair_f32.hip kernels: counted in all_convs,
+        if kind in (K_PWPAIR, K_PW1, K_SC3, K_PW3):   # csrc/pw_pair_f32.hip kernels: counted in all_convs,
             continue                              # not a tile instance of the conv_igemm family
         a = agg.setdefault(tile, [0, 0.0, 0.0])
         a[0] += 1

@@ -144,6 +144,16 @@ int64_t usot_pw_pair_f32_ws_floats(int M, int CM, int CO, int CN);
 int usot_pw_single_f32(void *stream, const float *x, const float *wp, const float *b, const float *res, float *y,
                        int M, int K, int N, int act);
 int usot_pw_single_f32_supported(int K, int N);
+/* a whole bottleneck tail in one launch (layer1 of the fp32 frame): conv2 (3x3 / stride 1) + BN + ReLU on the im2col pixel
+ * tile, then the pair of usot_pw_pair_f32 on its output without leaving the CU.  x NHWC [Nb][H][W][Cin] (conv1's output);
+ * w2p conv2's packed bank [CM][9 Cin] in fragment order; d as for usot_pw_pair_f32 (d->t2 and d->ws ignored,
+ * d->M = Nb * OH * OW).                                                                                               */
+int usot_pw_triple_f32(void *stream, const float *x, const float *w2p, const float *b2, const usot_pw_pair_desc *d,
+                       int Nb, int H, int W, int Cin, int OH, int OW, int pad_h, int pad_w, int dil_h, int dil_w);
+int usot_pw_triple_f32_supported(int Cin, int CM, int CO, int CN);
+int usot_plan_add_pw_triple(void *plan, const float *x, const float *w2p, const float *b2, const usot_pw_pair_desc *d,
+                            int Nb, int H, int W, int Cin, int OH, int OW, int pad_h, int pad_w, int dil_h, int dil_w);
+
 /* 3x3 / stride-1 convolution in that form (the pixel tile is the 16 x 9 Cin im2col image, zeros for padding taps):
  * x NHWC [Nb][H][W][Cin] dense, wp the packed bank [N][9 Cin] in fragment order, y [Nb * OH * OW][N] (+ res of that shape). */
 int usot_stream_conv3x3_f32(void *stream, const float *x, const float *wp, const float *b, const float *res, float *y,

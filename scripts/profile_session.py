@@ -20,9 +20,9 @@ for kind, tile, ks, groups, ms in prof:
     if kind == 0:
         nm, M, N, K, g, macs = next(convs)
         name = '%s M=%d N=%d K=%d g=%d tile=%s ks=%d' % (nm, M, N, K, g, hip.tile_name(tile) if tile else '?', ks)
-    elif kind in (18, 19, 20):
+    elif kind in (18, 19, 20, 21):
         nm, M, N, K, g, macs = next(convs)
-        name = '%s M=%d (%s, %.2f GFLOP)' % (nm, M, 'fused pair' if kind == 18 else 'streaming N=%d K=%d' % (N, K), 2e-9 * macs)
+        name = '%s M=%d (%s, %.2f GFLOP)' % (nm, M, 'fused pair' if kind == 18 else 'fused conv2 + pair' if kind == 21 else 'streaming N=%d K=%d' % (N, K), 2e-9 * macs)
     print('%8.1f us  %s' % (ms * 1e3, name))
 print('sum %.1f us' % (tot * 1e3))
 torch.cuda.synchronize(); t0 = time.perf_counter()

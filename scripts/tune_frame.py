@@ -75,7 +75,7 @@ prof = p['plan'].profile(10)
 spans = {}
 convs = iter(p['log'])
 for kind, tile, ks, groups, ms in prof:
-    if kind in (18, 19, 20):                                          # fused pointwise pair: a log entry, no tile to choose
+    if kind in (18, 19, 20, 21):                                          # fused pointwise pair: a log entry, no tile to choose
         next(convs)
     if kind == 0:
         nm, M, N, K, g, macs = next(convs)

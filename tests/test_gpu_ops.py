@@ -312,6 +312,34 @@ def test_stream_conv3x3_f32(cin, n, nb, h, w, pad, dil):
     assert rel_err(y.cpu().numpy(), y2.cpu().numpy()) < 2e-5          # two float32 sums of up to 2304 products, each < 1e-5 from float64
 
 
+@pytest.mark.parametrize('cin,cn,nb,h,w', [(64, 64, 1, 63, 63), (64, 128, 1, 63, 63), (64, 64, 2, 9, 7), (64, 128, 1, 67, 67),
+                                            (128, 128, 1, 31, 31), (128, 128, 2, 6, 5)])
+def test_pw_triple_f32_equals_three_convolutions(cin, cn, nb, h, w):
+    """csrc/pw_pair_f32.hip: pw_triple_f32_kernel — layer1's conv2 (3x3) + conv3 + residual + ReLU + next conv1 in one launch —
+    against float64 and against the three launches it replaces."""
+    cm, co = cin, 4 * cin
+    g = torch.Generator().manual_seed(cn + h)
+    x = torch.randn(nb, cin, h, w, generator=g)
+    w2 = torch.randn(cm, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    b2 = torch.randn(cm, generator=g)
+    w3 = torch.randn(co, cm, generator=g) / np.sqrt(cm)
+    b3 = torch.randn(co, generator=g)
+    res = torch.randn(nb, h, w, co, generator=g)
+    w1 = torch.randn(cn, co, generator=g) / np.sqrt(co)
+    b1 = torch.randn(cn, generator=g)
+    t2 = F.relu(F.conv2d(x.double(), w2.double(), b2.double(), 1, 1, 1)).permute(0, 2, 3, 1)
+    y64 = F.relu(t2 @ w3.double().t() + b3.double() + res.double())
+    t64 = F.relu(y64 @ w1.double().t() + b1.double())
+    d = lambda t: t.to(DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y, t = hip.pw_triple_f32(xd, pack_w(w2).to(DEV), d(b2), d(w3), d(b3), d(res), d(w1), d(b1))
+    e_y, e_t = rel_err(y.cpu().numpy(), y64.numpy()), rel_err(t.cpu().numpy(), t64.numpy())
+    assert e_y < 1e-5 and e_t < 1e-5, (e_y, e_t)
+    t2d = hip.conv2d(xd, pack_w(w2).to(DEV), d(b2), KH=3, KW=3, pad=(1, 1), act=hip.ACT_RELU)
+    y2, tt = hip.pw_pair_f32(t2d, d(w3), d(b3), d(res), d(w1), d(b1))
+    assert rel_err(y.cpu().numpy(), y2.cpu().numpy()) < 1e-5 and rel_err(t.cpu().numpy(), tt.cpu().numpy()) < 1e-5
+
+
 def _prroi_grad_case(seed, shape, n):
     from prroi_cases import random_rois
     B, C, H, W = shape

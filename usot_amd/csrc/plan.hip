@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3 };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3, K_PW3 };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -106,6 +106,10 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
             break;
         case K_CONVB: rc = usot_conv2d_lp(s, &op.conv, op.i[6], op.i[7]); break;
         case K_PWPAIR: rc = op.i[6] == 2 ? usot_pw_pair_f32(s, &op.pw) : usot_pw_pair_lp(s, &op.pw, op.i[6]); break;
+        case K_PW3:
+            rc = usot_pw_triple_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], &op.pw,
+                                    op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], op.i[7], (int)op.l[0], (int)op.l[1]);
+            break;
         case K_SC3:
             rc = usot_stream_conv3x3_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], (const float *)op.p[3],
                                          (float *)op.p[4], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], op.i[7],
@@ -264,6 +268,19 @@ extern "C" int usot_plan_add_pw_single(void *plan, const float *x, const float *
     if (!op) return USOT_ESTATE;
     op->p[0] = x; op->p[1] = wp; op->p[2] = b; op->p[3] = res; op->p[4] = y;
     op->i[0] = M; op->i[1] = K; op->i[2] = N; op->i[3] = act;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_pw_triple(void *plan, const float *x, const float *w2p, const float *b2, const usot_pw_pair_desc *d,
+                                       int Nb, int H, int W, int Cin, int OH, int OW, int pad_h, int pad_w, int dil_h, int dil_w)
+{
+    if (!d || !usot_pw_triple_f32_supported(Cin, d->CM, d->CO, d->CN)) return USOT_EINVAL;
+    Op *op = push(plan, K_PW3);
+    if (!op) return USOT_ESTATE;
+    op->pw = *d;
+    op->p[0] = x; op->p[1] = w2p; op->p[2] = b2;
+    op->i[0] = Nb; op->i[1] = H; op->i[2] = W; op->i[3] = Cin; op->i[4] = OH; op->i[5] = OW; op->i[6] = pad_h; op->i[7] = pad_w;
+    op->l[0] = dil_h; op->l[1] = dil_w;
     return USOT_OK;
 }
 

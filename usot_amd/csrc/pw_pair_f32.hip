@@ -79,8 +79,10 @@ __device__ __forceinline__ void gemm_blocks(const f32x4 *__restrict__ wf, const 
     g.run(wf, bs, cb0, r0, acc);
 }
 
-template <int CM, int COT, int CN, int S = 1>
-__global__ __launch_bounds__(512) void pw_pair_f32_kernel(const PwF p)
+// Everything after "the pixel tile is in LDS": GEMM1 + residual + ReLU -> Y (global + LDS), GEMM2 (+ wave-group / workgroup
+// meeting) -> T.  Xs: the [16][CM + 4] tile (published by a barrier before the call); Ys / Ps: scratch.
+template <int CM, int COT, int CN, int S>
+__device__ __forceinline__ void pair_tail(const PwF &p, const float *Xs, float *Ys, float *Ps, int pt, int sl)
 {
     constexpr int NW = 8, BM = 16;
     constexpr int CO = COT / S;                           // channels of Y this workgroup owns
@@ -93,36 +95,20 @@ __global__ __launch_bounds__(512) void pw_pair_f32_kernel(const PwF p)
     static_assert(NB1 % NW == 0 && (NB2 % NW == 0 || NW % NB2 == 0) && R2 % KS == 0, "shape");
     static_assert(S == 1 || KS == 1, "the sliced form keeps GEMM2's k range of a workgroup in one piece");
     constexpr int XP = CM + 4, YP = CO + 4, PP = CN + 4;  // LDS row pitches (floats): 16 B aligned, rows spread over banks
-    __shared__ __attribute__((aligned(16))) float Xs[BM * XP];
-    __shared__ __attribute__((aligned(16))) float Ys[BM * YP];
-    __shared__ __attribute__((aligned(16))) float Ps[(KS > 1 ? (KS - 1) * BM * PP : 16)];
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, quad = lane >> 4;
-    const int pt = S > 1 ? (int)blockIdx.x / S : (int)blockIdx.x, sl = S > 1 ? (int)blockIdx.x % S : 0;
-    const int bm0 = pt * BM;
-    const int m = bm0 + l15;
+    const int m = pt * BM + l15;
     const bool mok = m < p.M;
 
-    // pixel tile -> LDS (rows past M are zero)
-    for (int i = tid; i < BM * (CM / 4); i += NW * 64) {
-        const int row = i / (CM / 4), c4 = i - row * (CM / 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (bm0 + row < p.M) v = *(const f32x4 *)(p.t2 + (long)(bm0 + row) * CM + c4 * 4);
-        *(f32x4 *)(Xs + row * XP + c4 * 4) = v;
-    }
-    // residual and bias of this wave's column blocks fly under GEMM1
-    f32x4 rr[CBW1], bb[CBW1];
-#pragma unroll
-    for (int u = 0; u < CBW1; ++u) {
-        const int cog = sl * CO + (wave * CBW1 + u) * 16 + quad * 4;
-        rr[u] = mok ? *(const f32x4 *)(p.res + (long)m * COT + cog) : f32x4{0.f, 0.f, 0.f, 0.f};
-        bb[u] = *(const f32x4 *)(p.b3 + cog);
-    }
-    __syncthreads();
-
-    // ---- GEMM1: K = CM from the pixel tile; this wave's CBW1 column blocks of the slice
+    // ---- GEMM1: K = CM from the pixel tile; this wave's CBW1 column blocks of the slice (residual and bias fly under it)
     {
+        f32x4 rr[CBW1], bb[CBW1];
+#pragma unroll
+        for (int u = 0; u < CBW1; ++u) {
+            const int cog = sl * CO + (wave * CBW1 + u) * 16 + quad * 4;
+            rr[u] = mok ? *(const f32x4 *)(p.res + (long)m * COT + cog) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bb[u] = *(const f32x4 *)(p.b3 + cog);
+        }
         f32x4 acc[CBW1];
         gemm_blocks<CBW1, R1, R1>((const f32x4 *)p.w3p + lane + (long)sl * NB1 * R1 * 64, Xs + l15 * XP + quad * 4, wave * CBW1, 0, acc);
 #pragma unroll
@@ -191,9 +177,123 @@ __global__ __launch_bounds__(512) void pw_pair_f32_kernel(const PwF p)
     }
 }
 
+template <int CN, int KSG> constexpr int ps_floats() { return KSG > 1 ? (KSG - 1) * 16 * (CN + 4) : 16; }
+
+template <int CM, int COT, int CN, int S = 1>
+__global__ __launch_bounds__(512) void pw_pair_f32_kernel(const PwF p)
+{
+    constexpr int NW = 8, BM = 16, XP = CM + 4, NB2 = CN / 16, KS = NB2 >= NW ? 1 : NW / NB2;
+    __shared__ __attribute__((aligned(16))) float Xs[BM * XP];
+    __shared__ __attribute__((aligned(16))) float Ys[BM * (COT / S + 4)];
+    __shared__ __attribute__((aligned(16))) float Ps[ps_floats<CN, KS>()];
+    const int tid = threadIdx.x;
+    const int pt = S > 1 ? (int)blockIdx.x / S : (int)blockIdx.x, sl = S > 1 ? (int)blockIdx.x % S : 0;
+    const int bm0 = pt * BM;
+    // pixel tile -> LDS (rows past M are zero)
+    for (int i = tid; i < BM * (CM / 4); i += NW * 64) {
+        const int row = i / (CM / 4), c4 = i - row * (CM / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (bm0 + row < p.M) v = *(const f32x4 *)(p.t2 + (long)(bm0 + row) * CM + c4 * 4);
+        *(f32x4 *)(Xs + row * XP + c4 * 4) = v;
+    }
+    __syncthreads();
+    pair_tail<CM, COT, CN, S>(p, Xs, Ys, Ps, pt, sl);
+}
+
+// ---- a whole bottleneck tail in one launch (layer1 at batch 1): conv2 (3x3 / stride 1, CIN -> CM) + BN + ReLU, then the
+// pair above.  The 16 x 9 CIN im2col image of the pixel tile is built in LDS (zeros for padding taps), conv2's CM / 16
+// column blocks run on the eight waves with the k range split over wave groups (meeting in LDS), its output tile stays in
+// LDS as the pair's input.  Three launches of the frame become one.
+struct PwT {
+    PwF pair;                                             // t2 unused
+    const float *x, *w2p, *b2;
+    int H, W, OH, OW, pad_h, pad_w, dil_h, dil_w;
+};
+
+template <int CIN, int CM, int COT, int CN>
+__global__ __launch_bounds__(512) void pw_triple_f32_kernel(const PwT q)
+{
+    constexpr int NW = 8, BM = 16, TAPS = 9, K0 = TAPS * CIN, RT0 = K0 / 16, NB0 = CM / 16;
+    constexpr int KS0 = NW / NB0, RS0 = RT0 / KS0;
+    static_assert(NB0 <= NW && NW % NB0 == 0 && RT0 % KS0 == 0, "conv2: one column block per wave group");
+    constexpr int XP0 = K0 + 4, XP = CM + 4, NB2 = CN / 16, KS2 = NB2 >= NW ? 1 : NW / NB2;
+    constexpr int PSF = ps_floats<CM, KS0>() > ps_floats<CN, KS2>() ? ps_floats<CM, KS0>() : ps_floats<CN, KS2>();
+    extern __shared__ __attribute__((aligned(16))) float ldst[];
+    float *X0 = ldst;                                     // [BM][XP0] im2col image
+    float *Xs = X0 + BM * XP0;                            // [BM][XP]  conv2 output tile
+    float *Ys = Xs + BM * XP;                             // [BM][COT + 4]
+    float *Ps = Ys + BM * (COT + 4);                      // wave-group partials
+    __shared__ int pix[BM][3];
+    const PwF &p = q.pair;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int pt = blockIdx.x, bm0 = pt * BM;
+    const int cb = wave % NB0, ksl = wave / NB0;
+    const f32x4 *wf = (const f32x4 *)q.w2p + lane;
+    GemmRing<1, RS0, RT0, 8> g;
+    g.prefetch(wf, cb, ksl * RS0);
+    if (tid < BM) {
+        const int mm = bm0 + tid;
+        if (mm < p.M) {
+            const int P = q.OH * q.OW, n = mm / P, r = mm - n * P, oh = r / q.OW;
+            pix[tid][0] = n * q.H;
+            pix[tid][1] = oh - q.pad_h;
+            pix[tid][2] = (r - oh * q.OW) - q.pad_w;
+        } else {
+            pix[tid][0] = -1;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < BM * TAPS * (CIN / 4); i += NW * 64) {
+        const int c4 = i % (CIN / 4), t = (i / (CIN / 4)) % TAPS, row = i / (TAPS * (CIN / 4));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pix[row][0] >= 0) {
+            const int ih = pix[row][1] + (t / 3) * q.dil_h, iw = pix[row][2] + (t % 3) * q.dil_w;
+            if ((unsigned)ih < (unsigned)q.H && (unsigned)iw < (unsigned)q.W)
+                v = *(const f32x4 *)(q.x + ((long)(pix[row][0] + ih) * q.W + iw) * CIN + c4 * 4);
+        }
+        *(f32x4 *)(X0 + row * XP0 + t * CIN + c4 * 4) = v;
+    }
+    const f32x4 b2 = *(const f32x4 *)(q.b2 + cb * 16 + quad * 4);
+    __syncthreads();
+    f32x4 acc[1];
+    g.run(wf, X0 + l15 * XP0 + quad * 4, cb, ksl * RS0, acc);
+    if constexpr (KS0 > 1) {
+        if (ksl > 0) *(f32x4 *)(Ps + ((ksl - 1) * BM + l15) * (CM + 4) + cb * 16 + quad * 4) = acc[0];
+        __syncthreads();
+        if (ksl == 0) {
+#pragma unroll
+            for (int s2 = 1; s2 < KS0; ++s2) acc[0] += *(const f32x4 *)(Ps + ((s2 - 1) * BM + l15) * (CM + 4) + cb * 16 + quad * 4);
+        }
+    }
+    if (ksl == 0) {
+        f32x4 v = acc[0] + b2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        *(f32x4 *)(Xs + l15 * XP + cb * 16 + quad * 4) = v;           // rows past M hold relu(b2): never stored
+    }
+    __syncthreads();                                      // conv2's tile complete (and Ps free again)
+    pair_tail<CM, COT, CN, 1>(p, Xs, Ys, Ps, pt, 0);
+}
+
 template <int CM, int CO, int CN, int S = 1> int launch(hipStream_t s, const PwF &p)
 {
     hipLaunchKernelGGL((pw_pair_f32_kernel<CM, CO, CN, S>), dim3(((p.M + 15) / 16) * S), dim3(512), 0, s, p);
+    return hipGetLastError() == hipSuccess ? USOT_OK : USOT_ELAUNCH;
+}
+
+template <int CIN, int CM, int CO, int CN> int launch_triple(hipStream_t s, const PwT &q)
+{
+    constexpr int NB2 = CN / 16, KS2 = NB2 >= 8 ? 1 : 8 / NB2, KS0 = 8 / (CM / 16);
+    constexpr int PSF = ps_floats<CM, KS0>() > ps_floats<CN, KS2>() ? ps_floats<CM, KS0>() : ps_floats<CN, KS2>();
+    const size_t lds = (size_t)(16 * (9 * CIN + 4) + 16 * (CM + 4) + 16 * (CO + 4) + PSF) * sizeof(float);
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        if (hipFuncSetAttribute((const void *)pw_triple_f32_kernel<CIN, CM, CO, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return USOT_ELAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((pw_triple_f32_kernel<CIN, CM, CO, CN>), dim3((q.pair.M + 15) / 16), dim3(512), lds, s, q);
     return hipGetLastError() == hipSuccess ? USOT_OK : USOT_ELAUNCH;
 }
 
@@ -457,4 +557,33 @@ extern "C" int usot_stream_conv3x3_f32(void *stream, const float *x, const float
     if (Cin == 256 && N == 256) return launch3<256, 256, 4>(s, p);
     if (Cin == 128 && N == 128) return launch3<128, 128, 4>(s, p);
     return USOT_EINVAL;
+}
+
+/* conv2 (3x3 / stride 1) + BN + ReLU, conv3 + BN + residual + ReLU and the next block's conv1 + BN + act2 in ONE launch
+ * (layer1 of the fp32 frame): x NHWC [Nb][H][W][Cin]; w2p the packed conv2 bank [CM][9 Cin] in fragment order; the rest as
+ * usot_pw_pair_f32 (d->t2 is ignored, d->M = Nb * OH * OW).  Shapes (Cin, CM, CO, CN): (64, 64, 256, 64 | 128), (128, 128, 512, 128). */
+extern "C" int usot_pw_triple_f32_supported(int Cin, int CM, int CO, int CN)
+{
+    return (Cin == 64 && CM == 64 && CO == 256 && (CN == 64 || CN == 128)) || (Cin == 128 && CM == 128 && CO == 512 && CN == 128);
+}
+
+extern "C" int usot_pw_triple_f32(void *stream, const float *x, const float *w2p, const float *b2, const usot_pw_pair_desc *d,
+                                  int Nb, int H, int W, int Cin, int OH, int OW, int pad_h, int pad_w, int dil_h, int dil_w)
+{
+    if (!x || !w2p || !b2 || !d || !d->w3p || !d->b3 || !d->res || !d->w1 || !d->b1 || !d->y || !d->t) return USOT_EINVAL;
+    if (!usot_pw_triple_f32_supported(Cin, d->CM, d->CO, d->CN) || d->M != Nb * OH * OW || d->M <= 0) return USOT_EINVAL;
+    if (OH != H + 2 * pad_h - 2 * dil_h || OW != W + 2 * pad_w - 2 * dil_w) return USOT_EINVAL;
+    if (d->act2 != USOT_ACT_NONE && d->act2 != USOT_ACT_RELU) return USOT_EINVAL;
+    const uintptr_t al = (uintptr_t)x | (uintptr_t)w2p | (uintptr_t)b2 | (uintptr_t)d->w3p | (uintptr_t)d->b3 | (uintptr_t)d->res |
+                         (uintptr_t)d->w1 | (uintptr_t)d->b1 | (uintptr_t)d->y | (uintptr_t)d->t;
+    if (al & 15) return USOT_EINVAL;
+    PwT q;
+    q.pair = PwF{nullptr, (const float *)d->w3p, d->b3, (const float *)d->res, (const float *)d->w1, d->b1, (float *)d->y,
+                 (float *)d->t, nullptr, d->M, d->act2};
+    q.x = x; q.w2p = w2p; q.b2 = b2;
+    q.H = H; q.W = W; q.OH = OH; q.OW = OW; q.pad_h = pad_h; q.pad_w = pad_w; q.dil_h = dil_h; q.dil_w = dil_w;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cin == 128) return launch_triple<128, 128, 512, 128>(s, q);
+    if (d->CN == 64) return launch_triple<64, 64, 256, 64>(s, q);
+    return launch_triple<64, 64, 256, 128>(s, q);
 }

@@ -355,24 +355,17 @@ class Builder:
             if t1_fused is not None:
                 t1, t1_fused = t1_fused, None
                 if ds is not None:
-                    sc, hs, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
-                t2, h2, _ = self.conv3x3('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
-                assert ds is None or hs == h2
+                    sc, _, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
             elif ds is not None and self.lanes < 3:   # shortcut conv shares conv1's launch
-                (sc, hs, _), (t1, _, _) = self.conv_batch([('b%d.ds' % bi, ds, cur, n, h, h, {}),
-                                                           ('b%d.conv1' % bi, c1, cur, n, h, h, dict(act=ACT_RELU))])
-                t2, h2, _ = self.conv3x3('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
-                assert hs == h2
+                (sc, _, _), (t1, _, _) = self.conv_batch([('b%d.ds' % bi, ds, cur, n, h, h, {}),
+                                                          ('b%d.conv1' % bi, c1, cur, n, h, h, dict(act=ACT_RELU))])
             else:
                 if ds is not None:                # shortcut conv on its own lane beside conv1 -> conv2
                     self.fork(1)
-                    sc, hs, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
+                    sc, _, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
                     self.fork(0)
                 t1, _, _ = self.conv1x1('b%d.conv1' % bi, c1, cur, n, h, act=ACT_RELU)
-                t2, h2, _ = self.conv3x3('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
-                if ds is not None:
-                    assert hs == h2
-                    self.join(1)
+            h2 = c2.out_hw(h, h)[0]
             last = bi + 1 == len(W.blocks)
             nxt = W.neck if last else W.blocks[bi + 1][0]
             shape = (c3.cin, c3.cout, nxt.cout)
@@ -381,11 +374,20 @@ class Builder:
                 (shape in FUSED_POINTWISE_F32 and m2 <= FUSED_POINTWISE_F32_MAX_M) or
                 (FUSED_POINTWISE_F32_SLICED and shape in FUSED_POINTWISE_F32_SLICED_ONLY
                  and hip.lib().usot_pw_pair_f32_ws_floats(m2, *shape) > 0))
-            if fuse:
-                cur, t1_fused = self.pw_pair_f32('b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1)), c3, nxt, t2, sc,
-                                                 n, h2, act2=ACT_NONE if last else ACT_RELU)
+            nm = 'b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1))
+            act2 = ACT_NONE if last else ACT_RELU
+            if (fuse and FUSED_TRIPLE_F32 and c2.kh == 3 and c2.stride == 1 and m2 <= FUSED_POINTWISE_F32_MAX_M
+                    and (c2.cin, c3.cin, c3.cout, nxt.cout) in FUSED_TRIPLE_F32_SHAPES
+                    and hip.lib().usot_pw_triple_f32_supported(c2.cin, c3.cin, c3.cout, nxt.cout)):
+                cur, t1_fused = self.pw_triple_f32('b%d.conv2+' % bi + nm, c2, c3, nxt, t1, sc, n, h, act2=act2)
             else:
-                cur, _, _ = self.conv1x1('b%d.conv3' % bi, c3, t2, n, h2, act=ACT_RELU, res=sc)
+                t2, _, _ = self.conv3x3('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
+                if ds is not None and self.lanes >= 3:
+                    self.join(1)
+                if fuse:
+                    cur, t1_fused = self.pw_pair_f32(nm, c3, nxt, t2, sc, n, h2, act2=act2)
+                else:
+                    cur, _, _ = self.conv1x1('b%d.conv3' % bi, c3, t2, n, h2, act=ACT_RELU, res=sc)
             h = h2
             if bi in (2, 6, 12):                      # ends of layer1 / layer2 / layer3
                 stages.append(cur)
@@ -498,6 +500,23 @@ class Builder:
                 and (pc.cin, pc.cout) in STREAM_1X1_SHAPES and hip.lib().usot_pw_single_f32_supported(pc.cin, pc.cout)):
             return self.pw_single(name, pc, x, n, h, act=act, res=res)
         return self.conv(name, pc, x, n, h, h, act=act, res=res)
+
+    def pw_triple_f32(self, name, c2, c3, nxt, t1, res, n, h, act2=ACT_RELU):
+        """fp32: conv2 (3x3 / stride 1) + conv3 + residual + ReLU + the next block's conv1 in ONE launch (pw_triple_f32_kernel).
+        Returns (y [n,oh,oh,c3.cout], t [n,oh,oh,nxt.cout])."""
+        oh, ow = c2.out_hw(h, h)
+        m = n * oh * ow
+        y = self.buf(n, oh, ow, c3.cout)
+        t = self.buf(n, oh, ow, nxt.cout)
+        w2p, w3p, w1p = c2.w_pw_pair_f32(), c3.w_pw_pair_f32(), nxt.w_pw_pair_f32()
+        d = hip.pw_pair_desc(None, w3p.data_ptr(), c3.b.data_ptr(), res.data_ptr(), y.data_ptr(), w1p.data_ptr(),
+                             nxt.b.data_ptr(), t.data_ptr(), m, c3.cin, c3.cout, nxt.cout, act2)
+        hip.check(hip.lib().usot_plan_add_pw_triple(self.plan.h, hip.ptr(t1), hip.ptr(w2p), hip.ptr(c2.b), C.byref(d),
+                                                    n, h, h, c2.cin, oh, ow, c2.pad[0], c2.pad[1], c2.dil[0], c2.dil[1]),
+                  'plan_add_pw_triple ' + name)
+        self.plan.keep += [t1, res, w2p, w3p, w1p, c2.b, c3.b, nxt.b]
+        self.log.append((name, m, c3.cout, c3.cin, 1, m * (c2.cout * 9 * c2.cin + c3.cout * c3.cin + nxt.cout * c3.cout)))
+        return y, t
 
     def cvt_lp(self, src, dtype):
         dst = self.buf(*src.shape, dtype=dtype)
@@ -710,6 +729,11 @@ FUSED_POINTWISE = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
 # already rides in the shortcut conv's launch.  Above MAX_M pixels the tiled conv kernels fill the chip and win.
 FUSED_POINTWISE_F32 = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
 FUSED_POINTWISE_F32_MAX_M = 4 * 3969
+# layer1: conv2 (3x3) joins the pair's launch (pw_triple_f32_kernel): 16.0 -> 10.9 us per bottleneck isolated, graph
+# replay 873.7 -> 863.2 us.  layer2's form (128 x 128 x 512 x 128; 61 workgroups) makes the frame slower (861 -> 881 us).
+FUSED_TRIPLE_F32 = os.environ.get('USOT_FUSED_TRIPLE_F32', '1') == '1'
+FUSED_TRIPLE_F32_SHAPES = {tuple(int(v) for v in t.split('x')) for t in
+                           os.environ.get('USOT_FUSED_TRIPLE_F32_SHAPES', '64x64x256x64,64x64x256x128').split(',')}
 # the unfused 1x1 EXPANSION convolutions (conv3 of layer3's blocks and of layer2's last) on the small-M streaming kernel
 # up to this many pixels: graph replay 896.6 -> 878 us.  The 1024 -> 256 reductions gain nothing there (898 us with them
 # alone, 877-881 with everything): (Cin, Cout) pairs, overridable for experiments.

@@ -29,7 +29,7 @@ EXPORTS = (
     'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
     'PrRoIPoolingForwardGpu', 'usot_groupdw_auto_variant',
-    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single', 'usot_stream_conv3x3_f32', 'usot_stream_conv3x3_f32_supported', 'usot_plan_add_stream_conv3x3',
+    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single', 'usot_stream_conv3x3_f32', 'usot_stream_conv3x3_f32_supported', 'usot_plan_add_stream_conv3x3', 'usot_pw_triple_f32', 'usot_pw_triple_f32_supported', 'usot_plan_add_pw_triple',
 )
 
 
@@ -124,6 +124,9 @@ def lib():
         L.usot_stream_conv3x3_f32.argtypes = [C.c_void_p] * 6 + [C.c_int] * 12
         L.usot_plan_add_stream_conv3x3.argtypes = [C.c_void_p] * 6 + [C.c_int] * 12
         L.usot_stream_conv3x3_f32_supported.argtypes = [C.c_int] * 2
+        L.usot_pw_triple_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 10
+        L.usot_plan_add_pw_triple.argtypes = [C.c_void_p] * 5 + [C.c_int] * 10
+        L.usot_pw_triple_f32_supported.argtypes = [C.c_int] * 4
         L.usot_plan_add_cvt_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.usot_plan_add_maxpool_lp.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] * 7
         L.usot_conv2d_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -523,6 +526,24 @@ def stream_conv3x3_f32(x, w, b, pad, dil, res=None, act=ACT_NONE):
     check(lib().usot_stream_conv3x3_f32(stream(), ptr(x), ptr(wp), ptr(b), ptr(res) if res is not None else None, ptr(y),
                                         Nb, H, W_, Cin, OH, OW, N, pad[0], pad[1], dil[0], dil[1], act), 'usot_stream_conv3x3_f32')
     return y
+
+
+def pw_triple_f32(x, w2, b2, w3, b3, res, w1, b1, pad=(1, 1), dil=(1, 1), act2=ACT_RELU):
+    """fp32 NHWC: T2 = relu(conv3x3(x, w2) + b2); Y = relu(T2 . w3^T + b3 + res); T = act2(Y . w1^T + b1) in one launch.
+    w2 packed [CM, 9*Cin] ((kh, kw, ci) order), w3 [CO, CM], w1 [CN, CO].  Returns (Y, T) as [Nb, OH, OW, C]."""
+    for t in (x, w2, b2, w3, b3, res, w1, b1):
+        _dev(t)
+    Nb, H, W_, Cin = x.shape
+    CM, CO, CN = w2.shape[0], w3.shape[0], w1.shape[0]
+    OH, OW = H + 2 * pad[0] - 2 * dil[0], W_ + 2 * pad[1] - 2 * dil[1]
+    y = torch.empty((Nb, OH, OW, CO), device=x.device, dtype=torch.float32)
+    t = torch.empty((Nb, OH, OW, CN), device=x.device, dtype=torch.float32)
+    w2p, w3p, w1p = pw_pair_f32_pack(w2), pw_pair_f32_pack(w3), pw_pair_f32_pack(w1)
+    d = pw_pair_desc(None, w3p.data_ptr(), b3.data_ptr(), res.data_ptr(), y.data_ptr(), w1p.data_ptr(), b1.data_ptr(), t.data_ptr(),
+                     Nb * OH * OW, CM, CO, CN, act2)
+    check(lib().usot_pw_triple_f32(stream(), ptr(x), ptr(w2p), ptr(b2), C.byref(d), Nb, H, W_, Cin, OH, OW, pad[0], pad[1], dil[0], dil[1]),
+          'usot_pw_triple_f32')
+    return y, t
 
 
 def pw_pair_supported(cm, co, cn):
