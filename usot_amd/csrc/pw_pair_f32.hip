@@ -27,6 +27,10 @@
 #include "usot_hip.h"
 #include "common.h"
 
+#ifndef USOT_RING          // filter fragments (1 KiB per wave each) a wave keeps in flight
+#define USOT_RING 8
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -74,7 +78,7 @@ struct GemmRing {
 template <int CBW, int RS, int RT>
 __device__ __forceinline__ void gemm_blocks(const f32x4 *__restrict__ wf, const float *bs, int cb0, int r0, f32x4 (&acc)[CBW])
 {
-    GemmRing<CBW, RS, RT, (CBW * RS < 8 ? CBW * RS : 8)> g;
+    GemmRing<CBW, RS, RT, (CBW * RS < USOT_RING ? CBW * RS : USOT_RING)> g;
     g.prefetch(wf, cb0, r0);
     g.run(wf, bs, cb0, r0, acc);
 }
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(512) void pw_triple_f32_kernel(const PwT q)
     const int pt = blockIdx.x, bm0 = pt * BM;
     const int cb = wave % NB0, ksl = wave / NB0;
     const f32x4 *wf = (const f32x4 *)q.w2p + lane;
-    GemmRing<1, RS0, RT0, 8> g;
+    GemmRing<1, RS0, RT0, (RS0 < USOT_RING ? RS0 : USOT_RING)> g;
     g.prefetch(wf, cb, ksl * RS0);
     if (tid < BM) {
         const int mm = bm0 + tid;
@@ -316,7 +320,7 @@ struct Pw1 {
     int M, act;
 };
 
-template <int K, int N, int S, int PFD = 8>
+template <int K, int N, int S, int PFD = USOT_RING>
 __global__ __launch_bounds__(512) void pw_single_f32_kernel(const Pw1 p)
 {
     constexpr int NW = 8, BM = 16;
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(512) void stream_conv3x3_f32_kernel(const PwC p)
     const int ksl = KS > 1 ? wave / NB : 0;
     const int cb0 = KS > 1 ? wave % NB : wave * CBW;
     const f32x4 *wf = (const f32x4 *)p.wp + lane + (long)sl * NB * RT * 64;
-    GemmRing<CBW, RS, RT, 8> g;
+    GemmRing<CBW, RS, RT, (CBW * RS < USOT_RING ? CBW * RS : USOT_RING)> g;
     g.prefetch(wf, cb0, ksl * RS);
     if (tid < BM) {
         const int mm = bm0 + tid;
