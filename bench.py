@@ -120,7 +120,7 @@ def roofline(sess, frames):
         name, M, N, K, g, macs = next(convs)
         conv_ms += ms
         conv_flops += 2.0 * macs
-        if kind in (K_PWPAIR, K_PW1, K_SC3, K_PW3):   # csrc/pw_pair_f32.hip kernels: counted in all_convs,
+        if kind in (K_PWPAIR, K_PW1, K_SC3, K_PW3):   # csrc/smallm_f32.hip kernels: counted in all_convs,
             continue                              # not a tile instance of the conv_igemm family
         a = agg.setdefault(tile, [0, 0.0, 0.0])
         a[0] += 1

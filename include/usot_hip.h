@@ -127,7 +127,7 @@ int usot_pw_pair_layout(int CM, int CO, int CN, int which, int32_t *row, int32_t
 int usot_pw_pair_supported(int CM, int CO, int CN);
 int usot_plan_add_pw_pair(void *plan, const usot_pw_pair_desc *d, int dtype);   /* dtype 2: the fp32 form below */
 
-/* the same pair in fp32 for the batch-1 frame (csrc/pw_pair_f32.hip; v_mfma_f32_16x16x4_f32, 16 pixels per workgroup):
+/* the same pair in fp32 for the batch-1 frame (csrc/smallm_f32.hip; v_mfma_f32_16x16x4_f32, 16 pixels per workgroup):
  * every pointer of the descriptor is float32.  w3p / w1 in fragment order: the float at
  * [((cb * (K / 16) + r) * 64 + lane) * 4 + c] is W[cb * 16 + (lane & 15)][16 * r + 4 * (lane >> 4) + c]
  * (W = the [rows][K] filter bank: K = CM for w3p, CO for w1).  Shapes: usot_pw_pair_f32_supported.

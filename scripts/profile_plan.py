@@ -34,7 +34,7 @@ by_tile = {}
 print('%-16s %7s %5s %6s %3s %9s %9s %8s' % ('op', 'M', 'N', 'K', 'g', 'tile', 'us', 'TFLOP/s'))
 for kind, tile, ks, groups, ms in prof:
     tot += ms
-    if kind in (18, 19, 20, 21):                                          # fused pointwise pair (csrc/pw_pair_f32.hip)
+    if kind in (18, 19, 20, 21):                                          # fused pointwise pair (csrc/smallm_f32.hip)
         name, M, N, K, g, macs = next(convs)
         tot_conv += ms; flops += 2 * macs
         print('%-16s %7d %5s %6s %3s %9s %9.1f %8.1f' % (name[:16], M, '', '', '', 'fused', ms * 1e3, 2 * macs / (ms * 1e-3) / 1e12))

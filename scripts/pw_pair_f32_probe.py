@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fused fp32 pointwise pair (csrc/pw_pair_f32.hip) against the two conv launches it replaces, timed back to back and
+"""Fused fp32 pointwise pair (csrc/smallm_f32.hip) against the two conv launches it replaces, timed back to back and
 as graph-captured chains of the pair (the frame's regime: every launch depends on the previous one)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -246,7 +246,7 @@ def test_prroi_pool_vs_independent_float64_oracle(layout):
 @pytest.mark.parametrize('cm,co,cn,M', [(64, 256, 64, 3969), (64, 256, 128, 3969), (128, 512, 128, 961), (128, 512, 256, 961),
                                         (64, 256, 64, 7), (128, 512, 128, 2 * 961), (256, 1024, 256, 961), (256, 1024, 256, 1089)])
 def test_pw_pair_f32_equals_the_two_convolutions(cm, co, cn, M):
-    """csrc/pw_pair_f32.hip: conv3 + residual + ReLU and the next block's conv1 + ReLU in one launch (fp32, batch-1
+    """csrc/smallm_f32.hip: conv3 + residual + ReLU and the next block's conv1 + ReLU in one launch (fp32, batch-1
     frame) against the two conv launches it replaces and against torch in float64."""
     g = torch.Generator().manual_seed(cm + cn + M)
     t2 = torch.randn(M, cm, generator=g)
@@ -278,7 +278,7 @@ def test_pw_pair_f32_equals_the_two_convolutions(cm, co, cn, M):
 @pytest.mark.parametrize('K,N,M,res', [(256, 1024, 961, True), (128, 512, 961, True), (1024, 256, 961, False), (512, 128, 1089, False),
                                        (256, 1024, 5, True)])
 def test_pw_single_f32_streaming_conv(K, N, M, res):
-    """csrc/pw_pair_f32.hip: pw_single_f32_kernel (small-M 1x1 conv, filters streamed in fragment order) against float64
+    """csrc/smallm_f32.hip: pw_single_f32_kernel (small-M 1x1 conv, filters streamed in fragment order) against float64
     and against the tiled conv kernel it replaces for layer3's expansion convs at batch 1."""
     g = torch.Generator().manual_seed(K + N + M)
     x = torch.randn(1, 1, M, K, generator=g)
@@ -298,7 +298,7 @@ def test_pw_single_f32_streaming_conv(K, N, M, res):
 @pytest.mark.parametrize('cin,n,nb,h,w,pad,dil', [(128, 128, 1, 31, 31, 1, 1), (256, 256, 1, 31, 31, 2, 2), (256, 256, 1, 15, 15, 1, 1),
                                                   (128, 128, 2, 9, 11, 2, 2), (128, 128, 1, 7, 5, 0, 1)])
 def test_stream_conv3x3_f32(cin, n, nb, h, w, pad, dil):
-    """csrc/pw_pair_f32.hip: stream_conv3x3_f32_kernel (3x3 / stride 1 at small M: im2col pixel tile in LDS, filters streamed
+    """csrc/smallm_f32.hip: stream_conv3x3_f32_kernel (3x3 / stride 1 at small M: im2col pixel tile in LDS, filters streamed
     in fragment order) against torch in float64 and against the tiled kernel."""
     g = torch.Generator().manual_seed(cin + h * w + pad)
     x = torch.randn(nb, cin, h, w, generator=g)
@@ -315,7 +315,7 @@ def test_stream_conv3x3_f32(cin, n, nb, h, w, pad, dil):
 @pytest.mark.parametrize('cin,cn,nb,h,w', [(64, 64, 1, 63, 63), (64, 128, 1, 63, 63), (64, 64, 2, 9, 7), (64, 128, 1, 67, 67),
                                             (128, 128, 1, 31, 31), (128, 128, 2, 6, 5)])
 def test_pw_triple_f32_equals_three_convolutions(cin, cn, nb, h, w):
-    """csrc/pw_pair_f32.hip: pw_triple_f32_kernel — layer1's conv2 (3x3) + conv3 + residual + ReLU + next conv1 in one launch —
+    """csrc/smallm_f32.hip: pw_triple_f32_kernel — layer1's conv2 (3x3) + conv3 + residual + ReLU + next conv1 in one launch —
     against float64 and against the three launches it replaces."""
     cm, co = cin, 4 * cin
     g = torch.Generator().manual_seed(cn + h)

@@ -1,3 +1,15 @@
+// Small-M fp32 kernels of the batch-1 frame.  At batch 1 a backbone layer has M = 3969 or 961 pixels and 0.1-0.5 GFLOP:
+// on the tiled implicit-GEMM kernels (conv_igemm.hip) such a layer is a launch, one cold round trip for the map the
+// previous kernel wrote, a handful of k-steps and a boundary - 9-14 us for ~1 us of matrix work.  The kernels here share
+// one form instead: a workgroup owns 16 PIXELS (the MFMA's B operand, kept whole-K in LDS), the filters are pre-packed
+// in MFMA-fragment order and streamed from L2 straight into registers (no LDS staging of filters, no k-tile barriers),
+// and consecutive layers that share their pixel tile run in ONE launch with the intermediate map in LDS.
+//   pw_pair_f32_kernel        conv3 + residual + ReLU  ->  next conv1                      (layer2; optional channel slices)
+//   pw_triple_f32_kernel      conv2 (3x3)  ->  conv3 + residual + ReLU  ->  next conv1     (layer1)
+//   pw_single_f32_kernel      one 1x1 conv (+ residual)                                    (layer3's expansion convs)
+//   stream_conv3x3_f32_kernel one 3x3 / stride-1 conv                                      (layer2's conv2)
+// DESIGN.md section 3.1 has the measurements (and the shapes where the tiled kernels stay faster).
+//
 // Fused pair of pointwise convolutions for the fp32 batch-1 frame: a bottleneck's conv3 + BN + residual + ReLU
 // (modules.py:48-56) and the NEXT block's conv1 + BN + ReLU (modules.py:40-42; or the neck's 1x1, connect.py:294-300)
 // in one launch.

@@ -443,7 +443,7 @@ class Builder:
         return y, t
 
     def pw_pair_f32(self, name, c3, nxt, t2, res, n, h, act2=ACT_RELU):
-        """fp32: conv3 + residual + ReLU and the next block's conv1 in ONE launch (csrc/pw_pair_f32.hip).
+        """fp32: conv3 + residual + ReLU and the next block's conv1 in ONE launch (csrc/smallm_f32.hip).
         Returns (y [n,h,h,c3.cout], t [n,h,h,nxt.cout])."""
         m = n * h * h
         y = self.buf(n, h, h, c3.cout)
@@ -462,7 +462,7 @@ class Builder:
         return y, t
 
     def pw_single(self, name, pc, x, n, h, act=ACT_NONE, res=None):
-        """fp32 1x1 convolution on the small-M streaming kernel (csrc/pw_pair_f32.hip: pw_single_f32_kernel)."""
+        """fp32 1x1 convolution on the small-M streaming kernel (csrc/smallm_f32.hip: pw_single_f32_kernel)."""
         m = n * h * h
         y = self.buf(n, h, h, pc.cout)
         wp = pc.w_pw_pair_f32()
@@ -724,7 +724,7 @@ LP_TUNING = load_lp_tuning()
 # (C_mid, C_out, C_next) of the conv3 -> next-conv1 pairs that run as ONE launch (csrc/pw_pair.hip) in the batched
 # low-precision backbone: the shapes where the fused kernel measured faster than the two launches at batch 64
 FUSED_POINTWISE = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
-# the same fusion in the fp32 frame (csrc/pw_pair_f32.hip, 16 pixels per workgroup): at batch 1 these 1x1 layers are
+# the same fusion in the fp32 frame (csrc/smallm_f32.hip, 16 pixels per workgroup): at batch 1 these 1x1 layers are
 # launch-bound (two launches 20-23 us, fused 6-14: scripts/pw_pair_f32_probe.py).  Not (128, 512, 256): layer3.0's conv1
 # already rides in the shortcut conv's launch.  Above MAX_M pixels the tiled conv kernels fill the chip and win.
 FUSED_POINTWISE_F32 = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
