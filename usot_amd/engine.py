@@ -732,6 +732,7 @@ FUSED_POINTWISE_F32_MAX_M = 4 * 3969
 # layer1: conv2 (3x3) joins the pair's launch (pw_triple_f32_kernel): 16.0 -> 10.9 us per bottleneck isolated, graph
 # replay 873.7 -> 863.2 us.  layer2's form (128 x 128 x 512 x 128; 61 workgroups) makes the frame slower (861 -> 881 us).
 FUSED_TRIPLE_F32 = os.environ.get('USOT_FUSED_TRIPLE_F32', '1') == '1'
+SPIN_SECONDS = float(os.environ.get('USOT_SPIN_SECONDS', '0.004'))
 FUSED_TRIPLE_F32_SHAPES = {tuple(int(v) for v in t.split('x')) for t in
                            os.environ.get('USOT_FUSED_TRIPLE_F32_SHAPES', '64x64x256x64,64x64x256x128').split(',')}
 # the unfused 1x1 EXPANSION convolutions (conv3 of layer3's blocks and of layer2's last) on the small-M streaming kernel
@@ -1120,10 +1121,19 @@ class Session:
         rather than sleeping in hipStreamSynchronize (the PrRoIPool + bank append behind it are
         ordered before the next frame by the stream)."""
         out, tag = self._out_np, self._tag
-        for _ in range(20000):                  # a frame is ~1 ms: spin first ...
-            if out[8] == tag:
-                break
-        else:                                   # ... then give the core away between polls
+        # spin for SPIN_SECONDS (several frame times), then give the core away between polls.  The budget is wall-clock: a
+        # fixed 20 000 polls turned out to be 0.905 ms on this host (45 ns per numpy compare), i.e. it ran out right around
+        # the end of a 0.86 ms frame and every such frame then paid a 50 us sleep and a launch onto an idle queue
+        spin_until = time.perf_counter() + SPIN_SECONDS
+        while True:
+            for _ in range(512):
+                if out[8] == tag:
+                    break
+            else:
+                if time.perf_counter() < spin_until:
+                    continue
+            break
+        if out[8] != tag:
             deadline = time.monotonic() + 20.0
             while out[8] != tag and time.monotonic() < deadline:
                 time.sleep(5e-5)
