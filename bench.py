@@ -88,7 +88,7 @@ class Confidences:
 def run_frames(sess, crops, p, conf, n):
     for i in range(n):
         picks = select_memory(conf.view(), p.mem_queue_size)
-        out = sess.frame(crops[i % crops.shape[0]], picks, (63.5, 63.5))
+        out = sess.frame(crops[i % crops.shape[0]], picks, (63.5, 63.5), inplace=True)     # resident crops, read where they lie
         conf.append(float(out[1]))
 
 
@@ -99,7 +99,7 @@ def run_frames_multi(group, n):
     for i in range(n):
         for sess, crops, p, conf, st in group:
             with torch.cuda.stream(st):
-                sess.submit(crops[i % crops.shape[0]], select_memory(conf.view(), p.mem_queue_size), (63.5, 63.5))
+                sess.submit(crops[i % crops.shape[0]], select_memory(conf.view(), p.mem_queue_size), (63.5, 63.5), inplace=True)
         for sess, crops, p, conf, st in group:
             conf.append(float(sess.collect()[1]))
 

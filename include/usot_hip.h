@@ -171,6 +171,11 @@ int usot_plan_add_pw_single(void *plan, const float *x, const float *wp, const f
  * w packed [147][64] with row = (ci*7 + kh)*7 + kw, y NHWC [N][OH][OW][64].            */
 int usot_stem_conv_f32(void *stream, const float *x, const float *w, const float *bias,
                        float *y, int N, int H, int W, int OH, int OW);
+/* the same on x - mu[ci] (exact for this pad-0 conv; `bias` must then carry + sum_k w[k][co] * mu[ci(k)], folded in
+ * float64 by the caller): raw crops sit around ~100, and the 147-tap float32 chain of every output otherwise rides on
+ * 100 * sum(w).  mu = 0 is usot_stem_conv_f32. */
+int usot_stem_conv_mu_f32(void *stream, const float *x, const float *w, const float *bias,
+                          float *y, int N, int H, int W, int OH, int OW, float mu0, float mu1, float mu2);
 
 /* ---- max-pool 3x3 / stride 2 / pad 1 on NHWC (modules.py:74,141) ------------------- */
 int usot_maxpool3x3s2_f32(void *stream, const float *x, float *y,
@@ -347,6 +352,15 @@ int usot_plan_add_stem_pool_ind(void *plan, const float *x, const float *wfrag, 
                                 int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev);
 int usot_plan_add_stem(void *plan, const float *x, const float *w, const float *bias, float *y,
                        int N, int H, int W, int OH, int OW);
+/* ... and both stem forms on x - mu[ci] (see usot_stem_conv_mu_f32) */
+int usot_stem_pool_mu_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
+                          int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev,
+                          float mu0, float mu1, float mu2);
+int usot_plan_add_stem_pool_mu(void *plan, const float *x, const float *wfrag, const float *bias, float *y,
+                               int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev,
+                               float mu0, float mu1, float mu2);
+int usot_plan_add_stem_mu(void *plan, const float *x, const float *w, const float *bias, float *y,
+                          int N, int H, int W, int OH, int OW, float mu0, float mu1, float mu2);
 int usot_plan_add_maxpool(void *plan, const float *x, float *y, int N, int H, int W, int C,
                           int OH, int OW);
 int usot_plan_add_conf_reduce(void *plan, const float *cv, float *out, int B, int M, int P, int C);

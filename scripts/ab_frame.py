@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-process A/B of the tracked frame with engine switches: builds one Session per configuration and alternates timed
-runs of bench.run_frames (the driver's loop) and of bare graph replays.  python scripts/ab_frame.py STREAM_1X1=0 STREAM_1X1=1"""
+runs of bench.run_frames (the driver's loop) and of bare graph replays.  python scripts/ab_frame.py stream_1x1=0 stream_1x1=1"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,12 +8,14 @@ import torch
 import bench
 from usot_amd import engine
 dev = torch.device('cuda:0')
-cfgs = sys.argv[1:] or ['STREAM_1X1=0', 'STREAM_1X1=1']
+cfgs = sys.argv[1:] or ['stream_1x1=0', 'stream_1x1=1']
 sessions = []
 for c in cfgs:
     for kv in c.split(','):
         k, v = kv.split('=')
-        setattr(engine, k, type(getattr(engine, k))(int(v)) if not isinstance(getattr(engine, k), set) else set())
+        k = k.lower()                         # engine.OPTIONS keys: stream_1x1=0, fused_f32_sliced=1, ...
+        cur = engine.OPTIONS[k]
+        engine.OPTIONS[k] = set() if isinstance(cur, set) else type(cur)(int(v))
     model, _ = bench.build_model(0, 1, dev)
     sess, crops, p = bench.open_stream(model, dev, seed=0)
     conf = bench.Confidences()
@@ -39,7 +41,7 @@ for c, sess, crops, p, conf in sessions:
         picks = bench.select_memory(conf.view(), p.mem_queue_size)
         t1 = time.perf_counter()
         evs[i][0].record(st)
-        sess.submit(crops[i % crops.shape[0]], picks, (63.5, 63.5))
+        sess.submit(crops[i % crops.shape[0]], picks, (63.5, 63.5), inplace=True)
         evs[i][1].record(st)
         t2 = time.perf_counter()
         out = sess.collect()

@@ -12,7 +12,9 @@ def rel(got, ref):
     e = np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).mean() + 1e-30)
     return e.max(), np.sqrt((e ** 2).mean())
 
-m = USOT(); sd = synth.torch_state_dict(m); m.load_state_dict(sd); m.eval(); m = m.to('cuda:0')
+FAMILY = sys.argv[1] if len(sys.argv) > 1 else 'zero_dc'
+print('family', FAMILY)
+m = USOT(); sd = synth.torch_state_dict(m, family=FAMILY); m.load_state_dict(sd); m.eval(); m = m.to('cuda:0')
 m.engine_options['graphs'] = False
 sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
 t = lambda a: torch.from_numpy(a)

@@ -11,9 +11,9 @@ from usot_amd import synth, engine
 from usot_amd.model import USOT
 from usot_amd import hip
 if os.environ.get('USOT_NO_FUSED_F32'):
-    engine.FUSED_POINTWISE_F32 = set()
+    engine.OPTIONS['fused_pointwise_f32'] = set()
 if os.environ.get('USOT_SLICED'):            # channel-sliced pairs on (layer2 sliced, layer3's pairs fused)
-    engine.FUSED_POINTWISE_F32_SLICED = True
+    engine.OPTIONS['fused_f32_sliced'] = True
 if os.environ.get('USOT_NO_SLICE'):          # fused pairs without the channel-sliced form
     hip.pw_pair_f32_ws = lambda *a, **k: None
 gold = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_model.npz')))

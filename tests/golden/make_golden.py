@@ -10,7 +10,7 @@ in this process only:
      into /root/reference);
   3. forward passes run under no_grad and eval().
 
-Usage:  python tests/golden/make_golden.py [calib] [model] [host] [e2e] [datasets] [family]
+Usage:  python tests/golden/make_golden.py [calib] [model] [host] [e2e] [datasets] [family] [model64] [e2e_long]
 """
 import json
 import os
@@ -384,6 +384,124 @@ def do_e2e():
     np.savez_compressed(os.path.join(GOLD, 'golden_e2e.npz'), **out)
 
 
+def do_e2e_long():
+    """BASELINE configs[3] asks for >= 500 frames per stream so that the online memory queue (usot_tracker.py:222-265:
+    confidence-ranked sampling over a growing list) is exercised: the reference tracker + reference model on CPU over
+    500-frame synthetic videos, one per instance size (255 and 271), with the same documented stand-ins as do_e2e.
+    Two float32 implementations agree to ~1e-4 on the response maps, so a long trajectory is only comparable frame by
+    frame while every DISCRETE decision of the tracker is taken with a clear margin.  Recorded per frame, besides the
+    trajectory: `margins` (top-1 minus top-2 of the penalised score map: the argmax), `round_slack` (distance of
+    pos - c and of s_x from the nearest rounding boundary, pixels: the crop window, track_utils.py:42-47,121-127) and
+    `pick_slack` (smallest top-1 minus top-2 confidence inside a sampled memory slice, usot_tracker.py:241-252).
+    Seeds are searched until the first frame with a small margin lies beyond frame MIN_CLEAN."""
+    from usot_amd import hostutils
+    sys.path.insert(3, os.path.join(REPO, 'oracle'))
+    import usot_oracle as orc
+    rt = _import_ref_tracker(resize=lambda img, size: hostutils.resize_bilinear_u8(img, size[0], size[1]))
+
+    def prroi(features, rois, ph, pw, scale):
+        return orc.prroi_pool(features, rois, ph, pw, scale)
+    ref_models.prroi_pool2d = prroi
+    import lib.models.connect as rc
+    rc.PrRoIPool2D.forward = lambda self, f, r: prroi(f, r, self.pooled_height, self.pooled_width, self.spatial_scale)
+    net, _ = build(calibrated=True)
+    net.eval()
+    NFRAMES, MIN_CLEAN = 500, 200
+    # what counts as a clear decision (the GPU test reads these from the fixture).  Two float32 evaluations of the logits
+    # differ by ~1e-4 absolute, i.e. ~3e-5 in the sigmoid-blended score and ~1e-3 px in the smoothed position.
+    M_TOL, R_TOL, P_TOL = 1e-4, 5e-3, 1e-4
+    margins = []
+    orig_track = net.track
+
+    def spy(x, template_mem=None, score_mem=None):
+        res = orig_track(x, template_mem=template_mem, score_mem=score_mem)
+        cls, bbox, cmem, xf = res
+        p = spy.p
+        S = p.score_size
+        sig = lambda a: 1.0 / (1.0 + np.exp(-a.numpy().reshape(S, S).astype(np.float32)))
+        score = p.ratio * sig(cls) + (1 - p.ratio) * sig(cmem)
+        hy = orc.Hyper(p.instance_size)
+        gx, gy, _, _ = orc.grids(hy)
+        b = bbox.numpy()[0]
+        x1, y1, x2, y2 = gx - b[0], gy - b[1], gx + b[2], gy + b[3]
+        tz = spy.tsz
+        ch = lambda r: np.maximum(r, 1.0 / r)
+        szf = lambda w, h: np.sqrt((w + (w + h) * 0.5) * (h + (w + h) * 0.5))
+        pen = np.exp(-(ch((tz[0] / tz[1]) / ((x2 - x1) / (y2 - y1))) * ch(szf(x2 - x1, y2 - y1) / szf(tz[0], tz[1])) - 1) * p.penalty_k)
+        win = np.outer(np.hanning(S), np.hanning(S))
+        ps = np.sort((pen * score * (1 - p.window_influence) + win * p.window_influence).reshape(-1))
+        margins.append(float(ps[-1] - ps[-2]))
+        return res
+    net.track = spy
+
+    def frac_slack(v):
+        return abs((v - np.floor(v)) - 0.5)
+
+    out = {}
+    wanted = [(255, (52.0, 38.0)), (271, (16.0, 12.0))]
+    vid, seed = 0, 10
+    while vid < len(wanted) and seed < 60:
+        seed += 1
+        inst_want, sz = wanted[vid]
+        trk = rt.USOTTracker(_Info())
+        del margins[:]
+        rslack, pslack = [], []
+        with torch.no_grad():
+            im, (cx, cy) = synth.frame(seed, t=0)
+            state = trk.init(im, np.array([cx, cy]), np.array(sz), net)
+            if state['p'].instance_size != inst_want:
+                print('seed', seed, 'instance', state['p'].instance_size, 'skip')
+                continue
+            spy.p = p = state['p']
+            rows = [[cx, cy, sz[0], sz[1], 0.0]]
+            ok = True
+            for f in range(1, NFRAMES):
+                im, _ = synth.frame(seed, t=f)
+                tsz, tpos = state['target_sz'], state['target_pos']
+                s_z = np.sqrt((tsz[0] + 0.5 * sum(tsz)) * (tsz[1] + 0.5 * sum(tsz)))
+                scale_z = p.exemplar_size / s_z
+                s_x = s_z + 2 * ((p.instance_size - p.exemplar_size) / 2) / scale_z
+                spy.tsz = np.asarray(tsz) * scale_z
+                win = rt.python2round(s_x) if hasattr(rt, 'python2round') else round(s_x)
+                c = (win + 1) / 2
+                # frame 1 starts from the init box, identical bits in every implementation: no rounding can differ
+                rslack.append(1.0 if f == 1 else min(frac_slack(s_x), frac_slack(tpos[0] - c), frac_slack(tpos[1] - c)))
+                conf = state['memory_confidences']
+                n, upd = len(conf), p.mem_queue_size - 3
+                ps_ = 1.0
+                if n > 1:
+                    gap = (n - 1) / upd
+                    for i in range(upd):
+                        a, b_ = min(int(int(i * gap) * n), n - 1), min(int(int((i + 1) * gap) * n), n - 1)
+                        if a < b_ and b_ - a > 1:
+                            top = np.sort(np.array(conf[a:b_], np.float64))
+                            ps_ = min(ps_, float(top[-1] - top[-2]))
+                pslack.append(ps_)
+                state = trk.track(state, im)
+                rows.append([*state['target_pos'], *state['target_sz'], float(state['cls_score'])])
+                if f < MIN_CLEAN and margins[-1] < M_TOL:
+                    ok = False
+                    break
+        print('seed', seed, 'instance', inst_want, 'frames', len(rows), 'min margin %.2e' % min(margins),
+              'min round slack %.2e' % min(rslack), 'min pick slack %.2e' % min(pslack), 'OK' if ok else 'skip')
+        if not ok:
+            continue
+        m, r_, pk = np.array(margins), np.array(rslack), np.array(pslack)
+        amb = np.nonzero((m < M_TOL) | (r_ < R_TOL) | (pk < P_TOL))[0]
+        print('  first frames with an unclear decision (margin | rounding | pick):', (amb[:12] + 1).tolist())
+        out['video%d/seed_frames_sz' % vid] = np.array([seed, NFRAMES, *sz])
+        out['video%d/track' % vid] = np.array(rows, np.float64)
+        out['video%d/instance_size' % vid] = np.array(inst_want)
+        out['video%d/margins' % vid] = m
+        out['video%d/round_slack' % vid] = r_
+        out['video%d/pick_slack' % vid] = pk
+        out['video%d/tolerances' % vid] = np.array([M_TOL, R_TOL, P_TOL])
+        vid += 1
+    assert vid == len(wanted), 'no seed with clear margins found'
+    np.savez_compressed(os.path.join(GOLD, 'golden_e2e_long.npz'), **out)
+    print('long e2e goldens: %.1f KB' % (os.path.getsize(os.path.join(GOLD, 'golden_e2e_long.npz')) / 1024))
+
+
 def do_family():
     """Second weight family ('dc': non-zero-DC filters, ordinary last-BN gains; usot_amd/synth.py): BN
     statistics calibrated like the first, then ONE tracked frame (template by centre crop, N_q = 7) through
@@ -408,6 +526,62 @@ def do_family():
             s = np.maximum(np.abs(b.numpy()), np.abs(b.numpy()).mean())
             print('%-8s %-8s reference f32 vs f64: scaled max %.2e' % (fam, nm, float((d / s).max())))
     np.savez_compressed(os.path.join(GOLD, 'golden_family.npz'), **g)
+
+
+def do_model64():
+    """Float64 truth for every whole-model fixture: the backbone stages at the four (size, batch)
+    cases and every track_* output of do_model(), for BOTH weight families, from the reference model in its own float32
+    arithmetic and converted with net.double().  Stored at the sample points of sampling.sample_index (same names as
+    golden_model.npz, so the zero_dc float32 entries coincide with it) as float64.  The GPU test gates
+    HIP-vs-float64 <= 1.5 x reference-float32-vs-float64 on every entry (tests/test_gpu_model.py)."""
+    from sampling import sample_index
+    g = {}
+
+    def put(fam, name, a32, a64):
+        a32, a64 = np.asarray(a32, np.float64), np.asarray(a64, np.float64)
+        if a32.size > 8192:
+            idx = sample_index(name, a32.size)
+            a32, a64 = a32.reshape(-1)[idx], a64.reshape(-1)[idx]
+        g['%s/%s/f32' % (fam, name)], g['%s/%s/f64' % (fam, name)] = a32, a64
+        d = np.abs(a32 - a64) / np.maximum(np.abs(a64), np.abs(a64).mean())
+        print('%-8s %-28s reference f32 vs f64: scaled max %.2e' % (fam, name, float(d.max())))
+
+    def run(net, cast):
+        out = {}
+        for size, b, seed in ((127, 1, 0), (255, 1, 1), (271, 1, 3), (255, 2, 4)):
+            stages, p3 = net.feature_extractor(cast(t(synth.crop(seed, b, size))))
+            tag = 'backbone_%d_b%d' % (size, b)
+            for nm, ten in zip(('stem', 'p1', 'p2'), stages):
+                out['%s/%s' % (tag, nm)] = ten.numpy()
+            out[tag + '/p3'] = p3.numpy()
+            out[tag + '/neck'] = net.neck(p3).numpy()
+        net.template(cast(t(synth.crop(0, 1, 127))))
+        out['template_crop/zf'] = net.zf.numpy().copy()
+        x, mem = cast(t(synth.crop(1, 1, 255))), cast(t(synth.memory_kernels(7, 7)))
+        cls, bbox, _, _ = net.track(x)
+        out['track_offline/cls'], out['track_offline/bbox'] = cls.numpy(), bbox.numpy()
+        sm = cast(torch.full((1, 7), 0.9))
+        for tag, xx in (('track_mem', x), ('track_mem_271', cast(t(synth.crop(3, 1, 271))))):
+            res = net.track(xx, template_mem=mem, score_mem=sm)
+            for nm, ten in zip(('cls', 'bbox', 'cls_mem', 'xf'), res):
+                out['%s/%s' % (tag, nm)] = ten.numpy()
+        net.template(cast(t(synth.crop(5, 2, 127))))
+        res = net.track(cast(t(synth.crop(4, 2, 255))), template_mem=cast(t(synth.memory_kernels(8, 14))),
+                        score_mem=cast(torch.full((2, 7), 0.9)))
+        for nm, ten in zip(('cls', 'bbox', 'cls_mem'), res):
+            out['track_mem_b2/' + nm] = ten.numpy()
+        return out
+    for fam in ('zero_dc', 'dc'):
+        net, _ = build(calibrated=True, family=fam)
+        net.eval()
+        net.pr_pool = False
+        with torch.no_grad():
+            o32 = run(net, lambda a: a)
+            o64 = run(net.double(), lambda a: a.double())
+        for k in o32:
+            put(fam, k, o32[k], o64[k])
+    np.savez_compressed(os.path.join(GOLD, 'golden_model_f64.npz'), **g)
+    print('float64 goldens: %d arrays, %.1f KB' % (len(g), os.path.getsize(os.path.join(GOLD, 'golden_model_f64.npz')) / 1024))
 
 
 def do_datasets():
@@ -442,4 +616,5 @@ def do_datasets():
 if __name__ == '__main__':
     what = sys.argv[1:] or ['calib', 'model', 'host']
     for w in what:
-        {'calib': do_calib, 'model': do_model, 'host': do_host, 'e2e': do_e2e, 'datasets': do_datasets, 'family': do_family}[w]()
+        {'calib': do_calib, 'model': do_model, 'host': do_host, 'e2e': do_e2e, 'datasets': do_datasets, 'family': do_family,
+         'model64': do_model64, 'e2e_long': do_e2e_long}[w]()

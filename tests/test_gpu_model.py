@@ -177,17 +177,82 @@ def test_second_weight_family_vs_float64(family, capsys):
         f32, f64 = g['%s/%s/f32' % (family, nm)], g['%s/%s/f64' % (family, nm)]
         e_hip64, e_ref64, e_hip32 = scaled(npy(got), f64), scaled(f32, f64), scaled(npy(got), f32)
         rows.append((nm, e_hip64, e_ref64, e_hip32))
-        # same order of magnitude as the reference's own float32 error.  Not "at most equal": the MFMA
-        # accumulates a K = 4608 reduction as one sequential float32 chain per output, oneDNN on the CPU in
-        # blocks, and with DC-passing filters every partial sum rides on a large common offset (measured on
-        # the 'dc' family: HIP 9.6e-4 vs reference 4.0e-4 at the cls logits; both 4e-5 on 'zero_dc')
-        assert e_hip64 <= 4.0 * e_ref64 + 2e-5, (family, nm, e_hip64, e_ref64)
+        # no further from float64 than 1.5 x the reference's own float32 arithmetic (tests/golden/f64_gate.py).  Round 2
+        # measured 2.8 x on the 'dc' logits: every MFMA k-loop was ONE sequential float32 chain of K = 4608 additions
+        # per output; the kernels now sum 64-product blocks into fresh accumulators (conv_igemm.hip: blocked_mma)
+        assert e_hip64 <= 1.5 * e_ref64 + 2e-7, (family, nm, e_hip64, e_ref64)
         assert e_hip32 <= 1.5 * (e_hip64 + e_ref64) + 1e-6, (family, nm, e_hip32)
         if family == 'zero_dc':
             assert e_hip32 < TOL, (nm, e_hip32)                  # the north-star bar on the conditioned family
     with capsys.disabled():
         for nm, a, b, c in rows:
             print('\n[family %-7s] %-7s HIP vs f64 %.2e | reference f32 vs f64 %.2e | HIP vs reference f32 %.2e' % (family, nm, a, b, c), end='')
+
+
+@pytest.mark.parametrize('family', ['zero_dc', 'dc'])
+def test_every_fixture_within_1p5x_of_the_references_own_float32_error(family, capsys):
+    """THE acceptance rule for float32 kernels (tests/golden/f64_gate.py): on both weight families, every whole-model
+    fixture (backbone stages at 127 / 255 / 271 / batch 2, template, offline and memory tracking at 255 / 271 / batch 2)
+    must be no further from the reference model evaluated in float64 than 1.5 x the reference's own float32 arithmetic
+    is, in scaled max AND rms error.  With blocked accumulation (conv_igemm.hip: blocked_mma) the HIP path measures
+    0.6-1.2 x; a single sequential MFMA chain per output was 2.8 x on the 'dc' logits."""
+    import f64_gate
+    gold = f64_gate.load()
+    m = USOT()
+    m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True, family=family), strict=True)
+    m.eval()
+    m = m.to(DEV)
+    rows = f64_gate.table(gold, family, f64_gate.run_model(m, DEV))
+    with capsys.disabled():
+        print('\n' + f64_gate.fmt(family, rows))
+    bad = f64_gate.violations(rows)
+    assert not bad, bad
+    if family == 'zero_dc':                       # and the north-star bar itself on the conditioned family
+        for name, _, _, h32 in rows:
+            assert h32[0] < TOL, (name, h32)
+
+
+# every switch of usot_amd.engine.DEFAULT_OPTIONS that changes which kernels a frame uses, flipped away from its default
+OPTION_VARIANTS = [{'fused_f32_sliced': True}, {'fused_triple_f32': False}, {'stream_1x1': False}, {'stream_3x3': False},
+                   {'fused_pointwise_f32': set()},
+                   {'stream_3x3_shapes': {(128, 128), (256, 256)}}, {'stream_1x1_shapes': {(256, 1024), (128, 512), (1024, 256), (512, 128)}}]
+
+
+@pytest.mark.parametrize('variant', OPTION_VARIANTS, ids=lambda v: ','.join(sorted(v)))
+def test_engine_option_variants_keep_parity(variant, capsys):
+    """Every lowering switch (engine.DEFAULT_OPTIONS; env names in engine.ENV_SWITCHES) is a configuration of the product
+    path: each one, flipped, must pass the same acceptance rule as the default (f64_gate: HIP-vs-float64 within 1.5 x the
+    reference's own float32 error on both weight families) and the 1e-4 north-star bar on the conditioned family."""
+    import f64_gate
+    from usot_amd import engine
+    assert set(variant) <= set(engine.DEFAULT_OPTIONS)
+    gold = f64_gate.load()
+    for family in ('zero_dc', 'dc'):
+        m = USOT()
+        m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True, family=family), strict=True)
+        m.eval()
+        m = m.to(DEV)
+        m.engine_options['options'] = variant
+        rows = f64_gate.table(gold, family, f64_gate.run_model(m, DEV))
+        bad = f64_gate.violations(rows)
+        worst = max(rows, key=lambda r: r[1][1] / r[2][1])
+        with capsys.disabled():
+            print('\n[%s %s] worst rms ratio %.2f (%s), worst HIP-vs-reference-f32 %.2e' % (
+                sorted(variant), family, worst[1][1] / worst[2][1], worst[0], max(r[3][0] for r in rows)), end='')
+        assert not bad, (variant, family, bad)
+        if family == 'zero_dc':
+            for name, _, _, h32 in rows:
+                assert h32[0] < TOL, (variant, name, h32)
+
+
+def test_engine_options_are_enumerable_and_checked():
+    from usot_amd import engine, hip
+    assert set(k for k, _ in engine.ENV_SWITCHES.values()) <= set(engine.DEFAULT_OPTIONS)
+    opt = engine.options_from_env({'USOT_STREAM_1X1': '0', 'USOT_STREAM_3X3_SHAPES': '128x128,256x256', 'USOT_SPIN_SECONDS': '0.01'})
+    assert opt['stream_1x1'] is False and opt['stream_3x3_shapes'] == {(128, 128), (256, 256)} and opt['spin_seconds'] == 0.01
+    assert engine.options_from_env({}) == engine.DEFAULT_OPTIONS
+    with pytest.raises(hip.HipError):
+        engine.merged_options({'no_such_switch': 1})
 
 
 def test_backbone_bf16_batch64_tracks_fp32(net, oracle_sd):

@@ -129,6 +129,13 @@ def test_stem_and_maxpool(size, n):
     p = hip.maxpool3x3s2(y)
     want = F.max_pool2d(y.permute(0, 3, 1, 2).cpu(), 3, 2, 1)
     assert torch.equal(p.permute(0, 3, 1, 2).cpu(), want)         # max-pool is exact
+    # the offset form (x - mu[ci], bias + sum(w) * mu folded in float64) is the same convolution, closer to float64
+    mu = (104.0, 117.0, 123.0)
+    bmu = (b.double() + (w.double() * torch.tensor(mu, dtype=torch.float64).view(1, 3, 1, 1)).sum((1, 2, 3))).float()
+    ymu = hip.stem_conv(x.to(DEV), wd, bmu.to(DEV), mu)
+    ref64 = F.relu(F.conv2d(x.double(), w.double(), b.double(), 2, 0)).numpy()
+    e_mu, e_plain = rel_err(ymu.permute(0, 3, 1, 2).cpu().numpy(), ref64), rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), ref64)
+    assert e_mu < 1e-5 and e_mu <= e_plain * 1.05 + 1e-7, (e_mu, e_plain)
 
 
 XC = [(29, 29, 5, 5), (27, 29, 3, 5), (29, 27, 5, 3), (31, 31, 5, 5), (33, 31, 5, 3), (12, 9, 4, 2),
@@ -830,11 +837,12 @@ def test_thin_conv3x3_prediction_heads(n, hw):
 
 def test_rows_copy_multi_gather_scatter_and_stash():
     """Four banks of different row length move with the same device row indices in one launch; the gather
-    also stashes idx[n_rows] (the frame's append row) in device memory."""
+    also stashes idx[n_rows .. n_rows+2] (the frame's append row and the crop address words: usot_hip.h) in device memory,
+    so a gather with a stash needs n_rows + 3 index entries."""
     import ctypes as C
     lens = [64, 128, 32, 256]
     banks = [torch.randn(12, n, device=DEV) for n in lens]
-    idx = torch.tensor([5, 0, 11, 7, 9], dtype=torch.int32, device=DEV)        # 4 rows + the stashed entry
+    idx = torch.tensor([5, 0, 11, 7, 9, 1234, -77], dtype=torch.int32, device=DEV)   # 4 rows + the three stashed entries
     outs = [torch.zeros(4, n, device=DEV) for n in lens]
     stash = torch.zeros(4, dtype=torch.int32, device=DEV)
     pp = lambda ts: (C.c_void_p * 4)(*[t.data_ptr() for t in ts])
@@ -842,7 +850,7 @@ def test_rows_copy_multi_gather_scatter_and_stash():
     hip.check(hip.lib().usot_rows_copy_multi_f32(hip.stream(), 4, pp(banks), hip.ptr(idx), pp(outs), 4, rl, 0, hip.ptr(stash)), 'gather')
     for b, o in zip(banks, outs):
         assert torch.equal(o, b[idx[:4].long()])
-    assert int(stash[0]) == 9
+    assert stash.tolist() == [9, 1234, -77, 0]
     dsts = [torch.zeros(12, n, device=DEV) for n in lens]
     hip.check(hip.lib().usot_rows_copy_multi_f32(hip.stream(), 3, pp(outs), hip.ptr(idx), pp(dsts), 4, rl, 1, None), 'scatter')
     for k, (o, d) in enumerate(zip(outs, dsts)):
@@ -870,3 +878,7 @@ def test_stem_pool_f32(size, n):
     assert rel_err(got.numpy(), ref.numpy()) < 2e-5
     two = hip.maxpool3x3s2(hip.stem_conv(x.to(DEV), packed.to(DEV), b.to(DEV))).cpu()
     assert rel_err(got.numpy(), two.numpy()) < 2e-5
+    mu = (104.0, 117.0, 123.0)
+    bmu = (b.double() + (w.double() * torch.tensor(mu, dtype=torch.float64).view(1, 3, 1, 1)).sum((1, 2, 3))).float()
+    gmu = hip.stem_pool(x.to(DEV), pack_stem_f32(packed).to(DEV), bmu.to(DEV), mu).cpu()
+    assert rel_err(gmu.numpy(), ref.numpy()) < 2e-5

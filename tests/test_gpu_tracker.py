@@ -230,15 +230,17 @@ def test_session_honours_mem_queue_size(net):
 
 
 def test_resident_crop_is_read_in_place(net):
-    """A float32 crop already on the device is not copied into the session's input buffer: its address travels in
-    the control block and the frame graph's first convolution reads it in place.  Same results as the copying
-    paths (host tensor; non-contiguous device view), frame after frame, with the crop at odd byte offsets."""
+    """submit(inplace=True): a float32 crop already on the device is not copied into the session's input buffer: its
+    address travels in the control block and the frame graph's first convolution reads it in place.  Same results as the
+    copying paths (host tensor; device tensor snapshot; non-contiguous device view), frame after frame, with the crop at
+    odd byte offsets.  The DEFAULT is a snapshot: the caller may overwrite its buffer right after submit()."""
+    from usot_amd import hip
     picks = [[0, 0, 0, 0, 0], [0, 1, 0, 1, 0], [2, 1, 0, 2, 1]]
     sess, crops = _open(net, 5)
     want = [sess.frame(crops[i].cpu(), picks[i], (63.5, 63.5)) for i in range(3)]          # host -> pinned -> copy
     sess, crops = _open(net, 5)
     sentinel = float(sess.x.abs().sum())
-    got = [sess.frame(crops[i], picks[i], (63.5, 63.5)) for i in range(3)]                  # in place (slices of a batch)
+    got = [sess.frame(crops[i], picks[i], (63.5, 63.5), inplace=True) for i in range(3)]    # in place (slices of a batch)
     assert float(sess.x.abs().sum()) == sentinel          # the session's own buffer was never written
     sess, crops = _open(net, 5)
     wide = torch.zeros(4, 3, 255, 300, device=crops.device)
@@ -246,3 +248,19 @@ def test_resident_crop_is_read_in_place(net):
     view = [sess.frame(wide[i, :, :, :255], picks[i], (63.5, 63.5)) for i in range(3)]      # strided view -> copy
     np.testing.assert_array_equal(np.array(got), np.array(want))
     np.testing.assert_array_equal(np.array(view), np.array(want))
+    # default = snapshot: the double-buffer pattern (overwrite the crop between submit and collect) is safe
+    sess, crops = _open(net, 5)
+    snap = []
+    for i in range(3):
+        buf = crops[i].clone()
+        sess.submit(buf, picks[i], (63.5, 63.5))
+        buf.fill_(7.0)                                     # enqueued behind the snapshot copy on the same stream
+        snap.append(sess.collect())
+    np.testing.assert_array_equal(np.array(snap), np.array(want))
+    # in-place crops must qualify: no silent copy, no foreign pointer handed to the kernel
+    with pytest.raises(hip.HipError):
+        sess.submit(wide[0, :, :, :255], picks[0], (63.5, 63.5), inplace=True)
+    with pytest.raises(hip.HipError):
+        sess.submit(crops[0].cpu(), picks[0], (63.5, 63.5), inplace=True)
+    with pytest.raises(hip.HipError):
+        sess.submit(crops[0].double(), picks[0], (63.5, 63.5), inplace=True)

@@ -31,7 +31,8 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(INCLUDE, '*.h'))
+    deps = (sources() + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(INCLUDE, '*.h'))
+            + [os.path.abspath(__file__)])               # FLAGS / FILE_FLAGS live in this file
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -48,16 +49,25 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src] + hdrs):
             continue                              # object is newer than its source and every header
-        cmd = [cc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
+        tmp = obj + '.tmp%d' % os.getpid()          # an interrupted hipcc must not leave a fresh-looking .o
+        cmd = [cc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', tmp]
         if verbose:
             print(' '.join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, p in procs:
+        procs.append((src, obj, tmp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = None
+    for src, obj, tmp, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError('hipcc failed on %s:\n%s' % (src, out.decode(errors='replace')))
-    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
-    subprocess.check_call(cmd)
+            failed = failed or 'hipcc failed on %s:\n%s' % (src, out.decode(errors='replace'))
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        else:
+            os.replace(tmp, obj)
+    if failed:
+        raise RuntimeError(failed)
+    tmp = LIB + '.tmp%d' % os.getpid()
+    subprocess.check_call([cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs)
+    os.replace(tmp, LIB)
     return LIB
 
 

@@ -8,3 +8,42 @@
     } while (0)
 
 static inline int usot_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Running total of the finished k-blocks of an MFMA accumulator (4 floats per lane); see conv_igemm.hip: blocked_mma.
+// USOT_TOT selects its arithmetic (a build-time experiment switch; scripts/tot_variants.py builds and times all of them).
+// Measured on one MI355X box, frame graph replay / mean rms ratio of HIP-vs-float64 to reference-float32-vs-float64 over the
+// 34 fixtures of tests/golden/f64_gate.py ('zero_dc', 'dc'):
+//   1  plain float32 adds (default)     873.6 us   0.38 / 0.35    (K/64 sequential roundings of the growing total)
+//   2  float64 total                    931.3 us   0.37 / 0.35    (v_cvt_f64_f32 + v_add_f64 per register and block)
+//   4  float32 Kahan-compensated total  948.9 us   0.37 / 0.35
+// i.e. once the products are summed in 64-wide blocks the rounding of the TOTAL is no longer what separates the frame from
+// float64 (activation roundings between ~60 layers are), and the compensated forms buy nothing for 6-8 % of the frame.
+#ifndef USOT_TOT
+#define USOT_TOT 1
+#endif
+typedef float usot_f32x4 __attribute__((ext_vector_type(4)));
+typedef double usot_f64x4 __attribute__((ext_vector_type(4)));
+struct BlockTotal {
+#if USOT_TOT == 2
+    usot_f64x4 s;
+    __device__ __forceinline__ void clear() { s = usot_f64x4{0., 0., 0., 0.}; }
+    __device__ __forceinline__ void add(usot_f32x4 p) { s += __builtin_convertvector(p, usot_f64x4); }
+    __device__ __forceinline__ usot_f32x4 get() const { return __builtin_convertvector(s, usot_f32x4); }
+#elif USOT_TOT == 4
+    usot_f32x4 s, c;                 // c = what the additions so far have lost, negated (Kahan)
+    __device__ __forceinline__ void clear() { s = c = usot_f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ void add(usot_f32x4 p)
+    {
+        const usot_f32x4 y = p - c;
+        const usot_f32x4 t = s + y;
+        c = (t - s) - y;             // no -ffast-math in this build: evaluated as written
+        s = t;
+    }
+    __device__ __forceinline__ usot_f32x4 get() const { return s - c; }
+#else
+    usot_f32x4 s;
+    __device__ __forceinline__ void clear() { s = usot_f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ void add(usot_f32x4 p) { s += p; }
+    __device__ __forceinline__ usot_f32x4 get() const { return s; }
+#endif
+};

@@ -31,6 +31,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 struct ConvK {
@@ -167,6 +168,38 @@ __device__ __forceinline__ int xcd_remap(int b, int total)
 
 constexpr int LDK = 36;   // padded k-extent of an LDS row (floats)
 
+// Blocked accumulation.  v_mfma_f32_16x16x4_f32 adds its four products to C one after the other, so a plain k-loop is ONE
+// sequential float32 chain of K additions per output: on a K = 4608 reduction its rounding error is 4x (rms) that of a
+// CPU convolution of the same data, and with filters that pass the DC level of post-ReLU maps the frame's logits end up
+// 2.8x further from a float64 evaluation than the reference's own float32 arithmetic (tests/test_gpu_model.py, 'dc' family).
+// Every kernel of this file therefore sums a k-tile (32 / 64 products) into a fresh accumulator — the first MFMA of a block
+// takes C = 0, an inline constant: nothing to clear — and adds finished blocks to a running total (common.h: BlockTotal;
+// plain float32 by default, float64 / Kahan forms measured there), eight VALU adds per k-tile placed right after the
+// k-loop's barrier where the block's MFMAs have long retired, issued in the shadow of the next block's MFMAs.  Chains:
+// 64 + K/64 instead of K.  Emulated on the layer3.0 shortcut conv: rms error of the output 1.76e-6 (single
+// chain) -> 3.6e-7 (float32 total; torch-CPU: 3.9e-7); measured on the whole frame in tests/golden/f64_gate.py.
+// one 16-k round = 4 MFMAs per 16x16 block from the fragments wf / xf; first: this round starts a block
+template <int TN, int TM, bool DUAL = true>
+__device__ __forceinline__ void blocked_mma(f32x4 (&acc)[TN][TM], f32x4 &acc2, const f32x4 (&wf)[TN], const f32x4 (&xf)[TM], bool first)
+{
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (TM * TN == 1 && DUAL) {
+        // a wave with a single 16x16 block alternates two accumulators (40-cycle dependent latency vs 32-cycle issue)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][0], xf[0][0], first ? zero : acc[0][0], 0, 0, 0);
+        acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][1], xf[0][1], first ? zero : acc2, 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][2], xf[0][2], acc[0][0], 0, 0, 0);
+        acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][3], xf[0][3], acc2, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][c], xf[j][c], (first && c == 0) ? zero : acc[i][j], 0, 0, 0);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int DBG = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvBatch bt)
 {
@@ -266,6 +299,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvBatch bt)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    BlockTotal tot[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) tot[i][j].clear();
     if (kt0 < kt1) {
         load_tile(kt0);
         store_tile(0);
@@ -277,6 +315,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvBatch bt)
         if (more && DBG < 1) load_tile(kt + 1);
         const float *cX = sX + (cur * BM + wm * TM * 16 + l15) * LDK + quad * 4;
         const float *cW = sW + (cur * BN + wn * TN * 16 + l15) * LDK + quad * 4;
+        if (((kt - kt0) & 1) == 0) {                  // a block = two 32-deep k-tiles (blocked_mma above)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) tot[i][j].add(acc[i][j]);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             f32x4 wf[TN], xf[TM];
@@ -284,17 +328,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvBatch bt)
             for (int i = 0; i < TN; ++i) wf[i] = DBG < 2 ? *(const f32x4 *)(cW + i * 16 * LDK + r * 16) : f32x4{1.f + kt, 2.f, 3.f, 4.f + i};
 #pragma unroll
             for (int j = 0; j < TM; ++j) xf[j] = DBG < 2 ? *(const f32x4 *)(cX + j * 16 * LDK + r * 16) : f32x4{1.f, 2.f + kt, 3.f + j, 4.f};
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][c], xf[j][c], acc[i][j], 0, 0, 0);
+            f32x4 unused = {0.f, 0.f, 0.f, 0.f};
+            blocked_mma<TN, TM, false>(acc, unused, wf, xf, r == 0 && ((kt - kt0) & 1) == 0);
         }
         if (more && DBG < 1) store_tile(cur ^ 1);
         __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) { tot[i][j].add(acc[i][j]); acc[i][j] = tot[i][j].get(); }
 
     // ---- epilogue: lane holds channels co..co+3 (quad*4 + reg) of pixel m (l15)
     if (p.ksplit > 1) {
@@ -516,22 +559,21 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
     // dependent latency vs 32-cycle issue: an 80 % cap); it alternates two accumulators instead
     // (even / odd k-slots) and adds them at the end.
     f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-    auto mma = [&](int slot) {
-        if constexpr (TM * TN == 1) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][0], fx[slot][0][0], acc[0][0], 0, 0, 0);
-            acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][1], fx[slot][0][1], acc2, 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][2], fx[slot][0][2], acc[0][0], 0, 0, 0);
-            acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][3], fx[slot][0][3], acc2, 0, 0, 0);
-        } else {
+    // Blocked accumulation (blocked_mma above).  The block boundary sits at the mid-tile barrier: right after it the MFMAs
+    // issued before it have retired, the block is added to `tot` and the tile's last round starts the next block with C = 0.
+    BlockTotal tot[TN][TM];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
+        for (int j = 0; j < TM; ++j) tot[i][j].clear();
+    auto flush = [&]() {
 #pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][i][c], fx[slot][j][c], acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) tot[i][j].add(acc[i][j]);
+        if constexpr (TM * TN == 1) tot[0][0].add(acc2);
     };
+    auto mma = [&](int slot, bool first) { blocked_mma<TN, TM>(acc, acc2, fw[slot], fx[slot], first); };
 
     const int nt_all = kt1 - kt0;
     const int nt = (nt_all - grp + KSW - 1) / KSW;      // k-tiles of this wave group
@@ -559,12 +601,17 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
                 if (t + 2 < nt) load_tile(t + 3 < nt);
                 __syncthreads();                  // lowers to lgkmcnt(0) + s_barrier (no vmcnt drain)
                 if (t + 1 < nt) read_frags(st1, 0, 0);
+                flush();
             }
-            mma(r & 1);
+            mma(r & 1, r == NR - 1);
         }
         st = st1;
     }
-    if constexpr (TM * TN == 1) acc[0][0] += acc2;
+    flush();
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = tot[i][j].get();
 
     if (KSW > 1) {
         // meet in LDS: thread (lane, wave) of every group holds the same (channel, pixel) slots
@@ -864,24 +911,25 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
     // dependent latency vs 32-cycle issue: an 80 % cap); it alternates two accumulators instead
     // (even / odd k-slots) and adds them at the end.
     f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-    auto mma = [&](int slot) {
+    // Blocked accumulation (see blocked_mma above): `acc` holds ONE k-tile's partial sums (its first MFMA takes C = 0),
+    // `tot` the running total the finished k-tile is added to right after the barrier, when its MFMAs have long retired.
+    BlockTotal tot[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) tot[i][j].clear();
+    auto flush = [&]() {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) tot[i][j].add(acc[i][j]);
+        if constexpr (TM * TN == 1) tot[0][0].add(acc2);
+    };
+    auto mma = [&](int slot, bool first) {
 #ifdef USOT_ABL_NOMMA
         return;
 #endif
-        if constexpr (TM * TN == 1) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][0], fx[slot][0][0], acc[0][0], 0, 0, 0);
-            acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][1], fx[slot][0][1], acc2, 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][2], fx[slot][0][2], acc[0][0], 0, 0, 0);
-            acc2      = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][0][3], fx[slot][0][3], acc2, 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[slot][i][c], fx[slot][j][c], acc[i][j], 0, 0, 0);
-        }
+        blocked_mma<TN, TM>(acc, acc2, fw[slot], fx[slot], first);
     };
     // bias and residual of this lane's outputs are fetched NOW, while the producers bring the first k-tiles:
     // loaded in the epilogue they add a dependent L2/HBM round trip to the tail of every layer, when no
@@ -910,11 +958,12 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
     for (int t = 0; t < nt; ++t) {
         const int st1 = st == 2 ? 0 : st + 1;
         USOT_STAMP(0, t);
+        flush();                                      // the previous k-tile's block (zeros at t = 0)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
             else if (t + 1 < nt) read_frags(st1, 0, 0);
-            mma(r & 1);
+            mma(r & 1, r == 0);
         }
         st = st1;
         USOT_STAMP(1, t);
@@ -924,7 +973,11 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
         USOT_STAMP(2, t);
     }
 #undef USOT_STAMP
-    if constexpr (TM * TN == 1) acc[0][0] += acc2;
+    flush();
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = tot[i][j].get();
 
     if (p.ksplit > 1) {
 #pragma unroll

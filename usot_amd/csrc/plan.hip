@@ -79,8 +79,8 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
             break;
         case K_GDW:  rc = usot_groupdw_multi_f32(s, op.gdw, op.ngdw); break;
         case K_STEM:
-            rc = usot_stem_conv_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2],
-                                    (float *)op.p[3], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4]);
+            rc = usot_stem_conv_mu_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2],
+                                       (float *)op.p[3], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.f[1], op.f[2], op.f[3]);
             break;
         case K_POOL:
             rc = usot_maxpool3x3s2_f32(s, (const float *)op.p[0], (float *)op.p[1], op.i[0], op.i[1], op.i[2],
@@ -124,8 +124,9 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
             rc = usot_maxpool3x3s2_lp(s, op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6]);
             break;
         case K_STEMP:
-            rc = usot_stem_pool_ind_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], (float *)op.p[3],
-                                        op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], (const int32_t *)op.p[4]);
+            rc = usot_stem_pool_mu_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], (float *)op.p[3],
+                                       op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], (const int32_t *)op.p[4],
+                                       op.f[1], op.f[2], op.f[3]);
             break;
         case K_THIN: {
             usot_conv_desc tmp[4];
@@ -314,10 +315,18 @@ extern "C" int usot_plan_add_stem_pool(void *plan, const float *x, const float *
 extern "C" int usot_plan_add_stem_pool_ind(void *plan, const float *x, const float *wfrag, const float *bias, float *y,
                                            int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev)
 {
+    return usot_plan_add_stem_pool_mu(plan, x, wfrag, bias, y, N, H, W, OH, OW, PH, PW, xptr_dev, 0.f, 0.f, 0.f);
+}
+
+extern "C" int usot_plan_add_stem_pool_mu(void *plan, const float *x, const float *wfrag, const float *bias, float *y,
+                                          int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev,
+                                          float mu0, float mu1, float mu2)
+{
     Op *op = push(plan, K_STEMP);
     if (!op) return USOT_ESTATE;
     op->p[0] = x; op->p[1] = wfrag; op->p[2] = bias; op->p[3] = y; op->p[4] = xptr_dev;
     op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = OH; op->i[4] = OW; op->i[5] = PH; op->i[6] = PW;
+    op->f[1] = mu0; op->f[2] = mu1; op->f[3] = mu2;
     return USOT_OK;
 }
 
@@ -392,10 +401,17 @@ extern "C" int usot_plan_add_groupdw_multi(void *plan, const usot_groupdw_desc *
 extern "C" int usot_plan_add_stem(void *plan, const float *x, const float *w, const float *bias, float *y,
                                   int N, int H, int W, int OH, int OW)
 {
+    return usot_plan_add_stem_mu(plan, x, w, bias, y, N, H, W, OH, OW, 0.f, 0.f, 0.f);
+}
+
+extern "C" int usot_plan_add_stem_mu(void *plan, const float *x, const float *w, const float *bias, float *y,
+                                     int N, int H, int W, int OH, int OW, float mu0, float mu1, float mu2)
+{
     Op *op = push(plan, K_STEM);
     if (!op) return USOT_ESTATE;
     op->p[0] = x; op->p[1] = w; op->p[2] = bias; op->p[3] = y;
     op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = OH; op->i[4] = OW;
+    op->f[1] = mu0; op->f[2] = mu1; op->f[3] = mu2;
     return USOT_OK;
 }
 

@@ -46,6 +46,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 struct PwF {
@@ -74,15 +75,33 @@ struct GemmRing {
     }
     __device__ __forceinline__ void run(const f32x4 *__restrict__ wf, const float *bs, int cb0, int r0, f32x4 (&acc)[CBW])
     {
+        // Blocked accumulation (conv_igemm.hip, blocked_mma): four rounds = 64 products go into one of two alternating block
+        // accumulators (first MFMA with C = 0); a block joins the running total when its register is due for reuse, two
+        // blocks = 32 MFMAs later, so no add ever waits for the matrix pipe; the total is a BlockTotal (common.h).  Everything below is unrolled: static registers.
+        constexpr int G = 4;                              // rounds per block
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 part[CBW][2];
+        BlockTotal tot[CBW];                              // running total of finished blocks (common.h)
 #pragma unroll
-        for (int u = 0; u < CBW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < CBW; ++u) { part[u][0] = part[u][1] = zero; tot[u].clear(); }
 #pragma unroll
         for (int n = 0; n < N; ++n) {
             const f32x4 b = *(const f32x4 *)(bs + (r0 + n % RS) * 16);
             const f32x4 a = ring[n % PF];
             if (n + PF < N) ring[n % PF] = frag(wf, cb0, r0, n + PF);
+            const int u = n / RS, rr = n % RS, g = rr / G, s = g & 1;
+            const bool first = rr % G == 0;
+            if (first && g >= 2) tot[u].add(part[u][s]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[n / RS] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], acc[n / RS], 0, 0, 0);
+            for (int c = 0; c < 4; ++c)
+                part[u][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], (first && c == 0) ? zero : part[u][s], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < CBW; ++u) {                   // the last one or two blocks of every column block are still open
+            constexpr int GL = (RS - 1) / G;              // index of the last block
+            if (GL >= 1) tot[u].add(part[u][(GL & 1) ^ 1]);
+            tot[u].add(part[u][GL & 1]);
+            acc[u] = tot[u].get();
         }
     }
 };

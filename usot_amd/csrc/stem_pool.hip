@@ -26,7 +26,7 @@ constexpr int PTP = PTW + 2;          // padded LDS row
 
 __global__ __launch_bounds__(256) void stem_conv7_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-    float *__restrict__ y, int H, int W, int OH, int OW)
+    float *__restrict__ y, int H, int W, int OH, int OW, float mu0, float mu1, float mu2)
 {
     __shared__ __attribute__((aligned(16))) float wl[147 * 64];
     __shared__ float patch[3 * PT * PTP];
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void stem_conv7_kernel(
         const int ci = i / (PT * PTW), r = i - ci * PT * PTW;
         const int py = r / PTW, px = r - py * PTW;
         const int iy = iy0 + py, ix = ix0 + px;
-        preg[k] = (i < 3 * PT * PTW && iy < H && ix < W) ? xn[((long)ci * H + iy) * W + ix] : 0.f;
+        // x - mu[ci] (exact for pad 0: every tap of a valid output reads a real pixel; the caller's bias carries sum(w) * mu)
+        preg[k] = (i < 3 * PT * PTW && iy < H && ix < W) ? xn[((long)ci * H + iy) * W + ix] - (ci == 0 ? mu0 : ci == 1 ? mu1 : mu2) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
@@ -157,7 +158,8 @@ constexpr int FP_OP = 64 + 4;                        // stem-tile LDS row pitch 
 
 __global__ __launch_bounds__(256) void stem_pool_f32_kernel(
     const float *__restrict__ x, const float *__restrict__ wfrag, const float *__restrict__ bias,
-    float *__restrict__ y, int H, int W, int OH, int OW, int PH, int PW, const int *__restrict__ xptr)
+    float *__restrict__ y, int H, int W, int OH, int OW, int PH, int PW, const int *__restrict__ xptr,
+    float mu0, float mu1, float mu2)
 {
     // xptr != NULL: the crop's address comes from DEVICE memory (two ints: low / high half), written earlier in the
     // same graph from the host's control block — a captured frame can then read ANY resident crop, no copy into a
@@ -189,7 +191,11 @@ __global__ __launch_bounds__(256) void stem_pool_f32_kernel(
         const int py = r / FP_IP, px = r - py * FP_IP;
         const int iy = iy0 + py, ix = ix0 + px;
         float v = 0.f;
-        if (ci < 3 && px < FP_I && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xn[((long)ci * H + iy) * W + ix];
+        // x - mu[ci]: raw crops are 0..255 around ~100 (track_utils.py:24-27 feeds them unnormalised); without the offset
+        // every partial sum of the 147-tap chain rides on 100 * sum(w).  Exact for pad 0 (only real pixels reach a valid
+        // output; out-of-image patch entries feed halo stem pixels the pool never reads); the bias carries sum(w) * mu.
+        if (ci < 3 && px < FP_I && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            v = xn[((long)ci * H + iy) * W + ix] - (ci == 0 ? mu0 : ci == 1 ? mu1 : mu2);
         pv[q] = v;
     }
 #pragma unroll
@@ -248,12 +254,18 @@ __global__ __launch_bounds__(256) void stem_pool_f32_kernel(
 extern "C" int usot_stem_conv_f32(void *stream, const float *x, const float *w, const float *bias,
                                   float *y, int N, int H, int W, int OH, int OW)
 {
+    return usot_stem_conv_mu_f32(stream, x, w, bias, y, N, H, W, OH, OW, 0.f, 0.f, 0.f);
+}
+
+extern "C" int usot_stem_conv_mu_f32(void *stream, const float *x, const float *w, const float *bias,
+                                     float *y, int N, int H, int W, int OH, int OW, float mu0, float mu1, float mu2)
+{
     if (!x || !w || !bias || !y || N <= 0 || H < 7 || W < 7) return USOT_EINVAL;
     if (OH != (H - 7) / 2 + 1 || OW != (W - 7) / 2 + 1) return USOT_EINVAL;
     if ((uintptr_t)y % 16) return USOT_EINVAL;
     if ((uintptr_t)w % 16) return USOT_EINVAL;
     dim3 grid(usot_cdiv(OW, STW), usot_cdiv(OH, ST), N);
-    hipLaunchKernelGGL(stem_conv7_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, H, W, OH, OW);
+    hipLaunchKernelGGL(stem_conv7_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, H, W, OH, OW, mu0, mu1, mu2);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }
@@ -275,17 +287,22 @@ extern "C" int usot_maxpool3x3s2_f32(void *stream, const float *x, float *y,
 /* Fused fp32 stem + max-pool (frame plans: the stem map itself is not needed).  wfrag = the BN-folded
  * filter bank as MFMA A operands [4 channel blocks][48 k-steps][64 lanes] (usot_amd/engine.py:
  * pack_stem_f32), bias fp32[64], y NHWC [N][PH][PW][64]. */
-extern "C" int usot_stem_pool_ind_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
-                                      int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev);
 
 extern "C" int usot_stem_pool_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
                                   int N, int H, int W, int OH, int OW, int PH, int PW)
 {
-    return usot_stem_pool_ind_f32(stream, x, wfrag, bias, y, N, H, W, OH, OW, PH, PW, nullptr);
+    return usot_stem_pool_mu_f32(stream, x, wfrag, bias, y, N, H, W, OH, OW, PH, PW, nullptr, 0.f, 0.f, 0.f);
 }
 
 extern "C" int usot_stem_pool_ind_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
                                       int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev)
+{
+    return usot_stem_pool_mu_f32(stream, x, wfrag, bias, y, N, H, W, OH, OW, PH, PW, xptr_dev, 0.f, 0.f, 0.f);
+}
+
+extern "C" int usot_stem_pool_mu_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
+                                     int N, int H, int W, int OH, int OW, int PH, int PW, const int32_t *xptr_dev,
+                                     float mu0, float mu1, float mu2)
 {
     if (!x || !wfrag || !bias || !y || N <= 0 || N > 65535 || H < 7 || W < 7) return USOT_EINVAL;
     if (OH != (H - 7) / 2 + 1 || OW != (W - 7) / 2 + 1) return USOT_EINVAL;
@@ -293,7 +310,7 @@ extern "C" int usot_stem_pool_ind_f32(void *stream, const float *x, const float 
     if (((uintptr_t)y % 16) || ((uintptr_t)bias % 16)) return USOT_EINVAL;
     dim3 grid(usot_cdiv(PW, FP_P), usot_cdiv(PH, FP_P), N);
     hipLaunchKernelGGL(stem_pool_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, wfrag, bias, y, H, W, OH, OW, PH, PW,
-                       (const int *)xptr_dev);
+                       (const int *)xptr_dev, mu0, mu1, mu2);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }

@@ -98,7 +98,12 @@ class Weights:
         w = f.conv1.weight.detach().double().cpu()
         s = f.bn1.weight.detach().double().cpu() / torch.sqrt(f.bn1.running_var.detach().double().cpu() + f.bn1.eps)
         self.stem_w = (w * s.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(147, 64).float().contiguous().to(device)
-        self.stem_b = (f.bn1.bias.detach().double().cpu() - f.bn1.running_mean.detach().double().cpu() * s).float().to(device)
+        b64 = f.bn1.bias.detach().double().cpu() - f.bn1.running_mean.detach().double().cpu() * s
+        self.stem_b = b64.float().to(device)
+        # the fp32 stem kernels convolve x - STEM_MU[ci] too (exact for this pad-0 conv): their bias carries sum(w) * mu,
+        # folded here in float64 with the unrounded filters
+        mu = torch.tensor(self.STEM_MU, dtype=torch.float64).view(3, 1, 1, 1)
+        self.stem_b_mu = (b64 + ((w * s.view(-1, 1, 1, 1)).permute(1, 2, 3, 0) * mu).sum((0, 1, 2))).float().to(device)
         self._stem_lp = {}
         self.blocks = []
         for layer in (f.layer1, f.layer2, f.layer3):
@@ -123,7 +128,7 @@ class Weights:
         sm = lambda p: torch.softmax(p.detach().float().cpu(), 0).numpy()
         self.cls_wsm, self.reg_wsm = sm(cm.cls_dw.weight), sm(cm.reg_dw.weight)
 
-    # the low-precision stem convolves x - STEM_MU[ci] (raw BGR 0..255 crops, test_utils.py
+    # every stem kernel convolves x - STEM_MU[ci] (raw BGR 0..255 crops, test_utils.py
     # feeds them unnormalised) and carries the exact mu term in its bias
     STEM_MU = (104.0, 117.0, 123.0)
 
@@ -216,8 +221,9 @@ class Plan:
 class Builder:
     """Allocates static buffers and appends ops to a plan."""
 
-    def __init__(self, weights, tuning=None, lanes=True):
+    def __init__(self, weights, tuning=None, lanes=True, options=None):
         self.W = weights
+        self.opt = merged_options() if options is None else options
         self.dev = weights.device
         self.plan = Plan()
         self.tuning = tuning or {}
@@ -335,17 +341,17 @@ class Builder:
         s0 = None
         if need_stem:
             s0 = self.buf(n, oh, oh, 64)
-            hip.check(L.usot_plan_add_stem(self.plan.h, hip.ptr(x), hip.ptr(W.stem_w), hip.ptr(W.stem_b), hip.ptr(s0),
-                                           n, size, size, oh, oh), 'plan_add_stem')
+            hip.check(L.usot_plan_add_stem_mu(self.plan.h, hip.ptr(x), hip.ptr(W.stem_w), hip.ptr(W.stem_b_mu), hip.ptr(s0),
+                                              n, size, size, oh, oh, *W.STEM_MU), 'plan_add_stem')
             hip.check(L.usot_plan_add_maxpool(self.plan.h, hip.ptr(s0), hip.ptr(p0), n, oh, oh, 64, ph, ph), 'plan_add_maxpool')
         else:
             wf = W.stem_f32()
             # xptr_dev (device int32[2], optional): the crop's address is read from device memory at run time
-            hip.check(L.usot_plan_add_stem_pool_ind(self.plan.h, hip.ptr(x), hip.ptr(wf), hip.ptr(W.stem_b), hip.ptr(p0),
-                                                    n, size, size, oh, oh, ph, ph,
-                                                    C.c_void_p(xptr_dev.data_ptr()) if xptr_dev is not None else None),
-                      'plan_add_stem_pool')
-            self.plan.keep += [wf]
+            hip.check(L.usot_plan_add_stem_pool_mu(self.plan.h, hip.ptr(x), hip.ptr(wf), hip.ptr(W.stem_b_mu), hip.ptr(p0),
+                                                   n, size, size, oh, oh, ph, ph,
+                                                   C.c_void_p(xptr_dev.data_ptr()) if xptr_dev is not None else None,
+                                                   *W.STEM_MU), 'plan_add_stem_pool')
+            self.plan.keep += [wf, W.stem_b_mu]
         self.plan.keep += [x]
         cur, h = p0, ph
         stages = [s0]
@@ -370,14 +376,15 @@ class Builder:
             nxt = W.neck if last else W.blocks[bi + 1][0]
             shape = (c3.cin, c3.cout, nxt.cout)
             m2 = n * h2 * h2
+            O = self.opt
             fuse = self.lanes == 0 and nxt.kh == 1 and (
-                (shape in FUSED_POINTWISE_F32 and m2 <= FUSED_POINTWISE_F32_MAX_M) or
-                (FUSED_POINTWISE_F32_SLICED and shape in FUSED_POINTWISE_F32_SLICED_ONLY
+                (shape in O['fused_pointwise_f32'] and m2 <= O['fused_pointwise_f32_max_m']) or
+                (O['fused_f32_sliced'] and shape in O['fused_pointwise_f32_sliced_only']
                  and hip.lib().usot_pw_pair_f32_ws_floats(m2, *shape) > 0))
             nm = 'b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1))
             act2 = ACT_NONE if last else ACT_RELU
-            if (fuse and FUSED_TRIPLE_F32 and c2.kh == 3 and c2.stride == 1 and m2 <= FUSED_POINTWISE_F32_MAX_M
-                    and (c2.cin, c3.cin, c3.cout, nxt.cout) in FUSED_TRIPLE_F32_SHAPES
+            if (fuse and O['fused_triple_f32'] and c2.kh == 3 and c2.stride == 1 and m2 <= O['fused_pointwise_f32_max_m']
+                    and (c2.cin, c3.cin, c3.cout, nxt.cout) in O['fused_triple_f32_shapes']
                     and hip.lib().usot_pw_triple_f32_supported(c2.cin, c3.cin, c3.cout, nxt.cout)):
                 cur, t1_fused = self.pw_triple_f32('b%d.conv2+' % bi + nm, c2, c3, nxt, t1, sc, n, h, act2=act2)
             else:
@@ -452,7 +459,7 @@ class Builder:
         # channel-sliced form (four workgroups per pixel tile when there are few tiles): 13.6 -> 8.7 us per layer2 pair, but
         # its k-sliced second GEMM moved ONE end-to-end golden output from 9.3e-5 to 1.011e-4 of the 1e-4 bar
         # (scripts/golden_margins.py; rounding noise, every variant sits at 8-9.5e-5) - off unless asked for
-        ws = hip.pw_pair_f32_ws(m, c3.cin, c3.cout, nxt.cout, self.dev) if FUSED_POINTWISE_F32_SLICED else None
+        ws = hip.pw_pair_f32_ws(m, c3.cin, c3.cout, nxt.cout, self.dev) if self.opt['fused_f32_sliced'] else None
         d = hip.pw_pair_desc(t2.data_ptr(), w3p.data_ptr(), c3.b.data_ptr(), res.data_ptr(), y.data_ptr(), w1p.data_ptr(),
                              nxt.b.data_ptr(), t.data_ptr(), m, c3.cin, c3.cout, nxt.cout, act2,
                              ws.data_ptr() if ws is not None else None)
@@ -489,15 +496,15 @@ class Builder:
         """A backbone 3x3 convolution: the streaming kernel for the shapes / sizes where it wins at batch 1, else tiled."""
         oh, ow = pc.out_hw(h, w)
         tiles = (n * oh * ow + 15) // 16
-        if (STREAM_3X3 and self.lanes == 0 and pc.kh == 3 and pc.stride == 1 and (pc.cin, pc.cout) in STREAM_3X3_SHAPES
+        if (self.opt['stream_3x3'] and self.lanes == 0 and pc.kh == 3 and pc.stride == 1 and (pc.cin, pc.cout) in self.opt['stream_3x3_shapes']
                 and tiles * 4 <= 256 and hip.lib().usot_stream_conv3x3_f32_supported(pc.cin, pc.cout)):
             return self.stream3x3(name, pc, x, n, h, w, act=act)
         return self.conv(name, pc, x, n, h, w, act=act)
 
     def conv1x1(self, name, pc, x, n, h, act=ACT_NONE, res=None):
         """A backbone 1x1 convolution: the streaming kernel when the layer has few pixels (batch 1), else the tiled one."""
-        if (STREAM_1X1 and self.lanes == 0 and pc.kh == 1 and pc.stride == 1 and n * h * h <= STREAM_1X1_MAX_M
-                and (pc.cin, pc.cout) in STREAM_1X1_SHAPES and hip.lib().usot_pw_single_f32_supported(pc.cin, pc.cout)):
+        if (self.opt['stream_1x1'] and self.lanes == 0 and pc.kh == 1 and pc.stride == 1 and n * h * h <= self.opt['stream_1x1_max_m']
+                and (pc.cin, pc.cout) in self.opt['stream_1x1_shapes'] and hip.lib().usot_pw_single_f32_supported(pc.cin, pc.cout)):
             return self.pw_single(name, pc, x, n, h, act=act, res=res)
         return self.conv(name, pc, x, n, h, h, act=act, res=res)
 
@@ -585,7 +592,7 @@ class Builder:
             # neck after the last block): the 4x-wide map is written once and not read back
             last = bi + 1 == nb
             nxt = (W.neck if not neck_f32 else None) if last else W.blocks[bi + 1][0]
-            if fuse and nxt is not None and (c3.cin, c3.cout, nxt.cout) in FUSED_POINTWISE:
+            if fuse and nxt is not None and (c3.cin, c3.cout, nxt.cout) in self.opt['fused_pointwise_lp']:
                 cur, t1 = self.pw_pair('b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1)), c3, nxt, t2, sc, n, h2,
                                        ACT_NONE if last else ACT_RELU, dtype)
             else:
@@ -721,43 +728,87 @@ def load_lp_tuning(path=None):
 
 
 LP_TUNING = load_lp_tuning()
-# (C_mid, C_out, C_next) of the conv3 -> next-conv1 pairs that run as ONE launch (csrc/pw_pair.hip) in the batched
-# low-precision backbone: the shapes where the fused kernel measured faster than the two launches at batch 64
-FUSED_POINTWISE = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
-# the same fusion in the fp32 frame (csrc/smallm_f32.hip, 16 pixels per workgroup): at batch 1 these 1x1 layers are
-# launch-bound (two launches 20-23 us, fused 6-14: scripts/pw_pair_f32_probe.py).  Not (128, 512, 256): layer3.0's conv1
-# already rides in the shortcut conv's launch.  Above MAX_M pixels the tiled conv kernels fill the chip and win.
-FUSED_POINTWISE_F32 = {(64, 256, 64), (64, 256, 128), (128, 512, 128)}
-FUSED_POINTWISE_F32_MAX_M = 4 * 3969
-# layer1: conv2 (3x3) joins the pair's launch (pw_triple_f32_kernel): 16.0 -> 10.9 us per bottleneck isolated, graph
-# replay 873.7 -> 863.2 us.  layer2's form (128 x 128 x 512 x 128; 61 workgroups) makes the frame slower (861 -> 881 us).
-FUSED_TRIPLE_F32 = os.environ.get('USOT_FUSED_TRIPLE_F32', '1') == '1'
-SPIN_SECONDS = float(os.environ.get('USOT_SPIN_SECONDS', '0.004'))
-FUSED_TRIPLE_F32_SHAPES = {tuple(int(v) for v in t.split('x')) for t in
-                           os.environ.get('USOT_FUSED_TRIPLE_F32_SHAPES', '64x64x256x64,64x64x256x128').split(',')}
-# the unfused 1x1 EXPANSION convolutions (conv3 of layer3's blocks and of layer2's last) on the small-M streaming kernel
-# up to this many pixels: graph replay 896.6 -> 878 us.  The 1024 -> 256 reductions gain nothing there (898 us with them
-# alone, 877-881 with everything): (Cin, Cout) pairs, overridable for experiments.
-STREAM_1X1 = os.environ.get('USOT_STREAM_1X1', '1') == '1'
-STREAM_1X1_MAX_M = 1200
-# conv2 (3x3, stride 1) on the streaming form when its pixel tiles x 4 channel slices fit one wave of workgroups (255-pixel
-# crops at batch 1: 61 tiles): (Cin, Cout) pairs.  layer2's (128 -> 128, K = 1152): 10.9 -> 7.4 us isolated, graph replay
-# 881.7 -> 875.0 us.  layer3's (256 -> 256, K = 2304) streams 144 MB of filters per layer from L2 - 20.3 -> 18.6 us isolated
-# but 878 -> 892 us in the frame - and stays on the tiled kernel.
-STREAM_3X3 = os.environ.get('USOT_STREAM_3X3', '1') == '1'
-STREAM_3X3_SHAPES = {tuple(int(v) for v in t.split('x')) for t in os.environ.get('USOT_STREAM_3X3_SHAPES', '128x128').split(',')}
-STREAM_1X1_SHAPES = {tuple(int(v) for v in t.split('x')) for t in os.environ.get('USOT_STREAM_1X1_SHAPES', '256x1024,128x512').split(',')}
-FUSED_POINTWISE_F32_SLICED = os.environ.get('USOT_FUSED_F32_SLICED', '0') == '1'
-# layer3's pairs (and conv3 + neck) exist in the channel-sliced form only (an unsliced 16 x 1024 Y tile does not fit) and
-# bought nothing inside the frame: 22-25 us per pair against 28 for the two launches in per-op spans, the graph replay
-# unchanged at 877 us (every pixel tile re-streams 2 MB of cold filters).  Kept for experiments with the switch above.
-FUSED_POINTWISE_F32_SLICED_ONLY = {(256, 1024, 256)}
+
+
+def _shapes(text):
+    return {tuple(int(v) for v in t.split('x')) for t in text.split(',') if t}
+
+
+# Every switch of the lowering in ONE place.  `OPTIONS` is what Builders read when a plan is built; an Engine takes
+# per-engine overrides (Engine(..., options={...}), or model.engine_options['options']).  The environment variables in
+# ENV_SWITCHES are read once, at import, for experiments from the shell; tests enumerate DEFAULT_OPTIONS
+# (tests/test_gpu_model.py::test_engine_option_variants_keep_parity).  Measurements behind the defaults: DESIGN.md §3.1.
+DEFAULT_OPTIONS = {
+    # (C_mid, C_out, C_next) of the conv3 -> next-conv1 pairs that run as ONE launch (csrc/pw_pair.hip) in the batched
+    # low-precision backbone: the shapes where the fused kernel measured faster than the two launches at batch 64
+    'fused_pointwise_lp': {(64, 256, 64), (64, 256, 128), (128, 512, 128)},
+    # the same fusion in the fp32 frame (csrc/smallm_f32.hip, 16 pixels per workgroup): at batch 1 these 1x1 layers are
+    # launch-bound (two launches 20-23 us, fused 6-14: scripts/pw_pair_f32_probe.py).  Not (128, 512, 256): layer3.0's
+    # conv1 already rides in the shortcut conv's launch.  Above max_m pixels the tiled conv kernels fill the chip and win.
+    'fused_pointwise_f32': {(64, 256, 64), (64, 256, 128), (128, 512, 128)},
+    'fused_pointwise_f32_max_m': 4 * 3969,
+    # layer1: conv2 (3x3) joins the pair's launch (pw_triple_f32_kernel): 16.0 -> 10.9 us per bottleneck isolated, graph
+    # replay 873.7 -> 863.2 us.  layer2's form (128 x 128 x 512 x 128; 61 workgroups) makes the frame slower (861 -> 881).
+    'fused_triple_f32': True,
+    'fused_triple_f32_shapes': {(64, 64, 256, 64), (64, 64, 256, 128)},
+    # the unfused 1x1 EXPANSION convolutions (conv3 of layer3's blocks and of layer2's last) on the small-M streaming
+    # kernel up to max_m pixels: graph replay 896.6 -> 878 us.  The 1024 -> 256 reductions gain nothing there (898 us with
+    # them alone, 877-881 with everything).  (Cin, Cout) pairs.
+    'stream_1x1': True,
+    'stream_1x1_max_m': 1200,
+    'stream_1x1_shapes': {(256, 1024), (128, 512)},
+    # conv2 (3x3, stride 1) on the streaming form when its pixel tiles x 4 channel slices fit one wave of workgroups
+    # (255-pixel crops at batch 1: 61 tiles).  layer2's (128 -> 128, K = 1152): 10.9 -> 7.4 us isolated, graph replay
+    # 881.7 -> 875.0 us.  layer3's (256 -> 256, K = 2304) streams 144 MB of filters per layer from L2 - 20.3 -> 18.6 us
+    # isolated but 878 -> 892 us in the frame - and stays on the tiled kernel.
+    'stream_3x3': True,
+    'stream_3x3_shapes': {(128, 128)},
+    # channel-sliced fused pairs (four workgroups per pixel tile, in-launch ticket combine): 13.6 -> 8.7 us per layer2
+    # pair, frame -9.5 us; with it layer3's pairs and conv3 + neck (which exist in the sliced form only: an unsliced
+    # 16 x 1024 Y tile does not fit) fuse too - 22-25 us per pair against 28 for two launches, graph replay unchanged.
+    'fused_f32_sliced': False,
+    'fused_pointwise_f32_sliced_only': {(256, 1024, 256)},
+    # Session.collect(): wall-clock budget of the result-tag spin before it falls back to 50 us sleeps
+    'spin_seconds': 0.004,
+}
+ENV_SWITCHES = {      # environment variable -> (option, parser)
+    'USOT_FUSED_TRIPLE_F32': ('fused_triple_f32', lambda v: v == '1'),
+    'USOT_FUSED_TRIPLE_F32_SHAPES': ('fused_triple_f32_shapes', _shapes),
+    'USOT_STREAM_1X1': ('stream_1x1', lambda v: v == '1'),
+    'USOT_STREAM_1X1_SHAPES': ('stream_1x1_shapes', _shapes),
+    'USOT_STREAM_3X3': ('stream_3x3', lambda v: v == '1'),
+    'USOT_STREAM_3X3_SHAPES': ('stream_3x3_shapes', _shapes),
+    'USOT_FUSED_F32_SLICED': ('fused_f32_sliced', lambda v: v == '1'),
+    'USOT_SPIN_SECONDS': ('spin_seconds', float),
+}
+
+
+def options_from_env(env=None):
+    env = os.environ if env is None else env
+    opt = {k: (set(v) if isinstance(v, set) else v) for k, v in DEFAULT_OPTIONS.items()}
+    for var, (key, parse) in ENV_SWITCHES.items():
+        if var in env:
+            opt[key] = parse(env[var])
+    return opt
+
+
+OPTIONS = options_from_env()
+
+
+def merged_options(overrides=None):
+    opt = {k: (set(v) if isinstance(v, set) else v) for k, v in OPTIONS.items()}
+    for k, v in (overrides or {}).items():
+        if k not in DEFAULT_OPTIONS:
+            raise hip.HipError('unknown engine option %r (known: %s)' % (k, ', '.join(sorted(DEFAULT_OPTIONS))))
+        opt[k] = v
+    return opt
 
 
 class Engine:
     """Per-model, per-device executor with cached plans.  Stateless w.r.t. tracking."""
 
-    def __init__(self, model, device, graphs=True, tuning=None, lanes=0):
+    def __init__(self, model, device, graphs=True, tuning=None, lanes=0, options=None):
+        self.opt = merged_options(options)          # engine.OPTIONS + per-engine overrides, fixed for this engine's plans
         if torch.device(device).type != 'cuda':
             raise hip.HipError('the USOT HIP engine needs a GPU device; got %s (no CPU fallback)' % (device,))
         hip.lib()
@@ -775,7 +826,7 @@ class Engine:
     def _feat_plan(self, n, size):
         key = (n, size)
         if key not in self._feat:
-            bld = Builder(self.W, self.tuning, self.lanes)
+            bld = Builder(self.W, self.tuning, self.lanes, self.opt)
             x = bld.buf(n, 3, size, size)
             xf, h = bld.backbone(x, n, size)
             self._finish(bld.plan)
@@ -806,7 +857,7 @@ class Engine:
         n, _, s, _ = x.shape
         key = ('bf16' if dtype == torch.bfloat16 else 'f16', n, s)
         if key not in self._feat:
-            bld = Builder(self.W, self.tuning, 0)
+            bld = Builder(self.W, self.tuning, 0, self.opt)
             xin = bld.buf(n, 3, s, s)
             xf, h = bld.backbone_bf16(xin, n, s, dtype=dtype)
             self._finish(bld.plan)
@@ -821,7 +872,7 @@ class Engine:
         """zf NCHW-shaped [n,256,7,7] (any strides) -> cached merged cls|reg kernel maps."""
         n = zf_nchw.shape[0]
         if n not in self._zenc:
-            bld = Builder(self.W, self.tuning, self.lanes)
+            bld = Builder(self.W, self.tuning, self.lanes, self.opt)
             zf = bld.buf(n, 7, 7, 256)
             zk = bld.encode_kernel(zf, n, 512, 'z')
             self._finish(bld.plan)
@@ -861,7 +912,7 @@ class Engine:
     def _track_plan(self, b, size, m):
         key = (b, size, m)
         if key not in self._track:
-            bld = Builder(self.W, self.tuning, self.lanes)
+            bld = Builder(self.W, self.tuning, self.lanes, self.opt)
             x = bld.buf(b, 3, size, size)
             mem = bld.buf(b * m, 7, 7, 256) if m else None
             mk = None
@@ -918,7 +969,7 @@ class Engine:
         m = int(score_mem.shape[1])
         key = ('mixed', b, size, m, dtype, bool(heads_lp))
         if key not in self._track:
-            bld = Builder(self.W, self.tuning, 0)
+            bld = Builder(self.W, self.tuning, 0, self.opt)
             xin = bld.buf(b, 3, size, size)
             mem = bld.buf(b * m, 7, 7, 256)
             if heads_lp:
@@ -994,7 +1045,7 @@ class Session:
 
     def _build(self):
         e, L = self.e, hip.lib()
-        bld = Builder(e.W, e.tuning, e.lanes)
+        bld = Builder(e.W, e.tuning, e.lanes, e.opt)
         pl = bld.plan
         nq = self.nq
         self.x = bld.buf(1, 3, self.size, self.size)
@@ -1052,7 +1103,7 @@ class Session:
 
     def _encode_rows(self, lo, hi):
         """Encode bank rows [lo, hi) into bank_enc (session start: init feature, its flip, memory 0)."""
-        bld = Builder(self.e.W, self.e.tuning, 0)
+        bld = Builder(self.e.W, self.e.tuning, 0, self.e.opt)
         src = bld.buf(hi - lo, 7, 7, 256)
         src.copy_(self.bank[lo:hi])
         enc = bld.encode_kernel(src, hi - lo, 256, 'mem')
@@ -1088,19 +1139,29 @@ class Session:
         self.bank, self.bank_enc, self.cap = bank, enc, self.cap * 2
         self._build()
 
-    def submit(self, x_crop, picks, tsz_scaled, resident=False):
+    def submit(self, x_crop, picks, tsz_scaled, resident=False, inplace=False):
         """Enqueue one frame on the CURRENT stream and return immediately (several sessions on
-        separate streams overlap on the GPU).  Pair with collect()."""
+        separate streams overlap on the GPU).  Pair with collect().
+
+        x_crop is SNAPSHOT by default: host crops go through the pinned staging buffer, device crops are copied
+        into the session's input buffer (any device, dtype or strides), so the caller may reuse its buffer as
+        soon as submit() returns — the double-buffer pattern.
+        inplace=True opts into zero-copy: a contiguous float32 crop on the session's device is read where it
+        lies (its address travels in the control block, no device copy).  LIFETIME CONTRACT: the tensor must stay
+        alive and UNCHANGED until collect() returns for this frame; the session holds a reference until then.
+        Anything that does not qualify (other device, dtype, strides) raises instead of silently copying.
+        resident=True: the crop is already in the session's own input buffer (frame_from_image)."""
         self._ensure_capacity()
         xaddr = 0                                   # 0: the frame reads the session's own input buffer
         if not resident:
-            if x_crop.is_cuda:
-                if x_crop.dtype == torch.float32 and x_crop.is_contiguous() and x_crop.numel() == self.x.numel():
-                    # a resident crop is read in place: its address travels in the control block (no device copy);
-                    # the caller's tensor must stay alive and unchanged until collect()
-                    xaddr, self._x_ref = x_crop.data_ptr(), x_crop
-                else:
-                    self.x.copy_(x_crop.reshape(self.x.shape))
+            if inplace:
+                if not (x_crop.is_cuda and x_crop.device == self.e.device and x_crop.dtype == torch.float32
+                        and x_crop.is_contiguous() and x_crop.numel() == self.x.numel()):
+                    raise hip.HipError('submit(inplace=True) needs a contiguous float32 crop of %d elements on %s; got %s %s %s'
+                                       % (self.x.numel(), self.e.device, x_crop.device, x_crop.dtype, tuple(x_crop.shape)))
+                xaddr, self._x_ref = x_crop.data_ptr(), x_crop
+            elif x_crop.is_cuda:
+                self.x.copy_(x_crop.reshape(self.x.shape))            # handles other devices / dtypes / strides
             else:
                 np.copyto(self._x_host_np, x_crop.numpy().reshape(self._x_host_np.shape))
                 self.x.copy_(self.x_host, non_blocking=True)
@@ -1124,7 +1185,7 @@ class Session:
         # spin for SPIN_SECONDS (several frame times), then give the core away between polls.  The budget is wall-clock: a
         # fixed 20 000 polls turned out to be 0.905 ms on this host (45 ns per numpy compare), i.e. it ran out right around
         # the end of a 0.86 ms frame and every such frame then paid a 50 us sleep and a launch onto an idle queue
-        spin_until = time.perf_counter() + SPIN_SECONDS
+        spin_until = time.perf_counter() + self.e.opt['spin_seconds']
         while True:
             for _ in range(512):
                 if out[8] == tag:
@@ -1143,6 +1204,7 @@ class Session:
                     raise hip.HipError('frame %r never published its result block (tag reads %r): '
                                        'the frame graph did not run to the decode kernel' % (tag, float(out[8])))
         self.n += 1
+        self._x_ref = None                          # an in-place crop may be reused from here on
         return out[:8].copy()
 
     def append_feature(self, feat):
@@ -1156,10 +1218,10 @@ class Session:
         self._encode_rows(row, row + 1)
         self.n += 1
 
-    def frame(self, x_crop, picks, tsz_scaled, resident=False):
+    def frame(self, x_crop, picks, tsz_scaled, resident=False, inplace=False):
         """Run one frame.  x_crop: CHW float tensor (host or device); picks: memory indices
-        of the N_q-2 sampled slots; tsz_scaled: target size * scale_z."""
-        self.submit(x_crop, picks, tsz_scaled, resident)
+        of the N_q-2 sampled slots; tsz_scaled: target size * scale_z; inplace as in submit()."""
+        self.submit(x_crop, picks, tsz_scaled, resident, inplace)
         return self.collect()
 
     def frame_from_image(self, im, pos, win, avg_chans, picks, tsz_scaled):

@@ -29,7 +29,7 @@ EXPORTS = (
     'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
     'PrRoIPoolingForwardGpu', 'usot_groupdw_auto_variant',
-    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single', 'usot_stream_conv3x3_f32', 'usot_stream_conv3x3_f32_supported', 'usot_plan_add_stream_conv3x3', 'usot_pw_triple_f32', 'usot_pw_triple_f32_supported', 'usot_plan_add_pw_triple',
+    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_stem_conv_mu_f32', 'usot_stem_pool_mu_f32', 'usot_plan_add_stem_pool_mu', 'usot_plan_add_stem_mu', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single', 'usot_stream_conv3x3_f32', 'usot_stream_conv3x3_f32_supported', 'usot_plan_add_stream_conv3x3', 'usot_pw_triple_f32', 'usot_pw_triple_f32_supported', 'usot_plan_add_pw_triple',
 )
 
 
@@ -104,6 +104,10 @@ def lib():
         L.usot_plan_add_stem_pool.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7
         L.usot_plan_add_stem_pool_ind.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]
         L.usot_stem_pool_ind_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]
+        L.usot_stem_pool_mu_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p] + [C.c_float] * 3
+        L.usot_plan_add_stem_pool_mu.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p] + [C.c_float] * 3
+        L.usot_plan_add_stem_mu.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float] * 3
+        L.usot_stem_conv_mu_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_float] * 3
         L.usot_plan_add_thin_conv.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_rows_copy_multi_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.usot_plan_add_rows_copy_multi.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -251,25 +255,28 @@ def conv2d(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, ac
     return y
 
 
-def stem_conv(x, w, bias):
+def stem_conv(x, w, bias, mu=(0.0, 0.0, 0.0)):
+    """mu: per-input-channel offsets subtracted from the crop while it is staged (bias must carry + sum(w) * mu)."""
     _dev(x), _dev(w), _dev(bias)
     N, c, H, W_ = x.shape
     assert c == 3 and x.is_contiguous()
     OH, OW = (H - 7) // 2 + 1, (W_ - 7) // 2 + 1
     y = torch.empty((N, OH, OW, 64), device=x.device, dtype=torch.float32)
-    check(lib().usot_stem_conv_f32(stream(), ptr(x), ptr(w), ptr(bias), ptr(y), N, H, W_, OH, OW), 'usot_stem_conv_f32')
+    check(lib().usot_stem_conv_mu_f32(stream(), ptr(x), ptr(w), ptr(bias), ptr(y), N, H, W_, OH, OW, *[float(v) for v in mu]),
+          'usot_stem_conv_mu_f32')
     return y
 
 
-def stem_pool(x, wfrag, bias):
-    """Fused fp32 stem + max-pool: x NCHW fp32 -> NHWC [N][PH][PW][64]; wfrag from engine.pack_stem_f32."""
+def stem_pool(x, wfrag, bias, mu=(0.0, 0.0, 0.0)):
+    """Fused fp32 stem + max-pool: x NCHW fp32 -> NHWC [N][PH][PW][64]; wfrag from engine.pack_stem_f32; mu as in stem_conv."""
     _dev(x), _dev(wfrag), _dev(bias)
     N, c, H, W_ = x.shape
     assert c == 3 and x.is_contiguous()
     OH, OW = (H - 7) // 2 + 1, (W_ - 7) // 2 + 1
     PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
     y = torch.empty((N, PH, PW, 64), device=x.device, dtype=torch.float32)
-    check(lib().usot_stem_pool_f32(stream(), ptr(x), ptr(wfrag), ptr(bias), ptr(y), N, H, W_, OH, OW, PH, PW), 'usot_stem_pool_f32')
+    check(lib().usot_stem_pool_mu_f32(stream(), ptr(x), ptr(wfrag), ptr(bias), ptr(y), N, H, W_, OH, OW, PH, PW, None,
+                                      *[float(v) for v in mu]), 'usot_stem_pool_mu_f32')
     return y
 
 

@@ -30,7 +30,8 @@ class USOT_(nn.Module):
         self.mem_size = mem_size
         self.pr_pool = pr_pool
         self._engine = None
-        self.engine_options = {'graphs': True, 'tuning': None, 'lanes': 0}
+        # Engine(...) keyword arguments; 'options' = per-engine overrides of usot_amd.engine.OPTIONS (the lowering's switches)
+        self.engine_options = {'graphs': True, 'tuning': None, 'lanes': 0, 'options': None}
         self.grids()
 
     # ------------------------------------------------------------------ engine lifetime
