@@ -127,6 +127,23 @@ int usot_pw_pair_layout(int CM, int CO, int CN, int which, int32_t *row, int32_t
 int usot_pw_pair_supported(int CM, int CO, int CN);
 int usot_plan_add_pw_pair(void *plan, const usot_pw_pair_desc *d, int dtype);   /* dtype 2: the fp32 form below */
 
+/* one pointwise EXPANSION convolution of the batched low-precision backbone, pixel-stationary (csrc/pw_panel.hip: the
+ * panel's X fragments in registers, W streamed through LDS once per 256 pixels, register epilogue in 32-byte pieces):
+ * y[M][N] = act(x[M][K] . w^T + bias (+ res)); x, w ([N][K], the conv kernels' layout), res, y in the storage type
+ * (dtype 0 = bf16, 1 = fp16), bias fp32 or NULL, res NULL or [M][N], act USOT_ACT_NONE | USOT_ACT_RELU.
+ * Replaces the 1x1 convs of modules.py:48-56,108-113 at batch 64.  Shapes: usot_pw_panel_supported(K, N). */
+int usot_pw_panel_lp(void *stream, const void *x, const void *w, const float *bias, const void *res, void *y,
+                     int M, int K, int N, int act, int dtype);
+int usot_pw_panel_supported(int K, int N);
+int usot_plan_add_pw_panel(void *plan, const void *x, const void *w, const float *bias, const void *res, void *y,
+                           int M, int K, int N, int act, int dtype);
+/* ... and the fused pair of usot_pw_pair_lp in that form: Y's sixteen channels per lane, rounded, are the B fragments of
+ * the second GEMM (no LDS image of Y, no re-read from HBM).  Descriptor as for usot_pw_pair_lp EXCEPT that both banks
+ * are in the conv kernels' natural layout: d->w3p = w3 [CO][CM], d->w1 = w1 [CN][CO]. */
+int usot_pw_panel_pair_lp(void *stream, const usot_pw_pair_desc *d, int dtype);
+int usot_pw_panel_pair_supported(int CM, int CO, int CN);
+int usot_plan_add_pw_panel_pair(void *plan, const usot_pw_pair_desc *d, int dtype);
+
 /* the same pair in fp32 for the batch-1 frame (csrc/smallm_f32.hip; v_mfma_f32_16x16x4_f32, 16 pixels per workgroup):
  * every pointer of the descriptor is float32.  w3p / w1 in fragment order: the float at
  * [((cb * (K / 16) + r) * 64 + lane) * 4 + c] is W[cb * 16 + (lane & 15)][16 * r + 4 * (lane >> 4) + c]

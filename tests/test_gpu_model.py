@@ -213,7 +213,7 @@ def test_every_fixture_within_1p5x_of_the_references_own_float32_error(family, c
 
 
 # every switch of usot_amd.engine.DEFAULT_OPTIONS that changes which kernels a frame uses, flipped away from its default
-OPTION_VARIANTS = [{'fused_f32_sliced': True}, {'fused_triple_f32': False}, {'stream_1x1': False}, {'stream_3x3': False},
+OPTION_VARIANTS = [{'fused_f32_sliced': False}, {'fused_triple_f32': False}, {'stream_1x1': False}, {'stream_3x3': False},
                    {'fused_pointwise_f32': set()},
                    {'stream_3x3_shapes': {(128, 128), (256, 256)}}, {'stream_1x1_shapes': {(256, 1024), (128, 512), (1024, 256), (512, 128)}}]
 

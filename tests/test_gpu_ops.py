@@ -882,3 +882,83 @@ def test_stem_pool_f32(size, n):
     bmu = (b.double() + (w.double() * torch.tensor(mu, dtype=torch.float64).view(1, 3, 1, 1)).sum((1, 2, 3))).float()
     gmu = hip.stem_pool(x.to(DEV), pack_stem_f32(packed).to(DEV), bmu.to(DEV), mu).cpu()
     assert rel_err(gmu.numpy(), ref.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('K,N,M,res,act', [(256, 1024, 256 * 3, True, 1), (256, 1024, 1000, True, 1), (256, 1024, 77, False, 0),
+                                           (128, 512, 256 * 2 + 5, True, 1), (64, 256, 512 * 2 + 130, False, 0), (64, 256, 512, True, 1)])
+def test_pw_panel_lp_expansion_conv(K, N, M, res, act, dtype):
+    """Pixel-stationary 1x1 expansion conv (csrc/pw_panel.hip) vs the SAME rounded operands in float64: full and ragged panels
+    (M not a multiple of the panel, fewer pixels than one wave's block), with / without residual and ReLU; and bit-equal to the
+    tiled low-precision conv kernel's result (same products, fp32 accumulation in the same k order, one rounding)."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(K + N + M)
+    x = (torch.randn(M, K, generator=g)).to(dtype)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype)
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g).to(dtype) if res else None
+    ref = x.double() @ w.double().t() + b.double()
+    if res:
+        ref = ref + r.double()
+    if act:
+        ref = ref.relu()
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    rd = r.to(DEV) if res else None
+    y = torch.full((M + 3, N), 7.0, dtype=dtype, device=DEV)         # three guard rows behind the output
+    assert hip.lib().usot_pw_panel_supported(K, N) == 1 and hip.lib().usot_pw_panel_supported(K, N + 64) == 0
+    hip.check(hip.lib().usot_pw_panel_lp(hip.stream(), hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), hip.ptr(rd) if res else None, hip.ptr(y),
+                                         M, K, N, act, 1 if dtype == torch.float16 else 0), 'usot_pw_panel_lp')
+    got = y[:M].float().cpu().double()
+    assert torch.all(y[M:] == 7.0)                                   # nothing written past the last pixel
+    tol = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11           # one rounding of the output
+    assert float(((got - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= tol * 1.01
+    # the tiled kernel on the same operands (NHWC with H = M, W = 1)
+    y2 = torch.empty(M, N, dtype=dtype, device=DEV)
+    d = hip.conv_desc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y2.data_ptr(), N=1, H=M, W=1, Cin=K, OH=M, OW=1, Cout=N, KH=1, KW=1,
+                      res=rd.data_ptr() if res else None, act=act, tile=10)
+    hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d), 1 if dtype == torch.float16 else 0, 0), 'usot_conv2d_lp')
+    assert torch.equal(y2, y[:M])
+    assert hip.lib().usot_pw_panel_lp(hip.stream(), hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), None, hip.ptr(y), M, K, N + 64, act, 0) != 0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('cm,co,cn,M,act2', [(128, 512, 128, 256 * 4 + 17, 1), (128, 512, 128, 61, 0), (128, 512, 128, 256 * 2 + 17, 1),
+                                             (128, 512, 256, 128 + 9, 1), (64, 256, 64, 256 * 3, 1), (64, 256, 128, 256 + 200, 1)])
+def test_pw_panel_pair_equals_the_two_convolutions(cm, co, cn, M, act2, dtype):
+    """Pair form of the panel kernel (Y's accumulators feed the second GEMM from registers) vs the two tiled launches on the
+    same operands: Y bit-identical (same products, same k order, one rounding); T within 2 ulp of the storage type (the
+    second GEMM visits k in (group, quad, half) order: same products, another fp32 summation order)."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(cm + co + cn + M)
+    t2 = torch.randn(M, cm, generator=g).to(dtype)
+    w3 = (torch.randn(co, cm, generator=g) / cm ** 0.5).to(dtype)
+    w1 = (torch.randn(cn, co, generator=g) / co ** 0.5).to(dtype)
+    b3, b1 = torch.randn(co, generator=g) * 0.1, torch.randn(cn, generator=g) * 0.1
+    res = torch.randn(M, co, generator=g).to(dtype)
+    dt = 1 if dtype == torch.float16 else 0
+    dev = lambda a: a.to(DEV)
+    t2d, w3d, w1d, b3d, b1d, resd = map(dev, (t2, w3, w1, b3, b1, res))
+    y = torch.full((M + 2, co), 3.0, dtype=dtype, device=DEV)
+    t = torch.full((M + 2, cn), 3.0, dtype=dtype, device=DEV)
+    d = hip.pw_pair_desc(t2d.data_ptr(), w3d.data_ptr(), b3d.data_ptr(), resd.data_ptr(), y.data_ptr(), w1d.data_ptr(), b1d.data_ptr(),
+                         t.data_ptr(), M, cm, co, cn, act2)
+    assert hip.lib().usot_pw_panel_pair_supported(cm, co, cn) == 1
+    hip.check(hip.lib().usot_pw_panel_pair_lp(hip.stream(), C.byref(d), dt), 'usot_pw_panel_pair_lp')
+    assert torch.all(y[M:] == 3.0) and torch.all(t[M:] == 3.0)
+    y2 = torch.empty(M, co, dtype=dtype, device=DEV)
+    d1 = hip.conv_desc(t2d.data_ptr(), w3d.data_ptr(), b3d.data_ptr(), y2.data_ptr(), N=1, H=M, W=1, Cin=cm, OH=M, OW=1, Cout=co, KH=1, KW=1,
+                       res=resd.data_ptr(), act=1, tile=10)
+    hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d1), dt, 0), 'conv3')
+    tt = torch.empty(M, cn, dtype=dtype, device=DEV)
+    d2 = hip.conv_desc(y2.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), tt.data_ptr(), N=1, H=M, W=1, Cin=co, OH=M, OW=1, Cout=cn, KH=1, KW=1,
+                       act=act2, tile=10)
+    hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d2), dt, 0), 'conv1')
+    assert torch.equal(y[:M], y2)
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    a, b = t[:M].float(), tt.float()
+    assert float(((a - b).abs() / b.abs().clamp_min(0.25)).max()) <= 2 * ulp
+    ref = (y2.double() @ w1d.double().t() + b1d.double())
+    if act2:
+        ref = ref.relu()
+    assert float(((a.double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= ulp
+    assert hip.lib().usot_pw_panel_pair_supported(cm, co, cn + 32) == 0

@@ -1,6 +1,7 @@
 // Shared helpers for the libusot_hip translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 #define USOT_CHECK_LAUNCH()                                   \
     do {                                                      \
@@ -47,3 +48,16 @@ struct BlockTotal {
     __device__ __forceinline__ usot_f32x4 get() const { return s; }
 #endif
 };
+
+// two floats -> one dword of the low-precision storage type (low half = a), round to nearest even: ONE v_cvt_pk_bf16_f32 on
+// gfx950 (the shift / add / mask form of the same rounding is ~10 VALU instructions per pair; the epilogues of the HBM-bound
+// 1x1 layers spend a third of their time there), v_cvt_f16_f32 x 2 + v_pack_b32_f16 for fp16
+typedef float usot_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 usot_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 usot_f16x2 __attribute__((ext_vector_type(2)));
+template <bool F16> __device__ __forceinline__ uint32_t usot_pack2_lp(float a, float b)
+{
+    const usot_f32x2 v = {a, b};
+    if constexpr (F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, usot_f16x2));
+    else               return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, usot_bf16x2));
+}

@@ -46,11 +46,9 @@ __device__ __forceinline__ int xcd_remap_b(int b, int total)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-__device__ __forceinline__ uint32_t f2bf(float f)          // round to nearest even
+__device__ __forceinline__ uint32_t f2bf(float f)          // round to nearest even (v_cvt_pk_bf16_f32)
 {
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
 }
 __device__ __forceinline__ float bf2f(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
 __device__ __forceinline__ uint32_t f2h(float f) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f); }
@@ -482,10 +480,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
                         for (int e = 0; e < 4; ++e) { v0[e] = act_lp(v0[e], av); v1[e] = act_lp(v1[e], av); }
                     }
                     u32x4 o;
-                    o[0] = pack_lp<F16>(v0[0]) | (pack_lp<F16>(v0[1]) << 16);
-                    o[1] = pack_lp<F16>(v0[2]) | (pack_lp<F16>(v0[3]) << 16);
-                    o[2] = pack_lp<F16>(v1[0]) | (pack_lp<F16>(v1[1]) << 16);
-                    o[3] = pack_lp<F16>(v1[2]) | (pack_lp<F16>(v1[3]) << 16);
+                    o[0] = usot_pack2_lp<F16>(v0[0], v0[1]);
+                    o[1] = usot_pack2_lp<F16>(v0[2], v0[3]);
+                    o[2] = usot_pack2_lp<F16>(v1[0], v1[1]);
+                    o[3] = usot_pack2_lp<F16>(v1[2], v1[3]);
 #ifdef USOT_LPABL_NOSTORE
                     if (o[0] == 0x12345678u)           // keeps the value live, never true in practice
 #endif
@@ -515,8 +513,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
             *(f32x4 *)((float *)p.y + (long)m * p.Cout + co) = v;
         } else {
             u32x2 o;
-            o[0] = pack_lp<F16>(v[0]) | (pack_lp<F16>(v[1]) << 16);
-            o[1] = pack_lp<F16>(v[2]) | (pack_lp<F16>(v[3]) << 16);
+            o[0] = usot_pack2_lp<F16>(v[0], v[1]);
+            o[1] = usot_pack2_lp<F16>(v[2], v[3]);
             *(u32x2 *)(p.y + (long)m * p.Cout + co) = o;
         }
     });
@@ -574,8 +572,8 @@ __global__ __launch_bounds__(256) void cvt_f32_bf16_kernel(const float *__restri
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
         const f32x4 a = ((const f32x4 *)src)[2 * i], b = ((const f32x4 *)src)[2 * i + 1];
         u32x4 o;
-        o[0] = pack_lp<F16>(a[0]) | (pack_lp<F16>(a[1]) << 16); o[1] = pack_lp<F16>(a[2]) | (pack_lp<F16>(a[3]) << 16);
-        o[2] = pack_lp<F16>(b[0]) | (pack_lp<F16>(b[1]) << 16); o[3] = pack_lp<F16>(b[2]) | (pack_lp<F16>(b[3]) << 16);
+        o[0] = usot_pack2_lp<F16>(a[0], a[1]); o[1] = usot_pack2_lp<F16>(a[2], a[3]);
+        o[2] = usot_pack2_lp<F16>(b[0], b[1]); o[3] = usot_pack2_lp<F16>(b[2], b[3]);
         ((u32x4 *)dst)[i] = o;
     }
 }
@@ -613,7 +611,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bf16_kernel(
         }
         u32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = pack_lp<F16>(m[2 * e]) | (pack_lp<F16>(m[2 * e + 1]) << 16);
+        for (int e = 0; e < 4; ++e) o[e] = usot_pack2_lp<F16>(m[2 * e], m[2 * e + 1]);
         ((u32x4 *)y)[idx] = o;
     }
 }
@@ -741,8 +739,8 @@ __global__ __launch_bounds__(256) void stem_pool_lp_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             u32x2 o;
-            o[0] = pack_lp<F16>(v[0]) | (pack_lp<F16>(v[1]) << 16);
-            o[1] = pack_lp<F16>(v[2]) | (pack_lp<F16>(v[3]) << 16);
+            o[0] = usot_pack2_lp<F16>(v[0], v[1]);
+            o[1] = usot_pack2_lp<F16>(v[2], v[3]);
             *(u32x2 *)(stile + (blk * 16 + l15) * SP_OPB + (cb * 16 + quad * 4) * 2) = o;
         }
     }
@@ -774,7 +772,7 @@ __global__ __launch_bounds__(256) void stem_pool_lp_kernel(
     }
     u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack_lp<F16>(m[2 * e]) | (pack_lp<F16>(m[2 * e + 1]) << 16);
+    for (int e = 0; e < 4; ++e) o[e] = usot_pack2_lp<F16>(m[2 * e], m[2 * e + 1]);
     *(u32x4 *)(y + ((((long)n * PH + py) * PW + px) * 64 + c8 * 8)) = o;
 }
 

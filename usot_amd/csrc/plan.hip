@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3, K_PW3 };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3, K_PW3, K_PANEL, K_PANELP };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -105,6 +105,11 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
                                      op.f[0], op.d[0], op.d[1], (const double *)op.p[5], (float *)op.l[0]);
             break;
         case K_CONVB: rc = usot_conv2d_lp(s, &op.conv, op.i[6], op.i[7]); break;
+        case K_PANEL:
+            rc = usot_pw_panel_lp(s, op.p[0], op.p[1], (const float *)op.p[2], op.p[3], (void *)op.p[4], op.i[0], op.i[1], op.i[2],
+                                  op.i[3], op.i[6]);
+            break;
+        case K_PANELP: rc = usot_pw_panel_pair_lp(s, &op.pw, op.i[6]); break;
         case K_PWPAIR: rc = op.i[6] == 2 ? usot_pw_pair_f32(s, &op.pw) : usot_pw_pair_lp(s, &op.pw, op.i[6]); break;
         case K_PW3:
             rc = usot_pw_triple_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], &op.pw,
@@ -269,6 +274,27 @@ extern "C" int usot_plan_add_pw_single(void *plan, const float *x, const float *
     if (!op) return USOT_ESTATE;
     op->p[0] = x; op->p[1] = wp; op->p[2] = b; op->p[3] = res; op->p[4] = y;
     op->i[0] = M; op->i[1] = K; op->i[2] = N; op->i[3] = act;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_pw_panel_pair(void *plan, const usot_pw_pair_desc *d, int dtype)
+{
+    if (!d || !usot_pw_panel_pair_supported(d->CM, d->CO, d->CN) || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
+    Op *op = push(plan, K_PANELP);
+    if (!op) return USOT_ESTATE;
+    op->pw = *d;
+    op->i[6] = dtype;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_pw_panel(void *plan, const void *x, const void *w, const float *bias, const void *res, void *y,
+                                      int M, int K, int N, int act, int dtype)
+{
+    if (!usot_pw_panel_supported(K, N)) return USOT_EINVAL;
+    Op *op = push(plan, K_PANEL);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = x; op->p[1] = w; op->p[2] = bias; op->p[3] = res; op->p[4] = y;
+    op->i[0] = M; op->i[1] = K; op->i[2] = N; op->i[3] = act; op->i[6] = dtype;
     return USOT_OK;
 }
 

@@ -47,9 +47,7 @@ struct PwK {
 
 __device__ __forceinline__ uint32_t pw_f2bf(float f)
 {
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
 }
 template <bool F16> __device__ __forceinline__ uint32_t pw_pack(float f)
 {
@@ -281,8 +279,8 @@ __global__ __launch_bounds__(512) void pw_pair_kernel(const PwK p)
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
                     }
                     u32x2 o;
-                    o[0] = pw_pack<F16>(v[0]) | (pw_pack<F16>(v[1]) << 16);
-                    o[1] = pw_pack<F16>(v[2]) | (pw_pack<F16>(v[3]) << 16);
+                    o[0] = usot_pack2_lp<F16>(v[0], v[1]);
+                    o[1] = usot_pack2_lp<F16>(v[2], v[3]);
                     *(u32x2 *)(p.t + m * CN + n0) = o;
                 }
             }

@@ -417,6 +417,15 @@ class Builder:
                 self.buf(n, oh, ow, cout, dtype=torch.float32 if out_f32 else dtype)
         wb = pc.w_lp(dtype)
         k = pc.kh * pc.kw * pc.cin
+        if (tile == 0 and pc.kh == 1 and pc.kw == 1 and pc.stride == 1 and groups == 1 and not out_f32 and cout == pc.cout
+                and act in (ACT_NONE, ACT_RELU) and act_split == 0 and (k, cout) in self.opt['panel_1x1_lp']
+                and n * oh * ow >= self.opt['panel_1x1_lp_min_m'] and hip.lib().usot_pw_panel_supported(k, cout)):
+            hip.check(hip.lib().usot_plan_add_pw_panel(self.plan.h, hip.ptr(x), hip.ptr(wb), hip.ptr(pc.b),
+                                                       hip.ptr(res) if res is not None else None, hip.ptr(y), n * oh * ow, k, cout,
+                                                       act, 1 if dtype == torch.float16 else 0), 'plan_add_pw_panel ' + name)
+            self.plan.keep += [x, wb, pc.b, res]
+            self.log.append((name, n * oh * ow, cout, k, 1, n * oh * ow * cout * k))
+            return y, oh, ow
         if tile == 0:
             tile = LP_TUNING.get((n * oh * ow, cout, k), 0)
         if hasattr(self, 'lp_geoms'):       # scripts/tune_lp.py collects the shapes this way
@@ -446,6 +455,20 @@ class Builder:
         hip.check(hip.lib().usot_plan_add_pw_pair(self.plan.h, C.byref(d), 1 if dtype == torch.float16 else 0),
                   'plan_add_pw_pair ' + name)
         self.plan.keep += [t2, res, w3p, w1, c3.b, nxt.b]
+        self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
+        return y, t
+
+    def pw_panel_pair(self, name, c3, nxt, t2, res, n, h, act2, dtype):
+        """The same pair on the pixel-stationary kernel (csrc/pw_panel.hip: pair form; natural-layout filter banks)."""
+        m = n * h * h
+        y = self.buf(n, h, h, c3.cout, dtype=dtype)
+        t = self.buf(n, h, h, nxt.cout, dtype=dtype)
+        w3, w1 = c3.w_lp(dtype), nxt.w_lp(dtype)
+        d = hip.pw_pair_desc(t2.data_ptr(), w3.data_ptr(), c3.b.data_ptr(), res.data_ptr(), y.data_ptr(), w1.data_ptr(),
+                             nxt.b.data_ptr(), t.data_ptr(), m, c3.cin, c3.cout, nxt.cout, act2)
+        hip.check(hip.lib().usot_plan_add_pw_panel_pair(self.plan.h, C.byref(d), 1 if dtype == torch.float16 else 0),
+                  'plan_add_pw_panel_pair ' + name)
+        self.plan.keep += [t2, res, w3, w1, c3.b, nxt.b]
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
         return y, t
 
@@ -592,7 +615,12 @@ class Builder:
             # neck after the last block): the 4x-wide map is written once and not read back
             last = bi + 1 == nb
             nxt = (W.neck if not neck_f32 else None) if last else W.blocks[bi + 1][0]
-            if fuse and nxt is not None and (c3.cin, c3.cout, nxt.cout) in self.opt['fused_pointwise_lp']:
+            nm = 'b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1))
+            if (fuse and nxt is not None and nxt.kh == 1 and (c3.cin, c3.cout, nxt.cout) in self.opt['panel_pair_lp']
+                    and n * h2 * h2 >= self.opt['panel_1x1_lp_min_m']
+                    and hip.lib().usot_pw_panel_pair_supported(c3.cin, c3.cout, nxt.cout)):
+                cur, t1 = self.pw_panel_pair(nm, c3, nxt, t2, sc, n, h2, ACT_NONE if last else ACT_RELU, dtype)
+            elif fuse and nxt is not None and (c3.cin, c3.cout, nxt.cout) in self.opt['fused_pointwise_lp']:
                 cur, t1 = self.pw_pair('b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1)), c3, nxt, t2, sc, n, h2,
                                        ACT_NONE if last else ACT_RELU, dtype)
             else:
@@ -742,6 +770,15 @@ DEFAULT_OPTIONS = {
     # (C_mid, C_out, C_next) of the conv3 -> next-conv1 pairs that run as ONE launch (csrc/pw_pair.hip) in the batched
     # low-precision backbone: the shapes where the fused kernel measured faster than the two launches at batch 64
     'fused_pointwise_lp': {(64, 256, 64), (64, 256, 128), (128, 512, 128)},
+    # (K, N) of the unfused 1x1 EXPANSION convolutions of the low-precision backbone that run on the pixel-stationary
+    # panel kernel (csrc/pw_panel.hip) from panel_1x1_lp_min_m pixels up: layer3's conv3 89 -> ?? us at batch 64
+    'panel_1x1_lp': {(256, 1024), (128, 512), (64, 256)},
+    'panel_1x1_lp_min_m': 16384,
+    # (C_mid, C_out, C_next) of the conv3 -> next-1x1 pairs of the low-precision backbone that run as ONE launch of the
+    # panel kernel's pair form (Y's accumulators feed the second GEMM from registers); takes precedence over
+    # fused_pointwise_lp (csrc/pw_pair.hip: 64-pixel tiles with an LDS image of Y)
+    # (not layer3's (256, 1024, 256): csrc/pw_panel.hip, usot_pw_panel_pair_supported)
+    'panel_pair_lp': {(64, 256, 64), (64, 256, 128), (128, 512, 128), (128, 512, 256)},
     # the same fusion in the fp32 frame (csrc/smallm_f32.hip, 16 pixels per workgroup): at batch 1 these 1x1 layers are
     # launch-bound (two launches 20-23 us, fused 6-14: scripts/pw_pair_f32_probe.py).  Not (128, 512, 256): layer3.0's
     # conv1 already rides in the shortcut conv's launch.  Above max_m pixels the tiled conv kernels fill the chip and win.
@@ -764,9 +801,11 @@ DEFAULT_OPTIONS = {
     'stream_3x3': True,
     'stream_3x3_shapes': {(128, 128)},
     # channel-sliced fused pairs (four workgroups per pixel tile, in-launch ticket combine): 13.6 -> 8.7 us per layer2
-    # pair, frame -9.5 us; with it layer3's pairs and conv3 + neck (which exist in the sliced form only: an unsliced
-    # 16 x 1024 Y tile does not fit) fuse too - 22-25 us per pair against 28 for two launches, graph replay unchanged.
-    'fused_f32_sliced': False,
+    # pair; with it layer3's pairs and conv3 + neck (which exist in the sliced form only: an unsliced 16 x 1024 Y tile
+    # does not fit) fuse too.  Round 2 shipped it OFF: its re-associated second GEMM put one golden output at 1.011e-4 of
+    # the 1e-4 bar.  With blocked accumulation + the offset stem every output sits at <= 5e-5 and the variant passes the
+    # float64 acceptance rule (tests/golden/f64_gate.py) on both weight families: ON, graph replay 880.5 -> 855.7 us.
+    'fused_f32_sliced': True,
     'fused_pointwise_f32_sliced_only': {(256, 1024, 256)},
     # Session.collect(): wall-clock budget of the result-tag spin before it falls back to 50 us sleeps
     'spin_seconds': 0.004,
