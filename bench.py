@@ -180,9 +180,36 @@ def xcorr_bandwidth(device, sizes=(2048, 128), iters=20):
                      'achieved': round(samples * GROUPDW_BYTES_PER_SAMPLE / (ms * 1e-3) / 1e9, 1)})
         del xs, zs
     top = rows[0]
+    probe = hbm_ceiling_probe(device)
     return {'bound': 'hbm', 'kernel': top['kernel'], 'samples': top['samples'], 'ms': top['ms'],
             'achieved': top['achieved'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(top['achieved'] / HBM_PEAK_GBPS, 4),
+            'ceiling_probe': probe, 'frac_of_measured_ceiling': round(top['achieved'] / probe['mix_4r_1w'], 4),
             'algorithmic_bytes': top['bytes'], **xcorr_traffic(top['kernel'], top['samples']), 'by_samples': rows}
+
+
+def hbm_ceiling_probe(device, gib=2, iters=10):
+    """What THIS box's HBM delivers (csrc/bw_probe.hip, 16 bytes per lane, far beyond the 256 MiB Infinity Cache): read-only,
+    copy, and GroupDW's byte mix — 4 bytes read per byte written, one interleaved read stream, non-temporal stores.  GB/s of
+    bytes moved (read + written)."""
+    n = gib << 30
+    src = torch.empty(n // 4, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty(n // 4, dtype=torch.float32, device=device)
+    out = {}
+    for name, mode, moved in (('read', 0, n), ('copy', 1, 2 * n), ('mix_4r_1w', 2, n + n // 4)):
+        run = lambda: hip.check(hip.lib().usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, mode), 'usot_bw_probe')
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = round(moved / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9, 1)
+    out['unit'] = 'GB/s'
+    out['what'] = '%d GiB buffers, 16 B per lane; mix_4r_1w = GroupDW byte mix (one interleaved read stream, non-temporal stores)' % gib
+    return out
 
 
 def xcorr_traffic(kernel, samples):
@@ -236,35 +263,57 @@ def host_threads(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(budget_s=12.0):
-    """The oracle's restatement of one tracked frame (models.py:179-198 + PrPool) on the host."""
+def cpu_model():
+    """CPU model string of the host (SURVEY §8d asks for it beside the core count)."""
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.lower().startswith('model name'):
+                    return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or 'unknown'
+
+
+def cpu_baseline(budget_s=14.0):
+    """The oracle's restatement of one tracked frame (models.py:179-198 + PrPool) on the host, at k = all the cores this
+    process may use (the headline `value` / `cores`) and at k = 1 (`single_thread`): SURVEY §8(d)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import usot_oracle as orc
     m = USOT()
     sd = synth.torch_state_dict(m, seed=0, calibrated=True)
     t = torch.from_numpy
     z, x = t(synth.crop(1000, 1, 127)), t(synth.crop(2000, 1, 255))
+
+    def timed(threads, budget, cap):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            zf = orc.template(sd, z, torch.tensor([[3.5, 3.5, 10.5, 10.5]]), pr_pool=True)
+            mem = torch.cat([zf] * 7, 0)
+            frame = lambda: orc.prpool_feature(orc.track(sd, x, zf, mem, torch.ones(1, 7))[3], torch.tensor([[9.0, 9.0, 16.0, 16.0]]))
+            t0 = time.perf_counter()
+            frame()                                   # warm-up (also guards the time budget)
+            if time.perf_counter() - t0 < budget / 4:
+                frame()
+            n, t0 = 0, time.perf_counter()
+            while True:
+                frame()
+                n += 1
+                dt = time.perf_counter() - t0
+                if dt > budget or n >= cap:
+                    break
+        return n, dt, torch.get_num_threads()
     cores = host_threads()
+    n, dt, used = timed(cores, budget_s * 0.55, 200)
+    n1, dt1, _ = timed(1, budget_s * 0.45, 12)
     torch.set_num_threads(cores)
-    with torch.no_grad():
-        zf = orc.template(sd, z, torch.tensor([[3.5, 3.5, 10.5, 10.5]]), pr_pool=True)
-        mem = torch.cat([zf] * 7, 0)
-        frame = lambda: orc.prpool_feature(orc.track(sd, x, zf, mem, torch.ones(1, 7))[3], torch.tensor([[9.0, 9.0, 16.0, 16.0]]))
-        t0 = time.perf_counter()
-        frame()                                   # warm-up (also guards the time budget)
-        if time.perf_counter() - t0 < budget_s / 4:
-            frame()
-        n, t0 = 0, time.perf_counter()
-        while True:
-            frame()
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt > budget_s or n >= 200:
-                break
-    return {'value': round(n / dt, 3), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d frames of the same workload (1 crop 255x255, N_q=7, fp32) in %.1f s: the torch-CPU oracle '
-                      'restatement under no_grad with the duplicate search-side encodes of connect.py:251-264 computed '
-                      'once (the reference runs them three times), i.e. a faster CPU path than the literal reference' % (n, dt)}
+    what = ('the torch-CPU oracle restatement under no_grad with the duplicate search-side encodes of connect.py:251-264 '
+            'computed once (the reference runs them three times), i.e. a faster CPU path than the literal reference')
+    return {'value': round(n / dt, 3), 'unit': 'frames/s', 'cores': used, 'kind': 'port', 'cpu_model': cpu_model(),
+            'sample': '%d frames of the same workload (1 crop 255x255, N_q=7, fp32) in %.1f s: %s' % (n, dt, what),
+            'single_thread': {'value': round(n1 / dt1, 3), 'unit': 'frames/s', 'cores': 1,
+                              'sample': '%d frames in %.1f s, torch.set_num_threads(1)' % (n1, dt1)}}
 
 
 BF16_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF is 2:1 sparse)
@@ -309,13 +358,29 @@ def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, 
             fl_conv += 2.0 * macs
             rows.append((ms, name, M, N, K, 2.0 * macs / ms / 1e9))
     ach = fl_conv / (ms_conv * 1e-3) / 1e12
+    # algorithmic HBM bytes of the step: every conv launch's operands and result once (engine.Builder.lp_bytes) + the stem's
+    # fp32 crops in and pooled map out; measured traffic from the committed PMC passes (scripts/pmc_lp_traffic.py)
+    ph = ((size - 7) // 2 + 1 - 1) // 2 + 1
+    alg_bytes = sum(p.get('lp_bytes', [])) + batch * (3 * size * size * 4 + ph * ph * 64 * 2)
+    traffic, tsrc, by_kernel = None, None, None
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic_bf16.json')
+    if batch == 64 and size == 255 and os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = tj.get('hbm_bytes_per_step')
+        tsrc = 'profiles/pmc_traffic_bf16.json@%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, summed over the step)' % tj['_meta'].get('commit', '?')
+        by_kernel = {k: v['hbm_bytes_per_launch'] for k, v in sorted(tj.get('by_kernel', {}).items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches_per_step'])[:6]}
     return {
         'workload': 'configs[2]: batch=%d search crops %dx%d bf16, backbone + neck convs on v_mfma_f32_16x16x32_bf16, '
                     'fp32 accumulate, one hipGraph' % (batch, size, size),
         'value': round(batch * n / dt, 1), 'unit': 'crops/s', 'steps': n, 'ms_per_step': round(dt / n * 1e3, 3),
         'roofline': {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(ach / BF16_PEAK_TFLOPS, 4), 'traffic': None,
-                     'kernel': 'conv_igemm_bf16 family (all %d conv launches)' % len(rows),
+                     'frac': round(ach / BF16_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': tsrc,
+                     'algorithmic_bytes_per_step': int(alg_bytes),
+                     'traffic_to_algorithmic': round(traffic / alg_bytes, 3) if traffic else None,
+                     'hbm_gbs_at_algorithmic_bytes': round(alg_bytes / (dt / n) / 1e9, 1),
+                     'traffic_per_launch_top_kernels': by_kernel,
+                     'kernel': 'conv_igemm_bf16 / pw_panel family (all %d conv launches)' % len(rows),
                      'algorithmic_gflop_per_step': round(fl_conv / 1e9, 1), 'conv_ms_per_step': round(ms_conv, 3),
                      'all_ops_ms_per_step': round(ms_all, 3),
                      'end_to_end_tflops': round(batch * (BACKBONE_GFLOP + 0.504) * n / dt / 1e3, 1),

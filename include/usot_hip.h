@@ -34,6 +34,9 @@ extern "C" {
 #define USOT_ACT_CONF      3   /* exp(min(max(x,0),4))    connect.py:128-131 (ReLU then clamp) */
 
 int usot_abi_version(void);
+/* HBM ceiling probe of the box (csrc/bw_probe.hip): mode 0 read `bytes`, 1 copy `bytes`, 2 read `bytes` + write bytes / 4
+ * (GroupDW's byte mix, one interleaved read stream, non-temporal stores).  bytes % 4096 == 0. */
+int usot_bw_probe(void *stream, const void *src, void *dst, int64_t bytes, int mode);
 const char *usot_strerror(int code);
 
 /* ---- convolution as implicit GEMM on fp32 MFMA (v_mfma_f32_16x16x4_f32) -------------
@@ -135,6 +138,7 @@ int usot_plan_add_pw_pair(void *plan, const usot_pw_pair_desc *d, int dtype);   
 int usot_pw_panel_lp(void *stream, const void *x, const void *w, const float *bias, const void *res, void *y,
                      int M, int K, int N, int act, int dtype);
 int usot_pw_panel_supported(int K, int N);
+int usot_pw_panel_pixels(int CM, int CO, int CN);      /* pixels per panel = per workgroup (CN = 0: single conv); 0 = unsupported */
 int usot_plan_add_pw_panel(void *plan, const void *x, const void *w, const float *bias, const void *res, void *y,
                            int M, int K, int N, int act, int dtype);
 /* ... and the fused pair of usot_pw_pair_lp in that form: Y's sixteen channels per lane, rounded, are the B fragments of

@@ -22,5 +22,15 @@ for c in FETCH_SIZE WRITE_SIZE; do
     python scripts/rocpd_pmc.py "$(db "$out/pmc_$c")" > "$out/pmc_${c,,}_kb.txt"
 done
 python scripts/pmc_to_traffic.py "$(db "$out/pmc_FETCH_SIZE")" "$(db "$out/pmc_WRITE_SIZE")" "$out/pmc_traffic.json" "$commit" > /dev/null
-rm -rf "$out/prof" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE"
+# configs[2] (batch-64 bf16 backbone): kernel table + the two PMC passes behind backbone_bf16_b64.roofline.traffic
+lp="--workload backbone_bf16 --steps 20 --min-seconds 0"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$out/prof_lp" -- python "$root/bench.py" $lp > "$out/config3_bf16_profiled_bench.json" 2>> "$out/prof.err")
+python scripts/rocpd_stats.py "$(db "$out/prof_lp")" > "$out/config3_kernel_stats.txt"
+for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$out/pmc_lp_$c" -- python "$root/bench.py" $lp > /dev/null 2>> "$out/prof.err")
+    python scripts/rocpd_pmc.py "$(db "$out/pmc_lp_$c")" > "$out/config3_pmc_${c,,}_kb.txt"
+done
+python scripts/pmc_lp_traffic.py "$(db "$out/pmc_lp_FETCH_SIZE")" "$(db "$out/pmc_lp_WRITE_SIZE")" "$out/pmc_traffic_bf16.json" "$commit" > /dev/null
+timeout 300 python bench.py --workload backbone_bf16 > "$out/config3_bf16_bench.json" 2>> "$out/bench.err"
+rm -rf "$out/prof" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/prof_lp" "$out/pmc_lp_FETCH_SIZE" "$out/pmc_lp_WRITE_SIZE"
 cat "$out/smoke.log" | tail -2; head -c 600 "$out/bench.json"; echo; head -12 "$out/kernel_stats.txt"

@@ -147,6 +147,50 @@ def test_track_mixed_precision(net, oracle_sd, dtype, heads_lp):
     assert lb < tol
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['fp16', 'bf16'])
+def test_track_mixed_b32_the_timed_plan_vs_oracle(net, oracle_sd, dtype, capsys):
+    """BASELINE configs[4] at the batch bench.py TIMES (`track_mixed_b32`: 32 streams in lock step, low-precision backbone and
+    head convs, fp32 xcorr / reduce / predictions; same inputs as bench.measure_track_mixed): a strided subset of the streams
+    against the float32 oracle.  fp16 is gated at <= 1e-2 mean-relative on cls / cls_mem / xf (11 mantissa bits over ~60
+    layers; measured 3-5e-3); bf16 (8 bits) is reported and only sanity-gated.  Max errors are printed beside the means."""
+    if not net.engine_options.get('graphs', True):
+        pytest.skip('one engine configuration is enough for the batch-32 run')
+    B = 32
+    z, x = t(synth.crop(5000, B, 127)), t(synth.crop(6000, B, 255))
+    mem = t(synth.memory_kernels(7000, 7 * B))
+    pick = [0, 11, 21, 31]
+    net.pr_pool = False
+    net.template(z.to(DEV))
+    net.pr_pool = True
+    got = net.engine.track_mixed(x.to(DEV), net.zf, mem.to(DEV), torch.ones(B, 7, device=DEV), dtype=dtype, heads_lp=True)
+    gcls, gbbox, gcm, gxf = [npy(a.float()) for a in got]
+    assert gcls.shape == (B, 1, 25, 25) and gbbox.shape == (B, 4, 25, 25) and np.isfinite(gcls).all() and np.isfinite(gbbox).all()
+    rows = []
+    for s_ in pick:
+        with torch.no_grad():
+            zf = orc.template(oracle_sd, z[s_:s_ + 1], pr_pool=False)
+            cls, bbox, cm, xf = orc.track(oracle_sd, x[s_:s_ + 1], zf, mem[7 * s_:7 * s_ + 7], torch.ones(1, 7))
+        for nm, g_, r_ in (('cls', gcls[s_], cls.numpy()[0]), ('cls_mem', gcm[s_], cm.numpy()[0]), ('xf', gxf[s_], xf.numpy()[0]),
+                           ('log bbox', np.log(gbbox[s_]), np.log(bbox.numpy()[0]))):
+            d = np.abs(g_ - r_)
+            rows.append((s_, nm, d.mean() / np.abs(r_).mean(), d.max() / np.abs(r_).mean()))
+    with capsys.disabled():
+        for s_, nm, mean, mx in rows:
+            print('\n[track_mixed b32 %s] stream %2d %-8s mean-relative %.2e  max / mean|ref| %.2e' % (
+                'fp16' if dtype == torch.float16 else 'bf16', s_, nm, mean, mx), end='')
+    gate = 1e-2 if dtype == torch.float16 else 1.5e-1
+    for s_, nm, mean, mx in rows:
+        assert mean <= gate, (s_, nm, mean)
+    # batch independence of the lock-step plan: stream 21 alone (batch 1 plan) gives the same maps
+    net.pr_pool = False
+    net.template(z[21:22].to(DEV))
+    net.pr_pool = True
+    alone = net.engine.track_mixed(x[21:22].to(DEV), net.zf, mem[147:154].to(DEV), torch.ones(1, 7, device=DEV), dtype=dtype, heads_lp=True)
+    for a, b in zip(alone[:3], (gcls[21:22], gbbox[21:22], gcm[21:22])):
+        a = npy(a.float())
+        assert np.abs(a - b).max() <= (2e-2 if dtype == torch.float16 else 2e-1) * max(1.0, np.abs(b).max())
+
+
 def scaled(got, ref):
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     return float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).mean() + 1e-30)))

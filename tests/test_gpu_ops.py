@@ -962,3 +962,23 @@ def test_pw_panel_pair_equals_the_two_convolutions(cm, co, cn, M, act2, dtype):
         ref = ref.relu()
     assert float(((a.double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= ulp
     assert hip.lib().usot_pw_panel_pair_supported(cm, co, cn + 32) == 0
+
+
+def test_bw_probe_kernels_move_the_right_bytes():
+    """The HBM ceiling probes bench.py quotes GroupDW against (csrc/bw_probe.hip): copy copies, the 4:1 mix sums the four
+    adjacent 1 KiB rows of each 64-element group, bad arguments are refused."""
+    n = 1 << 20
+    src = torch.randn(n // 4, device=DEV)
+    dst = torch.zeros(n // 4, device=DEV)
+    L = hip.lib()
+    hip.check(L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, 1), 'copy')
+    assert torch.equal(dst, src)
+    dst.zero_()
+    hip.check(L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, 2), 'mix')
+    v = src.view(-1, 4, 64, 4)                              # [group][row of the group][element][4 floats]
+    want = (v[:, 0] + v[:, 1]) + (v[:, 2] + v[:, 3])
+    got = dst[: n // 16].view(-1, 64, 4)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-6) and float(dst[n // 16:].abs().max()) == 0.0
+    hip.check(L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, 0), 'read')
+    assert L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n + 16, 1) != 0
+    assert L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, 3) != 0

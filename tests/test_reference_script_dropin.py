@@ -62,3 +62,52 @@ def test_reference_test_script_runs_on_this_lib(monkeypatch, tmp_path):
     mod.track(StubTracker(), net, video, args)
     out = (tmp_path / 'var' / 'result' / 'OTB2015' / 'USOT' / 'synth.txt').read_text().strip().splitlines()
     assert len(out) == 4 and out[1].split(',')[2:] == ['40.0', '30.0']
+
+
+def test_reference_vot_branch_reinitialises_after_a_failure(monkeypatch, tmp_path):
+    """The VOT protocol of the reference's driver (scripts/test_usot.py:90-103,111-118): overlap with the ground truth through
+    THIS repo's shapely-free `poly_iou`; a frame without overlap writes `2`, the next four write `0`, the fifth re-initialises
+    (writes `1`); the result file goes to var/result/<dataset>/<arch>/baseline/<video>/<video>_001.txt.  The stub tracker
+    jumps off the target on frame 3 only, so exactly one failure is forced."""
+    from usot_amd import synth
+    n = 12
+    frames = [synth.frame(5, t=t)[0] for t in range(n)]
+    mod = _load_script(monkeypatch, frames)
+    assert mod.poly_iou.__module__ == 'usot_amd.hostutils' or mod.poly_iou.__module__.startswith('usot_amd')
+    gt_box = [100.0, 80.0, 40.0, 30.0]                                  # x, y, w, h: an axis-aligned VOT "polygon" of 4 numbers
+    inits = []
+
+    class StubTracker:
+        def __init__(self):
+            self.f = 0
+
+        def init(self, im, pos, sz, net):
+            inits.append((self.f, pos.copy(), sz.copy()))
+            return {'target_pos': pos.astype(float), 'target_sz': sz.astype(float), 'cls_score': 1.0}
+
+        def track(self, state, im):
+            self.f += 1
+            if self.f == 3:                                             # far away from the target: IoU 0
+                state['target_pos'] = np.array([400.0, 300.0])
+            return state
+
+    trk = StubTracker()
+    real_imread = sys.modules['cv2'].imread
+
+    def imread(path):                                                   # lets the stub know the frame index
+        trk.f = int(os.path.basename(path).split('.')[0]) - 1
+        return real_imread(path)
+    sys.modules['cv2'].imread = imread
+    args = types.SimpleNamespace(epoch_test=False, dataset='VOT2018', arch='USOT', resume='x.pth')
+    video = {'name': 'synthvot', 'image_files': ['%d.jpg' % i for i in range(n)], 'gt': np.array([gt_box] * n)}
+    monkeypatch.chdir(tmp_path)
+    mod.track(trk, object(), video, args)
+    out = (tmp_path / 'var' / 'result' / 'VOT2018' / 'USOT' / 'baseline' / 'synthvot' / 'synthvot_001.txt').read_text().strip().splitlines()
+    assert len(out) == n
+    # frame 0 init, 1-2 tracked boxes, 3 failure, 4-7 skipped, 8 re-init, 9-11 tracked boxes
+    assert out[0] == '1' and out[3] == '2' and out[4:8] == ['0'] * 4 and out[8] == '1'
+    for k in (1, 2, 9, 10, 11):
+        assert len(out[k].split(',')) == 4
+    assert [f for f, _, _ in inits] == [-1, 7]                         # two initialisations: frame 0 and the re-init frame 8
+    np.testing.assert_allclose(inits[1][1], [120.0, 95.0])             # get_axis_aligned_bbox of the 4-number gt: x + w/2, y + h/2
+    np.testing.assert_allclose(inits[1][2], [40.0, 30.0])

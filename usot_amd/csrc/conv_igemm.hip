@@ -1181,6 +1181,9 @@ int fill_params(const usot_conv_desc *d, ConvK &p)
     if (oh != d->OH || ow != d->OW || oh <= 0 || ow <= 0) return USOT_EINVAL;
     const int ksplit = d->ksplit > 1 ? d->ksplit : 1;
     if (ksplit > 1 && !d->ws) return USOT_EINVAL;
+    // the split-K slabs are addressed through a raw buffer descriptor with 32-bit byte offsets (ws_rsrc): past 2 GiB the
+    // offsets would wrap and the accesses fall out of range silently
+    if (ksplit > 1 && (int64_t)ksplit * (d->groups > 1 ? d->groups : 1) * d->N * oh * ow * d->Cout * 4 >= 0x7fffffffLL) return USOT_EINVAL;
     p.x = d->x; p.w = d->w; p.bias = d->bias; p.res = d->res; p.y = d->y; p.ws = d->ws;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;

@@ -259,6 +259,9 @@ extern "C" int usot_plan_add_conv_bf16(void *plan, const usot_conv_desc *d) { re
 extern "C" int usot_plan_add_pw_pair(void *plan, const usot_pw_pair_desc *d, int dtype)
 {
     if (!d || !(dtype == 2 ? usot_pw_pair_f32_supported(d->CM, d->CO, d->CN) : usot_pw_pair_supported(d->CM, d->CO, d->CN))) return USOT_EINVAL;
+    // the fp32 (256, 1024, 256) pair exists in the channel-sliced form only: it needs M small enough to slice AND a workspace —
+    // refuse it here, at build time, not at the first run / graph capture
+    if (dtype == 2 && d->CM == 256 && !(d->ws && usot_pw_pair_f32_ws_floats(d->M, d->CM, d->CO, d->CN) > 0)) return USOT_EINVAL;
     Op *op = push(plan, K_PWPAIR);
     if (!op) return USOT_ESTATE;
     op->pw = *d;

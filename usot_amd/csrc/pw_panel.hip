@@ -392,6 +392,8 @@ int panel_launch(hipStream_t s, PanelK p, int dtype)
 
 }  // namespace
 
+extern "C" int usot_pw_panel_pair_supported(int CM, int CO, int CN);
+
 extern "C" int usot_pw_panel_supported(int K, int N)
 {
     return (K == 256 && N == 1024) || (K == 128 && N == 512) || (K == 64 && N == 256);
@@ -414,6 +416,19 @@ extern "C" int usot_pw_panel_lp(void *stream, const void *x, const void *w, cons
     if (K == 256) return panel_launch<256, 1024, 0, 2>(s, p, dtype);
     if (K == 128) return panel_launch<128, 512, 0, 2>(s, p, dtype);
     return panel_launch<64, 256, 0, 4>(s, p, dtype);
+}
+
+/* pixels per panel (= per workgroup) of a supported shape, CN = 0 for the single convolution; 0 = unsupported.  A launch
+ * keeps ceil(M / pixels) of the CUs busy: callers should prefer the tiled kernels when that is far below the CU count. */
+extern "C" int usot_pw_panel_pixels(int CM, int CO, int CN)
+{
+    if (CN == 0) {
+        if (!usot_pw_panel_supported(CM, CO)) return 0;
+        return CM == 256 ? PanelCfg<256, 1024, 0, 2>::BM : CM == 128 ? PanelCfg<128, 512, 0, 2>::BM : PanelCfg<64, 256, 0, 4>::BM;
+    }
+    if (!usot_pw_panel_pair_supported(CM, CO, CN)) return 0;
+    if (CM == 128) return CN == 128 ? PanelCfg<128, 512, 128, 2>::BM : PanelCfg<128, 512, 256, 1>::BM;
+    return CN == 64 ? PanelCfg<64, 256, 64, 2>::BM : PanelCfg<64, 256, 128, 2>::BM;
 }
 
 extern "C" int usot_pw_panel_pair_supported(int CM, int CO, int CN)

@@ -231,6 +231,7 @@ class Builder:
         self.batch = True                 # heterogeneous conv batching (one launch for sibling convs)
         self.default_batch_tile = 15      # v2 32x64 BK64 when the lead shape has no tuned entry
         self.log = []           # (name, M, N, K, groups, macs) per conv, for benchmarks
+        self.lp_bytes = []      # algorithmic HBM bytes of every low-precision conv launch (operands + result, once each)
         self.geoms = []         # full geometry per conv, for the tuner
 
     def buf(self, *shape, dtype=torch.float32):
@@ -419,12 +420,14 @@ class Builder:
         k = pc.kh * pc.kw * pc.cin
         if (tile == 0 and pc.kh == 1 and pc.kw == 1 and pc.stride == 1 and groups == 1 and not out_f32 and cout == pc.cout
                 and act in (ACT_NONE, ACT_RELU) and act_split == 0 and (k, cout) in self.opt['panel_1x1_lp']
-                and n * oh * ow >= self.opt['panel_1x1_lp_min_m'] and hip.lib().usot_pw_panel_supported(k, cout)):
+                and hip.lib().usot_pw_panel_supported(k, cout)
+                and n * oh * ow >= self.opt['panel_min_panels'] * hip.lib().usot_pw_panel_pixels(k, cout, 0)):
             hip.check(hip.lib().usot_plan_add_pw_panel(self.plan.h, hip.ptr(x), hip.ptr(wb), hip.ptr(pc.b),
                                                        hip.ptr(res) if res is not None else None, hip.ptr(y), n * oh * ow, k, cout,
                                                        act, 1 if dtype == torch.float16 else 0), 'plan_add_pw_panel ' + name)
             self.plan.keep += [x, wb, pc.b, res]
             self.log.append((name, n * oh * ow, cout, k, 1, n * oh * ow * cout * k))
+            self.lp_bytes.append(2 * (n * h * w * pc.cin + n * oh * ow * cout * (2 if res is not None else 1) + cout * k))
             return y, oh, ow
         if tile == 0:
             tile = LP_TUNING.get((n * oh * ow, cout, k), 0)
@@ -440,6 +443,7 @@ class Builder:
                   'plan_add_conv_lp ' + name)
         self.plan.keep += [x, wb, pc.b]
         self.log.append((name, n * oh * ow, cout, k, groups, groups * n * oh * ow * cout * k))
+        self.lp_bytes.append(groups * (2 * (n * h * w * pc.cin + cout * k) + n * oh * ow * cout * ((4 if out_f32 else 2) + (2 if res is not None else 0))))
         return y, oh, ow
 
     def pw_pair(self, name, c3, nxt, t2, res, n, h, act2, dtype):
@@ -456,6 +460,7 @@ class Builder:
                   'plan_add_pw_pair ' + name)
         self.plan.keep += [t2, res, w3p, w1, c3.b, nxt.b]
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
+        self.lp_bytes.append(2 * (m * (c3.cin + 2 * c3.cout + nxt.cout) + c3.cout * c3.cin + nxt.cout * c3.cout))
         return y, t
 
     def pw_panel_pair(self, name, c3, nxt, t2, res, n, h, act2, dtype):
@@ -470,6 +475,7 @@ class Builder:
                   'plan_add_pw_panel_pair ' + name)
         self.plan.keep += [t2, res, w3, w1, c3.b, nxt.b]
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
+        self.lp_bytes.append(2 * (m * (c3.cin + 2 * c3.cout + nxt.cout) + c3.cout * c3.cin + nxt.cout * c3.cout))
         return y, t
 
     def pw_pair_f32(self, name, c3, nxt, t2, res, n, h, act2=ACT_RELU):
@@ -617,8 +623,8 @@ class Builder:
             nxt = (W.neck if not neck_f32 else None) if last else W.blocks[bi + 1][0]
             nm = 'b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1))
             if (fuse and nxt is not None and nxt.kh == 1 and (c3.cin, c3.cout, nxt.cout) in self.opt['panel_pair_lp']
-                    and n * h2 * h2 >= self.opt['panel_1x1_lp_min_m']
-                    and hip.lib().usot_pw_panel_pair_supported(c3.cin, c3.cout, nxt.cout)):
+                    and hip.lib().usot_pw_panel_pair_supported(c3.cin, c3.cout, nxt.cout)
+                    and n * h2 * h2 >= self.opt['panel_min_panels'] * hip.lib().usot_pw_panel_pixels(c3.cin, c3.cout, nxt.cout)):
                 cur, t1 = self.pw_panel_pair(nm, c3, nxt, t2, sc, n, h2, ACT_NONE if last else ACT_RELU, dtype)
             elif fuse and nxt is not None and (c3.cin, c3.cout, nxt.cout) in self.opt['fused_pointwise_lp']:
                 cur, t1 = self.pw_pair('b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1)), c3, nxt, t2, sc, n, h2,
@@ -771,9 +777,11 @@ DEFAULT_OPTIONS = {
     # low-precision backbone: the shapes where the fused kernel measured faster than the two launches at batch 64
     'fused_pointwise_lp': {(64, 256, 64), (64, 256, 128), (128, 512, 128)},
     # (K, N) of the unfused 1x1 EXPANSION convolutions of the low-precision backbone that run on the pixel-stationary
-    # panel kernel (csrc/pw_panel.hip) from panel_1x1_lp_min_m pixels up: layer3's conv3 89 -> ?? us at batch 64
+    # panel kernel (csrc/pw_panel.hip) when the launch has at least panel_min_panels pixel panels (one workgroup = one CU each:
+    # batch 32 at layer2 / layer3 resolution is 120 panels — half the chip — and stays on the tiled kernels): layer3's
+    # conv3 89 -> 66 us, layer1's 1x1 shortcut 50 -> 38 at batch 64
     'panel_1x1_lp': {(256, 1024), (128, 512), (64, 256)},
-    'panel_1x1_lp_min_m': 16384,
+    'panel_min_panels': 192,
     # (C_mid, C_out, C_next) of the conv3 -> next-1x1 pairs of the low-precision backbone that run as ONE launch of the
     # panel kernel's pair form (Y's accumulators feed the second GEMM from registers); takes precedence over
     # fused_pointwise_lp (csrc/pw_pair.hip: 64-pixel tiles with an LDS image of Y)
@@ -900,7 +908,7 @@ class Engine:
             xin = bld.buf(n, 3, s, s)
             xf, h = bld.backbone_bf16(xin, n, s, dtype=dtype)
             self._finish(bld.plan)
-            self._feat[key] = dict(x=xin, xf=xf, h=h, plan=bld.plan, log=bld.log, p3=bld.p3)
+            self._feat[key] = dict(x=xin, xf=xf, h=h, plan=bld.plan, log=bld.log, p3=bld.p3, lp_bytes=bld.lp_bytes)
         p = self._feat[key]
         p['x'].copy_(x)
         p['plan'].run()

@@ -228,13 +228,19 @@ class USOTTracker(object):
         """numpy mirror of state['memory_confidences'] (the list the reference keeps, usot_tracker.py:265):
         select_memory takes argmax over quarter-length slices of it every frame, which on a python
         list costs a list -> array conversion that grows with the video (60 us per frame at 2 000
-        frames).  Rebuilt whenever the caller has edited the list."""
+        frames).  The list is APPEND-ONLY as far as this mirror can tell cheaply: it is rebuilt when the list object was
+        replaced, shrank, outgrew the buffer, or its last mirrored entry changed; an in-place edit of an EARLIER entry is
+        caught by a full comparison every 256 frames (a caller that rewrites history should drop state['_conf_buf'])."""
         buf, n = state.get('_conf_buf'), len(conf)
         m = state.get('_conf_n', 0)
-        if buf is None or m > n or n > len(buf) or (m and buf[m - 1] != conf[m - 1]):
+        stale = buf is None or state.get('_conf_id') != id(conf) or m > n or n > len(buf) or (m and buf[m - 1] != conf[m - 1])
+        if not stale and m and n % 256 == 0:
+            stale = not np.array_equal(buf[:m], np.asarray(conf[:m], np.float64))
+        if stale:
             buf = np.empty(max(1024, 2 * n), np.float64)
             buf[:n] = conf
             state['_conf_buf'] = buf
+            state['_conf_id'] = id(conf)
         elif n > m:
             buf[m:n] = conf[m:n]
         state['_conf_n'] = n
