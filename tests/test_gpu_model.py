@@ -151,8 +151,10 @@ def test_track_mixed_precision(net, oracle_sd, dtype, heads_lp):
 def test_track_mixed_b32_the_timed_plan_vs_oracle(net, oracle_sd, dtype, capsys):
     """BASELINE configs[4] at the batch bench.py TIMES (`track_mixed_b32`: 32 streams in lock step, low-precision backbone and
     head convs, fp32 xcorr / reduce / predictions; same inputs as bench.measure_track_mixed): a strided subset of the streams
-    against the float32 oracle.  fp16 is gated at <= 1e-2 mean-relative on cls / cls_mem / xf (11 mantissa bits over ~60
-    layers; measured 3-5e-3); bf16 (8 bits) is reported and only sanity-gated.  Max errors are printed beside the means."""
+    against the float32 oracle.  fp16 (11 mantissa bits over ~60 layers) is gated at <= 1e-2 mean-relative on cls / xf /
+    log bbox (measured 4.4e-3 .. 7.2e-3, 7e-4 .. 1e-3 on the boxes) and <= 1.5e-2 on cls_mem, which passes through
+    Conf_Fusion's exp() (measured 7.6e-3 .. 9.9e-3); bf16 (8 bits) is reported and sanity-gated at 1e-1 (measured 3e-2 .. 7e-2).
+    Max errors are printed beside the means."""
     if not net.engine_options.get('graphs', True):
         pytest.skip('one engine configuration is enough for the batch-32 run')
     B = 32
@@ -178,8 +180,8 @@ def test_track_mixed_b32_the_timed_plan_vs_oracle(net, oracle_sd, dtype, capsys)
         for s_, nm, mean, mx in rows:
             print('\n[track_mixed b32 %s] stream %2d %-8s mean-relative %.2e  max / mean|ref| %.2e' % (
                 'fp16' if dtype == torch.float16 else 'bf16', s_, nm, mean, mx), end='')
-    gate = 1e-2 if dtype == torch.float16 else 1.5e-1
     for s_, nm, mean, mx in rows:
+        gate = (1.5e-2 if nm == 'cls_mem' else 1e-2) if dtype == torch.float16 else 1e-1
         assert mean <= gate, (s_, nm, mean)
     # batch independence of the lock-step plan: stream 21 alone (batch 1 plan) gives the same maps
     net.pr_pool = False
@@ -257,7 +259,7 @@ def test_every_fixture_within_1p5x_of_the_references_own_float32_error(family, c
 
 
 # every switch of usot_amd.engine.DEFAULT_OPTIONS that changes which kernels a frame uses, flipped away from its default
-OPTION_VARIANTS = [{'fused_f32_sliced': False}, {'fused_triple_f32': False}, {'stream_1x1': False}, {'stream_3x3': False},
+OPTION_VARIANTS = [{'fused_f32_sliced': False}, {'conf_tail_split': None}, {'conf_tail_split': (2, 3)}, {'fused_triple_f32': False}, {'stream_1x1': False}, {'stream_3x3': False},
                    {'fused_pointwise_f32': set()},
                    {'stream_3x3_shapes': {(128, 128), (256, 256)}}, {'stream_1x1_shapes': {(256, 1024), (128, 512), (1024, 256), (512, 128)}}]
 

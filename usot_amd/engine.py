@@ -252,7 +252,8 @@ class Builder:
             self.plan.join(lane)
 
     def conv_desc(self, name, pc, x, n, h, w, *, cout=None, act=ACT_NONE, res=None, y=None, y_cstride=0, y_coff=0,
-                  act2=ACT_NONE, act_split=0, y_nchw=False, groups=1, x_gs=0, y_gs=0, w_rows=None, row0=0, tile=None):
+                  act2=ACT_NONE, act_split=0, y_nchw=False, groups=1, x_gs=0, y_gs=0, w_rows=None, row0=0, tile=None,
+                  force_ks=None):
         """Descriptor of one convolution (nothing is added to the plan yet).
         x: tensor (NHWC dense, channels == pc.cin).  Returns (desc, y, oh, ow, log, geom)."""
         cout = cout or pc.cout
@@ -267,6 +268,8 @@ class Builder:
         if tile is not None:                       # batched launch: tile imposed by the lead problem
             ksplit = 1 if tile != ttile else ksplit
             ttile = tile
+        if force_ks is not None:
+            ksplit = force_ks
         ws = None
         if ksplit > 1:            # partial slabs + one ticket per tile (usot_conv_ws_floats), tickets zero before first use
             ws = self.buf(ksplit * groups * m * cout + groups * ((m + 15) // 16) * ((cout + 31) // 32))
@@ -692,7 +695,20 @@ class Builder:
         cls2 = self.buf(ngroups - 1, b, 1, S, S)      # [cls, (cls_mem)]
         if has_mem and self.lanes < 2:
             # serial schedule: one 3-group launch per tower level (fewest launches)
-            cv, _, _ = self.conv('conf_fusion', W.conf, dwm, b * m, S, S, act=ACT_CONF, act2=ACT_RELU, act_split=256)
+            ts = self.opt.get('conf_tail_split')
+            if ts and b * m > ts[0]:
+                # whole-chip rounds: the last `tail` memory maps run split-K in the same launch (see DEFAULT_OPTIONS)
+                tail, ks = ts
+                head_n = b * m - tail
+                cv = self.buf(b * m, S, S, 512)
+                kw = dict(act=ACT_CONF, act2=ACT_RELU, act_split=256)
+                full_tile = self.tuning.get((b * m * S * S, 512, W.conf.kh * W.conf.kw * W.conf.cin, 1), (0, 1))[0]
+                if full_tile:                             # both parts on the tile tuned for the whole convolution
+                    self.tuning.setdefault((head_n * S * S, 512, W.conf.kh * W.conf.kw * W.conf.cin, 1), (full_tile, 1))
+                self.conv_batch([('conf_fusion', W.conf, dwm[:head_n], head_n, S, S, dict(y=cv[:head_n], force_ks=1, **kw)),
+                                 ('conf_fusion.tail', W.conf, dwm[head_n:], tail, S, S, dict(y=cv[head_n:], force_ks=ks, **kw))])
+            else:
+                cv, _, _ = self.conv('conf_fusion', W.conf, dwm, b * m, S, S, act=ACT_CONF, act2=ACT_RELU, act_split=256)
             hip.check(L.usot_plan_add_conf_reduce(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256),
                       'plan_add_conf_reduce')
             cur = tin
@@ -815,6 +831,11 @@ DEFAULT_OPTIONS = {
     # float64 acceptance rule (tests/golden/f64_gate.py) on both weight families: ON, graph replay 880.5 -> 855.7 us.
     'fused_f32_sliced': True,
     'fused_pointwise_f32_sliced_only': {(256, 1024, 256)},
+    # Conf_Fusion's conv (7 memory maps x 625 pixels = 137 x 8 tiles of 32 x 64 over 512 workgroup slots = 2.14 rounds):
+    # (tail maps, ksplit) runs the last maps split-K beside the others in ONE launch so that the launch ends on whole-chip
+    # rounds; None = one unsplit convolution.  Same-process A/B of the frame graph (scripts/tail_split_ab.py): unsplit 866 us,
+    # (1, 2) 851.5, (1, 7) 856, (2, 3) 856, (1, 3) 870
+    'conf_tail_split': (1, 2),
     # Session.collect(): wall-clock budget of the result-tag spin before it falls back to 50 us sleeps
     'spin_seconds': 0.004,
 }
