@@ -667,7 +667,9 @@ class Builder:
         W, L = self.W, hip.lib()
         es = [None] * 3
         if self.lanes < 3:                                # three encoder geometries in one launch
-            res = self.conv_batch([('enc_s%d' % g, W.enc_s[g], xf, b, hf, hf, dict(act=ACT_RELU)) for g in range(3)])
+            eks = self.opt.get('enc_s_ksplit') or (None, None, None)
+            res = self.conv_batch([('enc_s%d' % g, W.enc_s[g], xf, b, hf, hf,
+                                    dict(act=ACT_RELU, **({'force_ks': eks[g]} if eks[g] else {}))) for g in range(3)])
             es = [r[0] for r in res]
         else:
             for g, lane in ((1, 1), (2, 3), (0, 0)):
@@ -836,6 +838,8 @@ DEFAULT_OPTIONS = {
     # rounds; None = one unsplit convolution.  Same-process A/B of the frame graph (scripts/tail_split_ab.py): unsplit 866 us,
     # (1, 2) 851.5, (1, 7) 856, (2, 3) 856, (1, 3) 870
     'conf_tail_split': (1, 2),
+    # per-geometry split-K factors of the three search-side encoder convs that share one launch (None = the tuned table)
+    'enc_s_ksplit': None,
     # Session.collect(): wall-clock budget of the result-tag spin before it falls back to 50 us sleeps
     'spin_seconds': 0.004,
 }
