@@ -644,8 +644,7 @@ constexpr int SP_OPB = 144;                         // stem-tile LDS row pitch i
 template <bool F16>
 __global__ __launch_bounds__(256) void stem_pool_lp_kernel(
     const float *__restrict__ x, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
-    uint16_t *__restrict__ y, int H, int W, int OH, int OW, int PH, int PW, float mu0, float mu1, float mu2,
-    int tiles_x, int tiles_y, int ntiles)
+    uint16_t *__restrict__ y, int H, int W, int OH, int OW, int PH, int PW, float mu0, float mu1, float mu2)
 {
     // bf16 keeps 8 significant bits: rounding the CROP to bf16 doubles the end-to-end error of the
     // whole backbone (measured 4e-2 -> 8e-2 of the feature scale), so the bf16 variant stages the
@@ -654,140 +653,127 @@ __global__ __launch_bounds__(256) void stem_pool_lp_kernel(
     constexpr int PLANE = 3 * SP_IR * SP_ICP;
     __shared__ __attribute__((aligned(16))) uint16_t patch[(SPLIT ? 2 : 1) * PLANE];
     __shared__ __attribute__((aligned(16))) unsigned char stile[SP_NBLK * 16 * SP_OPB];
+    const int n = blockIdx.z;
+    const int py0 = blockIdx.y * SP_P, px0 = blockIdx.x * SP_Q;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
+    const int iy0 = 2 * sy0, ix0 = 2 * sx0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, quad = lane >> 4;
 
-    // PERSISTENT over tiles (round 3): the 24 filter fragments per lane (384 B) and the bias are loaded ONCE per workgroup —
-    // at one tile per workgroup (8 192 workgroups at batch 64) they were 800 MB of L2 reads per launch and a dependent
-    // round trip in front of every tile — and the crop patch of the NEXT tile is fetched into registers while the current
-    // tile is in the matrix pipe.
+    // filter fragments: 4 channel blocks x 6 k-steps, 16 bytes each, coalesced
     u32x4 wf[4][6];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) wf[cb][ks] = wfrag[(cb * 6 + ks) * 64 + lane];
+
+    // input patch -> LDS in the storage type (out-of-image pixels and the pad column are zero;
+    // they only ever feed stem pixels the pool masks out, or zero weights)
+    const float *xn = x + (long)n * 3 * H * W;
+    // every global load of the patch is issued before the first LDS store (a load -> store loop
+    // serialises ~11 dependent HBM round trips per thread)
+    constexpr int NPL = (3 * SP_IR * SP_ICP + 255) / 256;
+    float pv[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int i = tid + q * 256;
+        const int ci = i / (SP_IR * SP_ICP), r = i - ci * SP_IR * SP_ICP;
+        const int py = r / SP_ICP, px = r - py * SP_ICP;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v = 0.f;
+        if (i < 3 * SP_IR * SP_ICP && px < SP_IC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            v = xn[((long)ci * H + iy) * W + ix] - (ci == 0 ? mu0 : (ci == 1 ? mu1 : mu2));
+        pv[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int i = tid + q * 256;
+        if (i < 3 * SP_IR * SP_ICP) {
+            const uint32_t hi = pack_lp<F16>(pv[q]);
+            patch[i] = (uint16_t)hi;
+            if constexpr (SPLIT) patch[PLANE + i] = (uint16_t)pack_lp<F16>(pv[q] - unpack_lp<F16>(hi));
+        }
+    }
+    __syncthreads();
+
     f32x4 bv[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) bv[cb] = *(const f32x4 *)(bias + cb * 16 + quad * 4);
 
-    // input patch -> registers (out-of-image pixels and the pad column are zero; they only ever feed stem pixels the pool
-    // masks out, or zero weights); every global load of a patch is issued before anything waits for one
-    constexpr int NPL = (3 * SP_IR * SP_ICP + 255) / 256;
-    float pv[NPL];
-    auto load_patch = [&](int tile) {
-        const int n = tile / (tiles_x * tiles_y), r2 = tile - n * tiles_x * tiles_y;
-        const int ty = r2 / tiles_x, tx = r2 - ty * tiles_x;
-        const int iy0 = 2 * (2 * ty * SP_P - 1), ix0 = 2 * (2 * tx * SP_Q - 1);
-        const float *xn = x + (long)n * 3 * H * W;
+    for (int blk = wave; blk < SP_NBLK; blk += 4) {
+        int pi = blk * 16 + l15;
+        if (pi > SP_NPIX - 1) pi = SP_NPIX - 1;
+        const int sy = pi / SP_C, sx = pi - sy * SP_C;
+        f32x4 acc[4];
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = tid + q * 256;
-            const int ci = i / (SP_IR * SP_ICP), r = i - ci * SP_IR * SP_ICP;
-            const int py = r / SP_ICP, px = r - py * SP_ICP;
-            const int iy = iy0 + py, ix = ix0 + px;
-            float v = 0.f;
-            if (i < 3 * SP_IR * SP_ICP && px < SP_IC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = xn[((long)ci * H + iy) * W + ix] - (ci == 0 ? mu0 : (ci == 1 ? mu1 : mu2));
-            pv[q] = v;
-        }
-    };
-    int tile = blockIdx.x;
-    if (tile < ntiles) load_patch(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int n = tile / (tiles_x * tiles_y), r2 = tile - n * tiles_x * tiles_y;
-        const int ty = r2 / tiles_x, tx = r2 - ty * tiles_x;
-        const int py0 = ty * SP_P, px0 = tx * SP_Q;
-        const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
-        // patch registers -> LDS in the storage type (the previous tile's readers are past the barrier at the loop's end)
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = tid + q * 256;
-            if (i < 3 * SP_IR * SP_ICP) {
-                const uint32_t hi = pack_lp<F16>(pv[q]);
-                patch[i] = (uint16_t)hi;
-                if constexpr (SPLIT) patch[PLANE + i] = (uint16_t)pack_lp<F16>(pv[q] - unpack_lp<F16>(hi));
-            }
-        }
-        __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) load_patch(tile + gridDim.x);       // in flight under the MFMAs below
-
-        for (int blk = wave; blk < SP_NBLK; blk += 4) {
-            int pi = blk * 16 + l15;
-            if (pi > SP_NPIX - 1) pi = SP_NPIX - 1;
-            const int sy = pi / SP_C, sx = pi - sy * SP_C;
-            f32x4 acc[4];
+        for (int ks = 0; ks < 6; ++ks) {
+            int r = 4 * ks + quad;
+            if (r > 20) r = 20;                          // zero-weight rows: any valid address
+            const int ci = r / 7, kh = r - ci * 7;
+            const uint32_t *src = (const uint32_t *)(patch + (ci * SP_IR + 2 * sy + kh) * SP_ICP + 2 * sx);
+            u32x4 xf;
+            xf[0] = src[0]; xf[1] = src[1]; xf[2] = src[2]; xf[3] = src[3];
+            if constexpr (F16) {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[cb][ks]),
+                                                                     __builtin_bit_cast(f16x8, xf), acc[cb], 0, 0, 0);
+            } else {
+                const uint32_t *srl = src + PLANE / 2;
+                u32x4 xl;
+                xl[0] = srl[0]; xl[1] = srl[1]; xl[2] = srl[2]; xl[3] = srl[3];
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                int r = 4 * ks + quad;
-                if (r > 20) r = 20;                          // zero-weight rows: any valid address
-                const int ci = r / 7, kh = r - ci * 7;
-                const uint32_t *src = (const uint32_t *)(patch + (ci * SP_IR + 2 * sy + kh) * SP_ICP + 2 * sx);
-                u32x4 xf;
-                xf[0] = src[0]; xf[1] = src[1]; xf[2] = src[2]; xf[3] = src[3];
-                if constexpr (F16) {
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb)
-                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[cb][ks]),
-                                                                         __builtin_bit_cast(f16x8, xf), acc[cb], 0, 0, 0);
-                } else {
-                    const uint32_t *srl = src + PLANE / 2;
-                    u32x4 xl;
-                    xl[0] = srl[0]; xl[1] = srl[1]; xl[2] = srl[2]; xl[3] = srl[3];
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) {
-                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cb][ks]),
-                                                                          __builtin_bit_cast(bf16x8, xf), acc[cb], 0, 0, 0);
-                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cb][ks]),
-                                                                          __builtin_bit_cast(bf16x8, xl), acc[cb], 0, 0, 0);
-                    }
+                for (int cb = 0; cb < 4; ++cb) {
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cb][ks]),
+                                                                      __builtin_bit_cast(bf16x8, xf), acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cb][ks]),
+                                                                      __builtin_bit_cast(bf16x8, xl), acc[cb], 0, 0, 0);
                 }
             }
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                f32x4 v = acc[cb] + bv[cb];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                u32x2 o;
-                o[0] = usot_pack2_lp<F16>(v[0], v[1]);
-                o[1] = usot_pack2_lp<F16>(v[2], v[3]);
-                *(u32x2 *)(stile + (blk * 16 + l15) * SP_OPB + (cb * 16 + quad * 4) * 2) = o;
-            }
         }
-        __syncthreads();
-
-        // 3x3 / stride 2 / pad 1 max-pool: one pooled pixel x 8 channels per lane
-        const int pp = tid >> 3, c8 = tid & 7;
-        const int ppy = pp / SP_Q, ppx = pp - ppy * SP_Q;
-        const int py = py0 + ppy, px = px0 + ppx;
-        if (py < PH && px < PW) {
-            float m[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+        for (int cb = 0; cb < 4; ++cb) {
+            f32x4 v = acc[cb] + bv[cb];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int ly = 2 * ppy + dy, gy = sy0 + ly;
-                if ((unsigned)gy >= (unsigned)OH) continue;
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int lx = 2 * ppx + dx, gx = sx0 + lx;
-                    if ((unsigned)gx >= (unsigned)OW) continue;
-                    const u32x4 v = *(const u32x4 *)(stile + (ly * SP_C + lx) * SP_OPB + c8 * 16);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        m[2 * e] = fmaxf(m[2 * e], unpack_lp<F16>(v[e] & 0xffffu));
-                        m[2 * e + 1] = fmaxf(m[2 * e + 1], unpack_lp<F16>(v[e] >> 16));
-                    }
-                }
-            }
-            u32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = usot_pack2_lp<F16>(m[2 * e], m[2 * e + 1]);
-            *(u32x4 *)(y + ((((long)n * PH + py) * PW + px) * 64 + c8 * 8)) = o;
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            u32x2 o;
+            o[0] = usot_pack2_lp<F16>(v[0], v[1]);
+            o[1] = usot_pack2_lp<F16>(v[2], v[3]);
+            *(u32x2 *)(stile + (blk * 16 + l15) * SP_OPB + (cb * 16 + quad * 4) * 2) = o;
         }
-        __syncthreads();                                     // stile and patch are rewritten by the next tile
     }
+    __syncthreads();
+
+    // 3x3 / stride 2 / pad 1 max-pool: one pooled pixel x 8 channels per lane
+    const int pp = tid >> 3, c8 = tid & 7;
+    const int ppy = pp / SP_Q, ppx = pp - ppy * SP_Q;
+    const int py = py0 + ppy, px = px0 + ppx;
+    if (py >= PH || px >= PW) return;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int ly = 2 * ppy + dy, gy = sy0 + ly;
+        if ((unsigned)gy >= (unsigned)OH) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int lx = 2 * ppx + dx, gx = sx0 + lx;
+            if ((unsigned)gx >= (unsigned)OW) continue;
+            const u32x4 v = *(const u32x4 *)(stile + (ly * SP_C + lx) * SP_OPB + c8 * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m[2 * e] = fmaxf(m[2 * e], unpack_lp<F16>(v[e] & 0xffffu));
+                m[2 * e + 1] = fmaxf(m[2 * e + 1], unpack_lp<F16>(v[e] >> 16));
+            }
+        }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = usot_pack2_lp<F16>(m[2 * e], m[2 * e + 1]);
+    *(u32x4 *)(y + ((((long)n * PH + py) * PW + px) * 64 + c8 * 8)) = o;
 }
 
 }  // namespace
@@ -899,19 +885,9 @@ extern "C" int usot_stem_pool_lp(void *stream, const float *x, const void *wfrag
     if (OH != (H - 7) / 2 + 1 || OW != (W - 7) / 2 + 1) return USOT_EINVAL;
     if (PH != (OH + 2 - 3) / 2 + 1 || PW != (OW + 2 - 3) / 2 + 1) return USOT_EINVAL;
     if (((uintptr_t)wfrag % 16) || ((uintptr_t)y % 16) || ((uintptr_t)bias % 16) || N > 65535) return USOT_EINVAL;
-    const int tiles_x = usot_cdiv(PW, SP_Q), tiles_y = usot_cdiv(PH, SP_P);
-    const long ntiles = (long)tiles_x * tiles_y * N;
-    if (ntiles > 0x7fffffffL) return USOT_EINVAL;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
-    const int grid = (int)(ntiles < 3L * cus ? ntiles : 3L * cus);       // persistent: three 4-wave workgroups per CU (registers)
-    if (dtype) hipLaunchKernelGGL(stem_pool_lp_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2, tiles_x, tiles_y, (int)ntiles);
-    else       hipLaunchKernelGGL(stem_pool_lp_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2, tiles_x, tiles_y, (int)ntiles);
+    dim3 grid(usot_cdiv(PW, SP_Q), usot_cdiv(PH, SP_P), N);
+    if (dtype) hipLaunchKernelGGL(stem_pool_lp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2);
+    else       hipLaunchKernelGGL(stem_pool_lp_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }
