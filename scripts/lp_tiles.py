@@ -20,5 +20,7 @@ def run(name, N, H, Cin, Cout, k, pad, tiles):
         us = e0.elapsed_time(e1) / 20 * 1e3
         out.append('%d:%.0fus/%.0fTF' % (tile, us, 2.0 * N * H * H * Cout * k * k * Cin / us / 1e6))
     print(name, ' '.join(out))
-run('b7.ds 3x3 512->1024', 64, 31, 512, 1024, 3, 1, [21, 18, 22, 32, 33, 34, 19])
-run('L3 conv2 3x3 256->256', 64, 31, 256, 256, 3, 1, [21, 18, 22, 32, 33, 34, 19])
+tiles = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else [21, 18, 22, 19, 15, 20, 16, 10, 17, 26]
+run('b7.ds 3x3 512->1024', 64, 31, 512, 1024, 3, 1, tiles)
+run('L3 conv2 3x3 256->256', 64, 31, 256, 256, 3, 1, tiles)
+run('L3 conv1 1x1 1024->256', 64, 31, 1024, 256, 1, 0, tiles)

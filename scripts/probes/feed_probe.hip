@@ -89,6 +89,9 @@ int main()
     for (int w : {1, 2, 4, 8, 16}) run<0, 4>(src, out, w, "dma");
     for (int w : {4, 8, 16}) run<0, 8>(src, out, w, "dma");
     for (int w : {4, 8}) run<3, 2>(src, out, w, "dma-rows");
+    for (int w : {8, 16}) run<3, 4>(src, out, w, "dma-rows");
+    for (int w : {8, 16}) run<3, 8>(src, out, w, "dma-rows");
+    for (int w : {8, 16}) run<4, 4>(src, out, w, "dma-rows-xor");
     for (int w : {4, 8}) run<4, 2>(src, out, w, "dma-rows-xor");
     for (int w : {4, 8}) run<0, 2>(src, out, w, "dma");
     for (int w : {1, 2, 4, 8, 16}) run<1, 4>(src, out, w, "reg");
