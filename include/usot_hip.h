@@ -148,6 +148,16 @@ int usot_pw_panel_pair_lp(void *stream, const usot_pw_pair_desc *d, int dtype);
 int usot_pw_panel_pair_supported(int CM, int CO, int CN);
 int usot_plan_add_pw_panel_pair(void *plan, const usot_pw_pair_desc *d, int dtype);
 
+/* 3x3 / stride 1 / pad 1 convolution of the batched low-precision backbone as a direct convolution from an LDS halo tile
+ * (csrc/conv3x3_halo.hip; layer1's conv2 + BN + ReLU, modules.py:43-46): x, y NHWC dense [N][H][W][C] and w [Cout][9 Cin]
+ * (k = (kh*3 + kw)*Cin + ci, the conv kernels' layout) in the storage type (dtype 0 = bf16, 1 = fp16), bias fp32 or NULL,
+ * act USOT_ACT_NONE | USOT_ACT_RELU.  Shapes: usot_conv3x3_halo_supported(Cin, Cout) (64 -> 64). */
+int usot_conv3x3_halo_lp(void *stream, const void *x, const void *w, const float *bias, void *y,
+                         int N, int H, int W, int Cin, int Cout, int act, int dtype);
+int usot_conv3x3_halo_supported(int Cin, int Cout);
+int usot_plan_add_conv3x3_halo(void *plan, const void *x, const void *w, const float *bias, void *y,
+                               int N, int H, int W, int Cin, int Cout, int act, int dtype);
+
 /* the same pair in fp32 for the batch-1 frame (csrc/smallm_f32.hip; v_mfma_f32_16x16x4_f32, 16 pixels per workgroup):
  * every pointer of the descriptor is float32.  w3p / w1 in fragment order: the float at
  * [((cb * (K / 16) + r) * 64 + lane) * 4 + c] is W[cb * 16 + (lane & 15)][16 * r + 4 * (lane >> 4) + c]

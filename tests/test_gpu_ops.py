@@ -982,3 +982,35 @@ def test_bw_probe_kernels_move_the_right_bytes():
     hip.check(L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, 0), 'read')
     assert L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n + 16, 1) != 0
     assert L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, 3) != 0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('N,H,W,act', [(2, 63, 63, 1), (1, 16, 16, 0), (3, 17, 33, 1), (1, 5, 40, 1)])
+def test_conv3x3_halo_lp(N, H, W, act, dtype):
+    """Direct 3x3 convolution from an LDS halo tile (csrc/conv3x3_halo.hip) vs the same rounded operands in float64 and
+    bit-equal... no: equal to the tiled implicit-GEMM kernel within one rounding of the storage type (the halo kernel visits
+    k tap by tap in the same order, 32 channels per MFMA: same products, same fp32 chain) — full, ragged and sub-tile images."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
+    x = torch.randn(N, H, W, 64, generator=g).to(dtype)
+    w = (torch.randn(64, 3, 3, 64, generator=g) / 24).to(dtype)                  # [co][kh][kw][ci]
+    b = torch.randn(64, generator=g) * 0.1
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1)
+    if act:
+        ref = ref.relu()
+    xd, wd, bd = x.to(DEV), w.reshape(64, 576).contiguous().to(DEV), b.to(DEV)
+    y = torch.full((N * H * W + 2, 64), 5.0, dtype=dtype, device=DEV)
+    dt = 1 if dtype == torch.float16 else 0
+    assert hip.lib().usot_conv3x3_halo_supported(64, 64) == 1 and hip.lib().usot_conv3x3_halo_supported(128, 128) == 0
+    hip.check(hip.lib().usot_conv3x3_halo_lp(hip.stream(), hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), hip.ptr(y), N, H, W, 64, 64, act, dt), 'halo')
+    assert torch.all(y[N * H * W:] == 5.0)
+    got = y[:N * H * W].reshape(N, H, W, 64)
+    tol = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    assert float(((got.float().cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= tol * 1.01
+    y2 = torch.empty(N, H, W, 64, dtype=dtype, device=DEV)
+    d = hip.conv_desc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y2.data_ptr(), N=N, H=H, W=W, Cin=64, OH=H, OW=W, Cout=64, KH=3, KW=3,
+                      pad=(1, 1), act=act, tile=13)
+    hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d), dt, 0), 'tiled')
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert float(((got.float() - y2.float()).abs() / y2.float().abs().clamp_min(0.25)).max()) <= ulp
+    assert hip.lib().usot_conv3x3_halo_lp(hip.stream(), hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), hip.ptr(y), N, H, W, 128, 128, act, dt) != 0

@@ -421,6 +421,18 @@ class Builder:
                 self.buf(n, oh, ow, cout, dtype=torch.float32 if out_f32 else dtype)
         wb = pc.w_lp(dtype)
         k = pc.kh * pc.kw * pc.cin
+        if (tile == 0 and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and tuple(pc.pad) == (1, 1) and tuple(pc.dil) == (1, 1)
+                and groups == 1 and not out_f32 and res is None and cout == pc.cout and act in (ACT_NONE, ACT_RELU)
+                and act_split == 0 and (pc.cin, cout) in self.opt['halo_3x3_lp']
+                and hip.lib().usot_conv3x3_halo_supported(pc.cin, cout)
+                and n * ((h + 15) // 16) * ((w + 15) // 16) >= 256):
+            hip.check(hip.lib().usot_plan_add_conv3x3_halo(self.plan.h, hip.ptr(x), hip.ptr(wb), hip.ptr(pc.b), hip.ptr(y), n, h, w,
+                                                           pc.cin, cout, act, 1 if dtype == torch.float16 else 0),
+                      'plan_add_conv3x3_halo ' + name)
+            self.plan.keep += [x, wb, pc.b]
+            self.log.append((name, n * oh * ow, cout, k, 1, n * oh * ow * cout * k))
+            self.lp_bytes.append(2 * (n * h * w * pc.cin + n * oh * ow * cout + cout * k))
+            return y, oh, ow
         if (tile == 0 and pc.kh == 1 and pc.kw == 1 and pc.stride == 1 and groups == 1 and not out_f32 and cout == pc.cout
                 and act in (ACT_NONE, ACT_RELU) and act_split == 0 and (k, cout) in self.opt['panel_1x1_lp']
                 and hip.lib().usot_pw_panel_supported(k, cout)
@@ -800,6 +812,9 @@ DEFAULT_OPTIONS = {
     # conv3 89 -> 66 us, layer1's 1x1 shortcut 50 -> 38 at batch 64
     'panel_1x1_lp': {(256, 1024), (128, 512), (64, 256)},
     'panel_min_panels': 192,
+    # (Cin, Cout) of the 3x3 / stride-1 / pad-1 convolutions of the low-precision backbone that run as direct convolutions
+    # from an LDS halo tile (csrc/conv3x3_halo.hip) when the launch has at least one 16 x 16 tile per CU
+    'halo_3x3_lp': {(64, 64)},
     # (C_mid, C_out, C_next) of the conv3 -> next-1x1 pairs of the low-precision backbone that run as ONE launch of the
     # panel kernel's pair form (Y's accumulators feed the second GEMM from registers); takes precedence over
     # fused_pointwise_lp (csrc/pw_pair.hip: 64-pixel tiles with an LDS image of Y)
