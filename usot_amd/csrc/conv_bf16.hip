@@ -562,6 +562,13 @@ const TileB kTilesB[] = {
     // (4 wavefronts x (128 x 128) on a 256 x 256 tile - a quarter of tile 21's LDS fragment bytes per MFMA, accumulators in
     //  AGPRs - measured 648 TFLOP/s on layer3's shortcut conv against 1 082-1 186 for tiles 21 / 22, 981 on the 32x32x16 MFMA:
     //  one wave per SIMD under hipcc's schedule, 512 registers and spills.  Not kept.)
+    // (Round 3, "ping-pong": SQ_VALU_MFMA_BUSY_CYCLES is 67 % of the kernel on layer3's shortcut conv with tile 21 (rocprofv3
+    //  --pmc; the clock under this load is 1.8 GHz, LDS array 35 % busy, no bank conflicts).  A schedule in which the two halves
+    //  of the workgroup run half a k-step apart — one raw s_barrier per phase; a memory phase reads one k-step's fragments into
+    //  registers, a compute phase issues its MFMAs back to back from registers — did NOT close that gap: 8 waves x (128 x 64)
+    //  with the DMA pieces between the MFMAs 608 us against 510 (the 60-180-cycle issue stall of an LDS-DMA instruction lands on
+    //  the only wave feeding the SIMD's matrix pipe), 16 waves x (64 x 64) in teams of two per SIMD 524 against 521, worse on
+    //  K = 2304.  Issuing the DMAs between the two k-steps instead of before them: tiles 18 / 22 -3...-9 %, tile 21 +5 %.  Not kept.)
 };
 constexpr int kNumTilesB = sizeof(kTilesB) / sizeof(kTilesB[0]);
 
