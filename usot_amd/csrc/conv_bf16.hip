@@ -648,10 +648,13 @@ constexpr int SP_IR = 2 * SP_R + 5, SP_IC = 2 * SP_C + 5;   // 23 x 39 input pat
 constexpr int SP_ICP = 40;                          // padded patch row (elements)
 constexpr int SP_OPB = 144;                         // stem-tile LDS row pitch in bytes (64 ch * 2 + 16)
 
+#ifndef USOT_STEM_MINW
+#define USOT_STEM_MINW 4
+#endif
 template <bool F16>
-__global__ __launch_bounds__(256) void stem_pool_lp_kernel(
+__global__ __launch_bounds__(256, USOT_STEM_MINW) void stem_pool_lp_kernel(
     const float *__restrict__ x, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
-    uint16_t *__restrict__ y, int H, int W, int OH, int OW, int PH, int PW, float mu0, float mu1, float mu2)
+    uint16_t *__restrict__ y, int H, int W, int OH, int OW, int PH, int PW, float mu0, float mu1, float mu2, int strip, int tiles_x)
 {
     // bf16 keeps 8 significant bits: rounding the CROP to bf16 doubles the end-to-end error of the
     // whole backbone (measured 4e-2 -> 8e-2 of the feature scale), so the bf16 variant stages the
@@ -661,94 +664,124 @@ __global__ __launch_bounds__(256) void stem_pool_lp_kernel(
     __shared__ __attribute__((aligned(16))) uint16_t patch[(SPLIT ? 2 : 1) * PLANE];
     __shared__ __attribute__((aligned(16))) unsigned char stile[SP_NBLK * 16 * SP_OPB];
     const int n = blockIdx.z;
-    const int py0 = blockIdx.y * SP_P, px0 = blockIdx.x * SP_Q;
-    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
-    const int iy0 = 2 * sy0, ix0 = 2 * sx0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, quad = lane >> 4;
 
-    // filter fragments: 4 channel blocks x 6 k-steps, 16 bytes each, coalesced
-    u32x4 wf[4][6];
+    // filter fragments: 4 channel blocks x 6 k-steps, 16 bytes each, coalesced.  24 KB per wave: at one tile per workgroup
+    // (8 192 workgroups at batch 64) that is 800 MB of L2 -> CU traffic per launch — more than the launch's HBM bytes ten times
+    // over and ~half its time — so a workgroup walks a STRIP of `strip` tiles along x with the fragments resident.
+    // A wave owns HALF the channels (2 blocks of 16: 48 fragment registers instead of 96 -> four workgroups per CU) and every
+    // other pixel block; a pixel block's B fragments are read from LDS by two waves.
+    const int cb0 = (wave & 1) * 2;
+    u32x4 wf[2][6];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) wf[cb][ks] = wfrag[(cb * 6 + ks) * 64 + lane];
+        for (int ks = 0; ks < 6; ++ks) wf[cb][ks] = wfrag[((cb0 + cb) * 6 + ks) * 64 + lane];
+    __shared__ __attribute__((aligned(16))) float sbias[64];    // read back per pixel block: 16 registers less across the strip
+    if (tid < 64) sbias[tid] = bias[tid];
+
+    for (int tx = blockIdx.x * strip; tx < tiles_x && tx < (int)(blockIdx.x + 1) * strip; ++tx) {
+    if (tx != (int)blockIdx.x * strip) __syncthreads();         // the previous tile's pool has read `stile`
+    const int py0 = blockIdx.y * SP_P, px0 = tx * SP_Q;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
+    const int iy0 = 2 * sy0, ix0 = 2 * sx0;
 
     // input patch -> LDS in the storage type (out-of-image pixels and the pad column are zero;
     // they only ever feed stem pixels the pool masks out, or zero weights)
     const float *xn = x + (long)n * 3 * H * W;
-    // every global load of the patch is issued before the first LDS store (a load -> store loop
-    // serialises ~11 dependent HBM round trips per thread)
-    constexpr int NPL = (3 * SP_IR * SP_ICP + 255) / 256;
-    float pv[NPL];
+    // Four pixels per task: a patch row is 10 segments of 4 (global_load_dwordx4 needs 4-byte alignment only), 69 rows: 690
+    // tasks, 3 rounds of 256 threads, all loads issued before the first LDS store.  (One pixel per task — 11 rounds of index
+    // arithmetic, 22 two-byte LDS stores per thread — was 64 us of the 121 us launch at batch 64, scripts/stem_lp_probe.py.)
+    typedef f32x4 f32x4_a4 __attribute__((aligned(4)));
+    constexpr int SEGS = SP_ICP / 4, NTASK = 3 * SP_IR * SEGS, NPL = (NTASK + 255) / 256;
+    f32x4 pv[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int i = tid + q * 256;
-        const int ci = i / (SP_IR * SP_ICP), r = i - ci * SP_IR * SP_ICP;
-        const int py = r / SP_ICP, px = r - py * SP_ICP;
-        const int iy = iy0 + py, ix = ix0 + px;
-        float v = 0.f;
-        if (i < 3 * SP_IR * SP_ICP && px < SP_IC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            v = xn[((long)ci * H + iy) * W + ix] - (ci == 0 ? mu0 : (ci == 1 ? mu1 : mu2));
+        const int t = tid + q * 256;
+        const int row = t / SEGS, seg = t - row * SEGS;
+        const int ci = row / SP_IR, py = row - ci * SP_IR;
+        const int iy = iy0 + py, ix = ix0 + seg * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#ifndef USOT_SPABL_NOSTAGE     // scripts/stem_lp_probe.py: timing builds with parts of the kernel removed
+        if (t < NTASK && (unsigned)iy < (unsigned)H) {
+            const float *src = xn + ((long)ci * H + iy) * W + ix;
+            const float mu = ci == 0 ? mu0 : (ci == 1 ? mu1 : mu2);
+            if (ix >= 0 && ix + 3 < W) {
+                v = *(const f32x4_a4 *)src - mu;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((unsigned)(ix + e) < (unsigned)W) v[e] = src[e] - mu;
+            }
+        }
+#endif
+        if (seg == SEGS - 1) v[3] = 0.f;             // the pad column only meets zero weights: keep it finite whatever the crop holds
         pv[q] = v;
     }
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int i = tid + q * 256;
-        if (i < 3 * SP_IR * SP_ICP) {
-            const uint32_t hi = pack_lp<F16>(pv[q]);
-            patch[i] = (uint16_t)hi;
-            if constexpr (SPLIT) patch[PLANE + i] = (uint16_t)pack_lp<F16>(pv[q] - unpack_lp<F16>(hi));
+        const int t = tid + q * 256;
+        if (t < NTASK) {
+            const uint32_t h0 = usot_pack2_lp<F16>(pv[q][0], pv[q][1]), h1 = usot_pack2_lp<F16>(pv[q][2], pv[q][3]);
+            *(u32x2 *)(patch + t * 4) = u32x2{h0, h1};
+            if constexpr (SPLIT) {
+                const uint32_t l0 = usot_pack2_lp<F16>(pv[q][0] - unpack_lp<F16>(h0 & 0xffffu), pv[q][1] - unpack_lp<F16>(h0 >> 16));
+                const uint32_t l1 = usot_pack2_lp<F16>(pv[q][2] - unpack_lp<F16>(h1 & 0xffffu), pv[q][3] - unpack_lp<F16>(h1 >> 16));
+                *(u32x2 *)(patch + PLANE + t * 4) = u32x2{l0, l1};
+            }
         }
     }
     __syncthreads();
 
-    f32x4 bv[4];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) bv[cb] = *(const f32x4 *)(bias + cb * 16 + quad * 4);
-
-    for (int blk = wave; blk < SP_NBLK; blk += 4) {
+#ifdef USOT_SPABL_NOMMA
+    for (int blk = wave >> 1; blk < SP_NBLK && H < 0; blk += 2) {
+#else
+    for (int blk = wave >> 1; blk < SP_NBLK; blk += 2) {
+#endif
         int pi = blk * 16 + l15;
         if (pi > SP_NPIX - 1) pi = SP_NPIX - 1;
         const int sy = pi / SP_C, sx = pi - sy * SP_C;
-        f32x4 acc[4];
+        // two accumulation chains per channel block (bf16: the hi and the lo plane of the crop; fp16: even and odd k-steps), so
+        // that four independent MFMAs are in flight; summed at the end
+        f32x4 acc[2][2];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < 2; ++cb) acc[cb][0] = acc[cb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
             int r = 4 * ks + quad;
             if (r > 20) r = 20;                          // zero-weight rows: any valid address
             const int ci = r / 7, kh = r - ci * 7;
+            // (two copies of the patch one dword apart, so that every fragment is two aligned ds_read_b64, were slower: 103 us
+            //  against 98 at batch 64, fp16 76 against 65)
             const uint32_t *src = (const uint32_t *)(patch + (ci * SP_IR + 2 * sy + kh) * SP_ICP + 2 * sx);
-            u32x4 xf;
-            xf[0] = src[0]; xf[1] = src[1]; xf[2] = src[2]; xf[3] = src[3];
+            const u32x4 xf = {src[0], src[1], src[2], src[3]};
             if constexpr (F16) {
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[cb][ks]),
-                                                                     __builtin_bit_cast(f16x8, xf), acc[cb], 0, 0, 0);
+                for (int cb = 0; cb < 2; ++cb)
+                    acc[cb][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[cb][ks]),
+                                                                             __builtin_bit_cast(f16x8, xf), acc[cb][ks & 1], 0, 0, 0);
             } else {
                 const uint32_t *srl = src + PLANE / 2;
-                u32x4 xl;
-                xl[0] = srl[0]; xl[1] = srl[1]; xl[2] = srl[2]; xl[3] = srl[3];
+                const u32x4 xl = {srl[0], srl[1], srl[2], srl[3]};
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cb][ks]),
-                                                                      __builtin_bit_cast(bf16x8, xf), acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cb][ks]),
-                                                                      __builtin_bit_cast(bf16x8, xl), acc[cb], 0, 0, 0);
+                for (int cb = 0; cb < 2; ++cb) {
+                    acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cb][ks]),
+                                                                         __builtin_bit_cast(bf16x8, xf), acc[cb][0], 0, 0, 0);
+                    acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cb][ks]),
+                                                                         __builtin_bit_cast(bf16x8, xl), acc[cb][1], 0, 0, 0);
                 }
             }
         }
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            f32x4 v = acc[cb] + bv[cb];
+        for (int cb = 0; cb < 2; ++cb) {
+            f32x4 v = (acc[cb][0] + acc[cb][1]) + *(const f32x4 *)(sbias + (cb0 + cb) * 16 + quad * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             u32x2 o;
             o[0] = usot_pack2_lp<F16>(v[0], v[1]);
             o[1] = usot_pack2_lp<F16>(v[2], v[3]);
-            *(u32x2 *)(stile + (blk * 16 + l15) * SP_OPB + (cb * 16 + quad * 4) * 2) = o;
+            *(u32x2 *)(stile + (blk * 16 + l15) * SP_OPB + ((cb0 + cb) * 16 + quad * 4) * 2) = o;
         }
     }
     __syncthreads();
@@ -757,7 +790,11 @@ __global__ __launch_bounds__(256) void stem_pool_lp_kernel(
     const int pp = tid >> 3, c8 = tid & 7;
     const int ppy = pp / SP_Q, ppx = pp - ppy * SP_Q;
     const int py = py0 + ppy, px = px0 + ppx;
-    if (py >= PH || px >= PW) return;
+    bool live = py < PH && px < PW;
+#ifdef USOT_SPABL_NOPOOL
+    live = live && H < 0;
+#endif
+    if (live) {
     float m[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
@@ -781,6 +818,8 @@ __global__ __launch_bounds__(256) void stem_pool_lp_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = usot_pack2_lp<F16>(m[2 * e], m[2 * e + 1]);
     *(u32x4 *)(y + ((((long)n * PH + py) * PW + px) * 64 + c8 * 8)) = o;
+    }
+    }
 }
 
 }  // namespace
@@ -892,9 +931,16 @@ extern "C" int usot_stem_pool_lp(void *stream, const float *x, const void *wfrag
     if (OH != (H - 7) / 2 + 1 || OW != (W - 7) / 2 + 1) return USOT_EINVAL;
     if (PH != (OH + 2 - 3) / 2 + 1 || PW != (OW + 2 - 3) / 2 + 1) return USOT_EINVAL;
     if (((uintptr_t)wfrag % 16) || ((uintptr_t)y % 16) || ((uintptr_t)bias % 16) || N > 65535) return USOT_EINVAL;
-    dim3 grid(usot_cdiv(PW, SP_Q), usot_cdiv(PH, SP_P), N);
-    if (dtype) hipLaunchKernelGGL(stem_pool_lp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2);
-    else       hipLaunchKernelGGL(stem_pool_lp_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2);
+    const int tiles_x = usot_cdiv(PW, SP_Q), tiles_y = usot_cdiv(PH, SP_P);
+    // strip length: the longest of 4, 2, 1 that still leaves >= 6 workgroups per CU (three are resident)
+    static int strip_env = -1;
+    if (strip_env < 0) { const char *e = getenv("USOT_STEM_STRIP"); strip_env = e ? atoi(e) : 0; }
+    int strip = 4;
+    while (strip > 1 && (long)usot_cdiv(tiles_x, strip) * tiles_y * N < 6 * 256) strip >>= 1;
+    if (strip_env > 0) strip = strip_env;
+    dim3 grid(usot_cdiv(tiles_x, strip), tiles_y, N);
+    if (dtype) hipLaunchKernelGGL(stem_pool_lp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2, strip, tiles_x);
+    else       hipLaunchKernelGGL(stem_pool_lp_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2, strip, tiles_x);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }
