@@ -103,7 +103,10 @@ int usot_maxpool3x3s2_lp(void *stream, const void *x, void *y, int N, int H, int
 int usot_conv_bf16_tile_count(void);
 /* fused low-precision stem (7x7/s2 conv + BN + ReLU) + 3x3/s2/p1 max-pool on the bf16|fp16 MFMA:
  * modules.py:70-74,138-141 in one launch.  wfrag: filter bank as MFMA A fragments [4][6][64][8].
- * The kernel convolves x - mu[ci]; bias must already contain sum_k w[co][k] * mu[ci(k)]. */
+ * The kernel convolves x - mu[ci]; bias must already contain sum_k w[co][k] * mu[ci(k)].
+ * dtype 0: bf16 fragments, crop as hi + lo bf16 (two MFMAs per fragment), bf16 output; 1: fp16 throughout; 2: fp16
+ * fragments and crop (11 significant bits on both operands, one MFMA per fragment), bf16 OUTPUT — the stem of the bf16
+ * backbone (|x - mu| < 152 and BN-folded stem filters are far inside the fp16 range). */
 int usot_stem_pool_lp(void *stream, const float *x, const void *wfrag, const float *bias, void *y,
                       int N, int H, int W, int OH, int OW, int PH, int PW, int dtype,
                       float mu0, float mu1, float mu2);

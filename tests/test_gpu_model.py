@@ -124,6 +124,28 @@ def test_backbone_bf16_tracks_fp32(net, oracle_sd):
     assert np.corrcoef(got.reshape(-1), ref.reshape(-1))[0, 1] > 0.999
 
 
+def test_bf16_stem_on_the_fp16_mfma_is_not_less_accurate(oracle_sd, capsys):
+    """engine option `stem_f16_math` (default on): the stem of the bf16 backbone rounds crop - mu and the folded filters to
+    fp16 (11 significant bits, one MFMA per fragment) instead of bf16 filters x (hi + lo bf16 crop); both against the fp32
+    oracle on the same crops — the default must not be the less accurate one (beyond noise)."""
+    from usot_amd import engine
+    x = t(synth.crop(40, 2, 255))
+    with torch.no_grad():
+        ref = orc.neck(oracle_sd, orc.backbone(oracle_sd, x)).numpy()
+    errs = {}
+    for flag in (True, False):
+        m = USOT()
+        m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True), strict=True)
+        m.eval()
+        m = m.to(DEV)
+        m.engine_options['options'] = {'stem_f16_math': flag}
+        got = m.engine.features_bf16(x.to(DEV)).float().cpu().numpy()
+        errs[flag] = float(np.abs(got - ref).mean() / np.abs(ref).mean())
+    with capsys.disabled():
+        print('\n[bf16 backbone, mean |err| / mean |ref|] stem on fp16 MFMA %.3e, bf16 hi+lo %.3e' % (errs[True], errs[False]), end='')
+    assert errs[True] < 6e-2 and errs[True] <= 1.15 * errs[False], errs
+
+
 @pytest.mark.parametrize('heads_lp', [False, True], ids=['heads_f32', 'heads_lp'])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['fp16', 'bf16'])
 def test_track_mixed_precision(net, oracle_sd, dtype, heads_lp):

@@ -749,12 +749,14 @@ def test_decode_dev_writes_roi_and_tag(gold_host):
     assert roi.cpu().numpy()[0] == 0.0
 
 
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
-@pytest.mark.parametrize('size,n', [(255, 2), (127, 1), (271, 1), (63, 3)])
-def test_stem_pool_lp(size, n, dtype):
+@pytest.mark.parametrize('dtype,wdtype', [(torch.bfloat16, torch.bfloat16), (torch.float16, torch.float16), (torch.bfloat16, torch.float16)],
+                         ids=['bf16', 'fp16', 'bf16_out_fp16_math'])
+@pytest.mark.parametrize('size,n', [(255, 2), (127, 1), (271, 1), (63, 3), (255, 9)])
+def test_stem_pool_lp(size, n, dtype, wdtype):
     """Fused MFMA stem + max-pool vs torch on the SAME rounded operands (filters rounded to the
-    storage type; crop rounded to fp16, or to hi + lo bf16 pairs; fp32 accumulate): differences are
-    accumulation order + one final rounding, i.e. at most 1 ulp of the storage type."""
+    fragment type; crop rounded to fp16, or to hi + lo bf16 pairs; fp32 accumulate): differences are
+    accumulation order + one final rounding, i.e. at most 1 ulp of the storage type.  Third mode: fp16 fragments and crop,
+    bf16 output (the stem of the bf16 backbone).  (255, 9): enough tiles for strips of 2 per workgroup."""
     from usot_amd.engine import pack_stem_lp
     g = torch.Generator().manual_seed(size + n)
     x = (torch.rand(n, 3, size, size, generator=g) * 2 - 1) * 3
@@ -762,11 +764,11 @@ def test_stem_pool_lp(size, n, dtype):
     w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
     b = torch.randn(64, generator=g) * 0.1
     packed = w.permute(1, 2, 3, 0).reshape(147, 64).contiguous()
-    got = hip.stem_pool_lp(x.to(DEV), pack_stem_lp(packed, dtype).to(DEV), b.to(DEV), dtype, mu).float().cpu()
+    got = hip.stem_pool_lp(x.to(DEV), pack_stem_lp(packed, wdtype).to(DEV), b.to(DEV), dtype, mu).float().cpu()
     xc = x - torch.tensor(mu).view(1, 3, 1, 1)
-    xr, wr = xc.to(dtype).double(), w.to(dtype).double()
-    if dtype == torch.bfloat16:
-        xr = xr + (xc - xc.to(dtype).float()).to(dtype).double()
+    xr, wr = xc.to(wdtype).double(), w.to(wdtype).double()
+    if wdtype == torch.bfloat16:
+        xr = xr + (xc - xc.to(wdtype).float()).to(wdtype).double()
     ref = torch.relu(F.conv2d(xr, wr, b.double(), stride=2)).float().to(dtype).float()
     ref = F.max_pool2d(ref, 3, 2, 1).permute(0, 2, 3, 1)
     assert got.shape == ref.shape

@@ -651,7 +651,7 @@ constexpr int SP_OPB = 144;                         // stem-tile LDS row pitch i
 #ifndef USOT_STEM_MINW
 #define USOT_STEM_MINW 4
 #endif
-template <bool F16>
+template <bool F16, bool O16 = F16>      // F16: the MFMA / staging type; O16: the storage type of the output (fp16 or bf16)
 __global__ __launch_bounds__(256, USOT_STEM_MINW) void stem_pool_lp_kernel(
     const float *__restrict__ x, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
     uint16_t *__restrict__ y, int H, int W, int OH, int OW, int PH, int PW, float mu0, float mu1, float mu2, int strip, int tiles_x)
@@ -779,8 +779,8 @@ __global__ __launch_bounds__(256, USOT_STEM_MINW) void stem_pool_lp_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             u32x2 o;
-            o[0] = usot_pack2_lp<F16>(v[0], v[1]);
-            o[1] = usot_pack2_lp<F16>(v[2], v[3]);
+            o[0] = usot_pack2_lp<O16>(v[0], v[1]);
+            o[1] = usot_pack2_lp<O16>(v[2], v[3]);
             *(u32x2 *)(stile + (blk * 16 + l15) * SP_OPB + ((cb0 + cb) * 16 + quad * 4) * 2) = o;
         }
     }
@@ -809,14 +809,14 @@ __global__ __launch_bounds__(256, USOT_STEM_MINW) void stem_pool_lp_kernel(
             const u32x4 v = *(const u32x4 *)(stile + (ly * SP_C + lx) * SP_OPB + c8 * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                m[2 * e] = fmaxf(m[2 * e], unpack_lp<F16>(v[e] & 0xffffu));
-                m[2 * e + 1] = fmaxf(m[2 * e + 1], unpack_lp<F16>(v[e] >> 16));
+                m[2 * e] = fmaxf(m[2 * e], unpack_lp<O16>(v[e] & 0xffffu));
+                m[2 * e + 1] = fmaxf(m[2 * e + 1], unpack_lp<O16>(v[e] >> 16));
             }
         }
     }
     u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = usot_pack2_lp<F16>(m[2 * e], m[2 * e + 1]);
+    for (int e = 0; e < 4; ++e) o[e] = usot_pack2_lp<O16>(m[2 * e], m[2 * e + 1]);
     *(u32x4 *)(y + ((((long)n * PH + py) * PW + px) * 64 + c8 * 8)) = o;
     }
     }
@@ -927,7 +927,7 @@ extern "C" int usot_stem_pool_lp(void *stream, const float *x, const void *wfrag
                                  int N, int H, int W, int OH, int OW, int PH, int PW, int dtype,
                                  float mu0, float mu1, float mu2)
 {
-    if (!x || !wfrag || !bias || !y || N <= 0 || H < 7 || W < 7 || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
+    if (!x || !wfrag || !bias || !y || N <= 0 || H < 7 || W < 7 || dtype < 0 || dtype > 2) return USOT_EINVAL;
     if (OH != (H - 7) / 2 + 1 || OW != (W - 7) / 2 + 1) return USOT_EINVAL;
     if (PH != (OH + 2 - 3) / 2 + 1 || PW != (OW + 2 - 3) / 2 + 1) return USOT_EINVAL;
     if (((uintptr_t)wfrag % 16) || ((uintptr_t)y % 16) || ((uintptr_t)bias % 16) || N > 65535) return USOT_EINVAL;
@@ -939,7 +939,8 @@ extern "C" int usot_stem_pool_lp(void *stream, const float *x, const void *wfrag
     while (strip > 1 && (long)usot_cdiv(tiles_x, strip) * tiles_y * N < 6 * 256) strip >>= 1;
     if (strip_env > 0) strip = strip_env;
     dim3 grid(usot_cdiv(tiles_x, strip), tiles_y, N);
-    if (dtype) hipLaunchKernelGGL(stem_pool_lp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2, strip, tiles_x);
+    if (dtype == 2) hipLaunchKernelGGL((stem_pool_lp_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2, strip, tiles_x);
+    else if (dtype) hipLaunchKernelGGL(stem_pool_lp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2, strip, tiles_x);
     else       hipLaunchKernelGGL(stem_pool_lp_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (const u32x4 *)wfrag, bias, (uint16_t *)y, H, W, OH, OW, PH, PW, mu0, mu1, mu2, strip, tiles_x);
     USOT_CHECK_LAUNCH();
     return USOT_OK;

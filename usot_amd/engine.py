@@ -137,6 +137,14 @@ class Weights:
             self._stem_lp['f32'] = pack_stem_f32(self.stem_w).to(self.device)
         return self._stem_lp['f32']
 
+    def stem_fits_f16(self):
+        """The folded stem filters are fp16 material: none near the top of the range, and every output channel's largest
+        tap is >= 2^-10, so that the absolute rounding step of the fp16 subnormals (2^-25) stays below 2^-15 of the
+        channel's scale (an all-zero channel is fine)."""
+        a = self.stem_w.detach().abs().float().reshape(147, 64)
+        top = a.max(0).values
+        return bool(a.max() < 16384.0 and ((top >= 2.0 ** -10) | (top == 0)).all())
+
     def stem_lp(self, dtype):
         """(filter fragments in `dtype`, fp32 bias with the folded mu term)."""
         if dtype not in self._stem_lp:
@@ -616,7 +624,10 @@ class Builder:
         oh = (size - 7) // 2 + 1
         ph = (oh - 1) // 2 + 1
         p0 = self.buf(n, ph, ph, 64, dtype=dtype)
-        wf, wb = W.stem_lp(dtype)
+        wdt = dtype
+        if dtype == torch.bfloat16 and self.opt['stem_f16_math'] and W.stem_fits_f16():
+            wdt, dt = torch.float16, 2                 # fp16 arithmetic, bf16 storage
+        wf, wb = W.stem_lp(wdt)
         hip.check(L.usot_plan_add_stem_pool_lp(self.plan.h, hip.ptr(x), hip.ptr(wf), hip.ptr(wb), hip.ptr(p0),
                                                n, size, size, oh, oh, ph, ph, dt, *W.STEM_MU), 'plan_add_stem_pool_lp')
         self.plan.keep += [wf, wb]
@@ -815,6 +826,11 @@ DEFAULT_OPTIONS = {
     # (Cin, Cout) of the 3x3 / stride-1 / pad-1 convolutions of the low-precision backbone that run as direct convolutions
     # from an LDS halo tile (csrc/conv3x3_halo.hip) when the launch has at least one 16 x 16 tile per CU
     'halo_3x3_lp': {(64, 64)},
+    # the stem of the bf16 backbone computes on the fp16 MFMA (crop - mu and the folded filters rounded to 11 significant
+    # bits, one MFMA per fragment) and stores bf16; False: bf16 filters (8 bits) against the crop as hi + lo bf16, two MFMAs
+    # per fragment — less accurate AND 98 instead of 65 us at batch 64.  Falls back by itself when a folded filter leaves
+    # the fp16 normal range.
+    'stem_f16_math': True,
     # (C_mid, C_out, C_next) of the conv3 -> next-1x1 pairs of the low-precision backbone that run as ONE launch of the
     # panel kernel's pair form (Y's accumulators feed the second GEMM from registers); takes precedence over
     # fused_pointwise_lp (csrc/pw_pair.hip: 64-pixel tiles with an LDS image of Y)

@@ -294,15 +294,17 @@ def stem_pool(x, wfrag, bias, mu=(0.0, 0.0, 0.0)):
 def stem_pool_lp(x, wfrag, bias, dtype=torch.bfloat16, mu=(0.0, 0.0, 0.0)):
     """Fused low-precision stem + max-pool: x NCHW fp32 -> NHWC [N][PH][PW][64] in `dtype`;
     wfrag from usot_amd.engine.pack_stem_lp; the kernel convolves x - mu[ci] (bias must hold the
-    folded mu term)."""
-    _dev(x), _dev(wfrag, dtype), _dev(bias)
+    folded mu term).  bf16 output with fp16 fragments = the kernel's mode 2 (fp16 arithmetic, bf16 storage)."""
+    _dev(x), _dev(wfrag, wfrag.dtype), _dev(bias)
+    if wfrag.dtype not in (torch.float16, torch.bfloat16) or (dtype == torch.float16 and wfrag.dtype != dtype):
+        raise HipError('stem_pool_lp: fragments %s for output %s' % (wfrag.dtype, dtype))
     N, c, H, W_ = x.shape
     assert c == 3 and x.is_contiguous()
     OH, OW = (H - 7) // 2 + 1, (W_ - 7) // 2 + 1
     PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
     y = torch.empty((N, PH, PW, 64), device=x.device, dtype=dtype)
     check(lib().usot_stem_pool_lp(stream(), ptr(x), ptr(wfrag), ptr(bias), ptr(y), N, H, W_, OH, OW, PH, PW,
-                                  1 if dtype == torch.float16 else 0, float(mu[0]), float(mu[1]), float(mu[2])),
+                                  1 if dtype == torch.float16 else (2 if wfrag.dtype == torch.float16 else 0), float(mu[0]), float(mu[1]), float(mu[2])),
           'usot_stem_pool_lp')
     return y
 
