@@ -161,6 +161,14 @@ int usot_conv3x3_halo_supported(int Cin, int Cout);
 int usot_plan_add_conv3x3_halo(void *plan, const void *x, const void *w, const float *bias, void *y,
                                int N, int H, int W, int Cin, int Cout, int act, int dtype);
 
+/* Channel-reducing 1x1 convolution of the batched low-precision backbone with the accumulators stationary and K streaming
+ * (csrc/pw_kstream.hip; layer3's conv1 + BN + ReLU 1024 -> 256, modules.py:40-42, and the neck's 1x1 + BN, connect.py:294-300):
+ * y[M][N] = act(x[M][K] . w^T + bias), x / w ([N][K]) / y in the storage type (dtype 0 = bf16, 1 = fp16), bias fp32 or NULL,
+ * act USOT_ACT_NONE | USOT_ACT_RELU.  Shapes: usot_pw_kstream_supported(K, N) ((1024, 256)). */
+int usot_pw_kstream_lp(void *stream, const void *x, const void *w, const float *bias, void *y, long M, int K, int N, int act, int dtype);
+int usot_pw_kstream_supported(int K, int N);
+int usot_plan_add_pw_kstream(void *plan, const void *x, const void *w, const float *bias, void *y, long M, int K, int N, int act, int dtype);
+
 /* the same pair in fp32 for the batch-1 frame (csrc/smallm_f32.hip; v_mfma_f32_16x16x4_f32, 16 pixels per workgroup):
  * every pointer of the descriptor is float32.  w3p / w1 in fragment order: the float at
  * [((cb * (K / 16) + r) * 64 + lane) * 4 + c] is W[cb * 16 + (lane & 15)][16 * r + 4 * (lane >> 4) + c]

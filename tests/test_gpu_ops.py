@@ -987,6 +987,33 @@ def test_bw_probe_kernels_move_the_right_bytes():
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('M,act,bias', [(961 * 3, 1, True), (256 * 5, 0, True), (61504, 1, True), (300, 0, False)])
+def test_pw_kstream_lp_reducing_conv(M, act, bias, dtype):
+    """Accumulator-stationary 1x1 convolution 1024 -> 256 (csrc/pw_kstream.hip: X fragments straight from global memory three
+    k-chunks ahead, W slabs through LDS) against the tiled low-precision conv on the same operands: same products, fp32
+    accumulation in a different order, one final rounding — a few ulp of the storage type; ragged last panels; no bias."""
+    K, N = 1024, 256
+    assert hip.lib().usot_pw_kstream_supported(K, N) == 1 and hip.lib().usot_pw_kstream_supported(256, 1024) == 0
+    g = torch.Generator().manual_seed(M + act)
+    x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(N, K, generator=g) / 32).to(dtype).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV) if bias else None
+    y = torch.full((M + 8, N), 7.0, dtype=dtype, device=DEV)
+    hip.check(hip.lib().usot_pw_kstream_lp(hip.stream(), hip.ptr(x), hip.ptr(w), hip.ptr(b) if bias else None, hip.ptr(y), M, K, N,
+                                           act, 1 if dtype == torch.float16 else 0), 'usot_pw_kstream_lp')
+    ref = x.float() @ w.float().t() + (b if bias else 0.0)
+    if act:
+        ref = torch.relu(ref)
+    got = y[:M].float()
+    ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    err = ((got - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+    assert err <= 1.5 * ulp, err
+    assert (y[M:].float() == 7.0).all()                        # nothing written past the last pixel
+    assert hip.lib().usot_pw_kstream_lp(hip.stream(), hip.ptr(x), hip.ptr(w), None, hip.ptr(y), M, 512, N, act, 0) == -1     # USOT_EINVAL
+
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 @pytest.mark.parametrize('N,H,W,act', [(2, 63, 63, 1), (1, 16, 16, 0), (3, 17, 33, 1), (1, 5, 40, 1)])
 def test_conv3x3_halo_lp(N, H, W, act, dtype):
     """Direct 3x3 convolution from an LDS halo tile (csrc/conv3x3_halo.hip) vs the same rounded operands in float64 and

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define USOT_CHECK_LAUNCH()                                   \
     do {                                                      \
@@ -60,4 +61,13 @@ template <bool F16> __device__ __forceinline__ uint32_t usot_pack2_lp(float a, f
     const usot_f32x2 v = {a, b};
     if constexpr (F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, usot_f16x2));
     else               return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, usot_bf16x2));
+}
+
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}): a loop whose index is a constant expression
+template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
 }

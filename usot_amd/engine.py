@@ -452,6 +452,15 @@ class Builder:
             self.log.append((name, n * oh * ow, cout, k, 1, n * oh * ow * cout * k))
             self.lp_bytes.append(2 * (n * h * w * pc.cin + n * oh * ow * cout * (2 if res is not None else 1) + cout * k))
             return y, oh, ow
+        if (tile == 0 and pc.kh == 1 and pc.kw == 1 and pc.stride == 1 and groups == 1 and not out_f32 and cout == pc.cout
+                and res is None and act in (ACT_NONE, ACT_RELU) and act_split == 0 and (k, cout) in self.opt['kstream_1x1_lp']
+                and hip.lib().usot_pw_kstream_supported(k, cout) and n * oh * ow >= self.opt['panel_min_panels'] * 256):
+            hip.check(hip.lib().usot_plan_add_pw_kstream(self.plan.h, hip.ptr(x), hip.ptr(wb), hip.ptr(pc.b), hip.ptr(y), n * oh * ow,
+                                                         k, cout, act, 1 if dtype == torch.float16 else 0), 'plan_add_pw_kstream ' + name)
+            self.plan.keep += [x, wb, pc.b]
+            self.log.append((name, n * oh * ow, cout, k, 1, n * oh * ow * cout * k))
+            self.lp_bytes.append(2 * (n * h * w * pc.cin + n * oh * ow * cout + cout * k))
+            return y, oh, ow
         if tile == 0:
             tile = LP_TUNING.get((n * oh * ow, cout, k), 0)
         if hasattr(self, 'lp_geoms'):       # scripts/tune_lp.py collects the shapes this way
@@ -826,6 +835,10 @@ DEFAULT_OPTIONS = {
     # (Cin, Cout) of the 3x3 / stride-1 / pad-1 convolutions of the low-precision backbone that run as direct convolutions
     # from an LDS halo tile (csrc/conv3x3_halo.hip) when the launch has at least one 16 x 16 tile per CU
     'halo_3x3_lp': {(64, 64)},
+    # (K, N) of the channel-REDUCING 1x1 convolutions of the low-precision backbone that run with stationary accumulators and
+    # K streaming three chunks ahead (csrc/pw_kstream.hip) when the launch has at least panel_min_panels panels of 256 pixels:
+    # layer3's conv1 and the neck's 1x1 (1024 -> 256)
+    'kstream_1x1_lp': {(1024, 256)},
     # the stem of the bf16 backbone computes on the fp16 MFMA (crop - mu and the folded filters rounded to 11 significant
     # bits, one MFMA per fragment) and stores bf16; False: bf16 filters (8 bits) against the crop as hi + lo bf16, two MFMAs
     # per fragment — less accurate AND 98 instead of 65 us at batch 64.  Falls back by itself when a folded filter leaves
