@@ -169,6 +169,18 @@ int usot_pw_kstream_lp(void *stream, const void *x, const void *w, const float *
 int usot_pw_kstream_supported(int K, int N);
 int usot_plan_add_pw_kstream(void *plan, const void *x, const void *w, const float *bias, void *y, long M, int K, int N, int act, int dtype);
 
+/* 3x3 convolutions with K = 9 Cin >= 2304 of the batched low-precision backbone in the same accumulator-stationary form
+ * (csrc/conv_kstream.hip; layer3's shortcut conv and conv2, layer2's shortcut conv, modules.py:43-46,115-126): a lane is an
+ * output pixel and fetches its MFMA B fragments straight from global memory three k-chunks ahead, W streams through LDS.
+ * x, y NHWC dense, w [Cout][9 Cin] (k = (kh*3 + kw)*Cin + ci) in the storage type (dtype 0 = bf16, 1 = fp16), bias fp32 or
+ * NULL, stride 1 | 2, pad <= dil, act USOT_ACT_NONE | USOT_ACT_RELU.  Shapes: usot_conv_kstream_supported (Cin 256 | 512,
+ * Cout a multiple of 256, 3 x 3). */
+int usot_conv_kstream_lp(void *stream, const void *x, const void *w, const float *bias, void *y,
+                         int N, int H, int W, int Cin, int Cout, int stride, int pad, int dil, int act, int dtype);
+int usot_conv_kstream_supported(int Cin, int Cout, int KH, int KW);
+int usot_plan_add_conv_kstream(void *plan, const void *x, const void *w, const float *bias, void *y,
+                               int N, int H, int W, int Cin, int Cout, int stride, int pad, int dil, int act, int dtype);
+
 /* the same pair in fp32 for the batch-1 frame (csrc/smallm_f32.hip; v_mfma_f32_16x16x4_f32, 16 pixels per workgroup):
  * every pointer of the descriptor is float32.  w3p / w1 in fragment order: the float at
  * [((cb * (K / 16) + r) * 64 + lane) * 4 + c] is W[cb * 16 + (lane & 15)][16 * r + 4 * (lane >> 4) + c]

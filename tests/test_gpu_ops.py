@@ -987,6 +987,50 @@ def test_bw_probe_kernels_move_the_right_bytes():
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride,pad,dil,act', [
+    (2, 31, 31, 256, 256, 1, 2, 2, 1),        # layer3.1-5 conv2 (dilation 2)
+    (1, 31, 31, 256, 256, 1, 1, 1, 1),        # layer3.0 conv2
+    (2, 31, 31, 512, 1024, 1, 1, 1, 0),       # layer3's shortcut conv
+    (2, 63, 63, 256, 512, 2, 0, 1, 0),        # layer2's shortcut conv (stride 2, no padding)
+    (1, 7, 9, 256, 256, 1, 1, 1, 1),          # one ragged panel, every border case
+    (3, 16, 16, 256, 512, 1, 1, 2, 1)])       # pad < dil
+def test_conv_kstream_lp(N, H, W, Cin, Cout, stride, pad, dil, act, dtype):
+    """Accumulator-stationary implicit GEMM for the K >= 2304 3x3 convolutions (csrc/conv_kstream.hip: a lane is a pixel, B
+    fragments straight from global memory, padding taps parked on the centre pixel and zeroed after landing) against the
+    tiled low-precision kernel on the same operands (within 1 ulp of the storage type: same products, another fp32 order) and
+    against float64 on the rounded operands."""
+    import ctypes as Ct
+    L = hip.lib()
+    assert L.usot_conv_kstream_supported(Cin, Cout, 3, 3) == 1 and L.usot_conv_kstream_supported(64, 256, 3, 3) == 0
+    g = torch.Generator().manual_seed(N + H * 7 + Cin + Cout + stride + dil)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dtype)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (3 * Cin ** 0.5)).to(dtype)
+    b = torch.randn(Cout, generator=g) * 0.1
+    OH, OW = (H + 2 * pad - 2 * dil - 1) // stride + 1, (W + 2 * pad - 2 * dil - 1) // stride + 1
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), stride=stride, padding=pad,
+                   dilation=dil).permute(0, 2, 3, 1)
+    if act:
+        ref = ref.relu()
+    xd, wd, bd = x.to(DEV), w.reshape(Cout, 9 * Cin).contiguous().to(DEV), b.to(DEV)
+    M = N * OH * OW
+    y = torch.full((M + 2, Cout), 5.0, dtype=dtype, device=DEV)
+    dt = 1 if dtype == torch.float16 else 0
+    hip.check(L.usot_conv_kstream_lp(hip.stream(), hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), hip.ptr(y), N, H, W, Cin, Cout, stride, pad, dil,
+                                     act, dt), 'conv_kstream')
+    assert torch.all(y[M:] == 5.0)
+    got = y[:M].reshape(N, OH, OW, Cout).float()
+    tol = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    assert float(((got.cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= tol * 1.01
+    y2 = torch.empty(N, OH, OW, Cout, dtype=dtype, device=DEV)
+    d = hip.conv_desc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y2.data_ptr(), N=N, H=H, W=W, Cin=Cin, OH=OH, OW=OW, Cout=Cout,
+                      KH=3, KW=3, stride=stride, pad=(pad, pad), dil=(dil, dil), act=act, tile=13)
+    hip.check(L.usot_conv2d_lp(hip.stream(), Ct.byref(d), dt, 0), 'tiled')
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert float(((got - y2.float()).abs() / y2.float().abs().clamp_min(0.25)).max()) <= ulp
+    assert L.usot_conv_kstream_lp(hip.stream(), hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), hip.ptr(y), N, H, W, Cin, Cout, stride, 3, 1, act, dt) == -1   # pad > dil
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 @pytest.mark.parametrize('M,act,bias', [(961 * 3, 1, True), (256 * 5, 0, True), (61504, 1, True), (300, 0, False)])
 def test_pw_kstream_lp_reducing_conv(M, act, bias, dtype):
     """Accumulator-stationary 1x1 convolution 1024 -> 256 (csrc/pw_kstream.hip: X fragments straight from global memory three

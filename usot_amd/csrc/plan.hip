@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3, K_PW3, K_PANEL, K_PANELP, K_HALO, K_KSTREAM };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3, K_PW3, K_PANEL, K_PANELP, K_HALO, K_KSTREAM, K_CKSTREAM };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -113,6 +113,10 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
         case K_HALO:
             rc = usot_conv3x3_halo_lp(s, op.p[0], op.p[1], (const float *)op.p[2], (void *)op.p[3], op.i[0], op.i[1], op.i[2], op.i[3],
                                       op.i[4], op.i[5], op.i[6]);
+            break;
+        case K_CKSTREAM:
+            rc = usot_conv_kstream_lp(s, op.p[0], op.p[1], (const float *)op.p[2], (void *)op.p[3], op.i[0], op.i[1], op.i[2], op.i[3],
+                                      op.i[4], op.i[5], op.i[7], (int)op.l[0], (int)op.l[1], op.i[6]);
             break;
         case K_KSTREAM:
             rc = usot_pw_kstream_lp(s, op.p[0], op.p[1], (const float *)op.p[2], (void *)op.p[3], op.l[0], op.i[1], op.i[2], op.i[3], op.i[6]);
@@ -295,6 +299,18 @@ extern "C" int usot_plan_add_conv3x3_halo(void *plan, const void *x, const void 
     if (!op) return USOT_ESTATE;
     op->p[0] = x; op->p[1] = w; op->p[2] = bias; op->p[3] = y;
     op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = Cin; op->i[4] = Cout; op->i[5] = act; op->i[6] = dtype;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_conv_kstream(void *plan, const void *x, const void *w, const float *bias, void *y,
+                                          int N, int H, int W, int Cin, int Cout, int stride, int pad, int dil, int act, int dtype)
+{
+    if (!usot_conv_kstream_supported(Cin, Cout, 3, 3)) return USOT_EINVAL;
+    Op *op = push(plan, K_CKSTREAM);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = x; op->p[1] = w; op->p[2] = bias; op->p[3] = y;
+    op->i[0] = N; op->i[1] = H; op->i[2] = W; op->i[3] = Cin; op->i[4] = Cout; op->i[5] = stride; op->i[7] = pad; op->i[6] = dtype;
+    op->l[0] = dil; op->l[1] = act;
     return USOT_OK;
 }
 

@@ -452,6 +452,17 @@ class Builder:
             self.log.append((name, n * oh * ow, cout, k, 1, n * oh * ow * cout * k))
             self.lp_bytes.append(2 * (n * h * w * pc.cin + n * oh * ow * cout * (2 if res is not None else 1) + cout * k))
             return y, oh, ow
+        if (tile == 0 and pc.kh == 3 and pc.kw == 3 and groups == 1 and not out_f32 and cout == pc.cout and res is None
+                and act in (ACT_NONE, ACT_RELU) and act_split == 0 and (pc.cin, cout) in self.opt['kstream_3x3_lp']
+                and pc.pad[0] == pc.pad[1] and pc.dil[0] == pc.dil[1] and pc.pad[0] <= pc.dil[0] and pc.stride in (1, 2)
+                and hip.lib().usot_conv_kstream_supported(pc.cin, cout, 3, 3) and n * oh * ow >= self.opt['panel_min_panels'] * 256):
+            hip.check(hip.lib().usot_plan_add_conv_kstream(self.plan.h, hip.ptr(x), hip.ptr(wb), hip.ptr(pc.b), hip.ptr(y), n, h, w,
+                                                           pc.cin, cout, pc.stride, pc.pad[0], pc.dil[0], act,
+                                                           1 if dtype == torch.float16 else 0), 'plan_add_conv_kstream ' + name)
+            self.plan.keep += [x, wb, pc.b]
+            self.log.append((name, n * oh * ow, cout, k, 1, n * oh * ow * cout * k))
+            self.lp_bytes.append(2 * (n * h * w * pc.cin + n * oh * ow * cout + cout * k))
+            return y, oh, ow
         if (tile == 0 and pc.kh == 1 and pc.kw == 1 and pc.stride == 1 and groups == 1 and not out_f32 and cout == pc.cout
                 and res is None and act in (ACT_NONE, ACT_RELU) and act_split == 0 and (k, cout) in self.opt['kstream_1x1_lp']
                 and hip.lib().usot_pw_kstream_supported(k, cout) and n * oh * ow >= self.opt['panel_min_panels'] * 256):
@@ -839,6 +850,12 @@ DEFAULT_OPTIONS = {
     # K streaming three chunks ahead (csrc/pw_kstream.hip) when the launch has at least panel_min_panels panels of 256 pixels:
     # layer3's conv1 and the neck's 1x1 (1024 -> 256)
     'kstream_1x1_lp': {(1024, 256)},
+    # (Cin, Cout) of the 3x3 convolutions with K >= 2304 that run in the same accumulator-stationary form (csrc/conv_kstream.hip).
+    # EMPTY by default: parity-green but 5-8 % slower than the tiled 256 x 256 kernel on all three candidates at batch 64 —
+    # layer3's shortcut conv (512, 1024) 494 vs 456 us, its conv2 (256, 256) 72 vs 68, layer2's shortcut conv (256, 512) 158 vs
+    # 151: the B fragments fetched straight from global memory are 16 rows x 64 B per instruction and for a 3x3 conv they are
+    # L2 hits nine times over, which the texture path serves worse than the LDS-DMA's whole lines
+    'kstream_3x3_lp': set(),
     # the stem of the bf16 backbone computes on the fp16 MFMA (crop - mu and the folded filters rounded to 11 significant
     # bits, one MFMA per fragment) and stores bf16; False: bf16 filters (8 bits) against the crop as hi + lo bf16, two MFMAs
     # per fragment — less accurate AND 98 instead of 65 us at batch 64.  Falls back by itself when a folded filter leaves
