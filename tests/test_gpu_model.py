@@ -323,11 +323,21 @@ def test_engine_options_are_enumerable_and_checked():
         engine.merged_options({'no_such_switch': 1})
 
 
-def test_backbone_bf16_batch64_tracks_fp32(net, oracle_sd):
+@pytest.mark.parametrize('lp_options', [{}, {'kstream_3x3_lp': {(512, 1024), (256, 256), (256, 512)}, 'halo_3x3_lp': set(), 'kstream_1x1_lp': set()}],
+                         ids=['default', 'kstream3x3_no_halo_no_kstream1x1'])
+def test_backbone_bf16_batch64_tracks_fp32(net, oracle_sd, lp_options):
     """BASELINE configs[2] at its real batch: 64 crops through the bf16 MFMA backbone + neck; a strided
-    subset of the batch is checked against the float32 oracle (the oracle needs ~1 s per crop)."""
+    subset of the batch is checked against the float32 oracle (the oracle needs ~1 s per crop).  Second configuration: the
+    large-batch lowering switches flipped (the K >= 2304 3x3 convs on csrc/conv_kstream.hip, layer1's 3x3 and layer3's 1x1
+    reductions back on the tiled kernel) — these routes only exist at this batch size."""
     if not net.engine_options.get('graphs', True):
         pytest.skip('one engine configuration is enough for the batch-64 run')
+    if lp_options:
+        net = USOT()
+        net.load_state_dict(synth.torch_state_dict(net, seed=0, calibrated=True), strict=True)
+        net.eval()
+        net = net.to(DEV)
+        net.engine_options['options'] = lp_options
     x = t(synth.crop(42, 64, 255))
     got = net.engine.features_bf16(x.to(DEV)).float().cpu().numpy()
     assert got.shape == (64, 256, 31, 31) and np.isfinite(got).all()
