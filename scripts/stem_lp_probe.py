@@ -23,11 +23,6 @@ if sys.argv[1:] == ['build']:
         os.remove(obj)
     sys.exit(0)
 if sys.argv[1:] == ['run']:
-    for strip in (1, 2, 4, 8):
-        for name in ('full', 'minw3'):
-            subprocess.check_call([sys.executable, os.path.abspath(__file__), 'one', '%s strip %d' % (name, strip)],
-                                  env=dict(os.environ, USOT_STEM_STRIP=str(strip), USOT_HIP_LIB=os.path.join(OUT, 'libusot_sp_%s.so' % name)))
-    os.environ['USOT_STEM_STRIP'] = '4'
     for name in VARIANTS:
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'one', name], env=dict(os.environ, USOT_HIP_LIB=os.path.join(OUT, 'libusot_sp_%s.so' % name)))
     sys.exit(0)
