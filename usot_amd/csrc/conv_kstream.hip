@@ -4,7 +4,8 @@
 //   * a workgroup (8 waves) owns 256 output pixels x 256 output channels; a wave keeps its 32 pixels x 256 channels in 128
 //     accumulator registers for all of K;
 //   * X never touches LDS: a lane IS a pixel — it fetches the MFMA B fragments (16 bytes: 8 consecutive input channels of its
-//     pixel's tap) straight from global memory, three 64-deep k-chunks ahead; a padding tap reads a zero page;
+//     pixel's tap) straight from global memory, three 64-deep k-chunks ahead; a padding tap re-reads the lane's centre
+//     pixel and is zeroed once it has landed;
 //   * W streams through LDS in slabs of 256 channels x 64 k (LDS-DMA, ring of three), an A fragment feeds two MFMAs;
 //   * every vector-memory operation of the loop is inline asm under counted s_waitcnt vmcnt(8): the tiled kernel's
 //     [DMA, fragment reads, MFMAs, vmcnt(0) + barrier] per k-tile leaves the matrix pipe 67 % busy —
@@ -29,8 +30,6 @@ struct CKStreamK {
     uint16_t *y;
     int N, H, W, OH, OW, Cout, stride, pad, dil, act, M, npanels, NT;
 };
-
-__device__ __attribute__((aligned(16))) uint32_t ck_zero[512] = {0u};      // 2 KB of zeros: the source of padding taps (+ offsets)
 
 template <bool F16> __device__ __forceinline__ f32x4 ck_mfma(u32x4 a, u32x4 b, f32x4 c)
 {
@@ -58,7 +57,7 @@ __global__ __launch_bounds__(512) void conv_kstream_kernel(const CKStreamK p)
     constexpr int NI = SLAB / 512;                  // DMA instructions per thread and slab (4)
     constexpr int NV = 4 + NI;
     constexpr int HEAD = (CK_BN / 4 > CC * 8 ? CK_BN / 4 : CC * 8);     // bias, and room for M0 = destination - instruction offset
-    static_assert(CIN % 64 == 0 && RC % CK_S == 0 && CC >= 2 && CC * 128 + 64 + 16 <= 2048, "shape");
+    static_assert(CIN % 64 == 0 && RC % CK_S == 0 && CC >= 2 && CC * 128 + 64 + 16 <= 4096, "shape (instruction offsets are 13-bit signed)");
     extern __shared__ __attribute__((aligned(16))) u32x4 ck_lds[];
     u32x4 *slabs = ck_lds + HEAD;
 
