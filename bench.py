@@ -111,22 +111,24 @@ def roofline(sess, frames):
     """Dominant kernel = the conv_igemm_f32 tile instance with the largest total time."""
     prof = sess.plan.profile(frames=frames, reps=1)      # every op once per pass, in frame order (cold operands, as in a replay)
     tiles = hip.tile_table()
-    convs = iter(sess.log)
-    agg, total_ms, conv_ms, conv_flops = {}, 0.0, 0.0, 0.0
+    convs = iter(zip(sess.log, sess.f32_bytes))
+    agg, total_ms, conv_ms, conv_flops, conv_bytes = {}, 0.0, 0.0, 0.0, 0
     for kind, tile, ks, groups, ms in prof:
         total_ms += ms
         if kind not in (0, K_PWPAIR, K_PW1, K_SC3, K_PW3):
             continue
-        name, M, N, K, g, macs = next(convs)
+        (name, M, N, K, g, macs), nbytes = next(convs)
         conv_ms += ms
         conv_flops += 2.0 * macs
+        conv_bytes += nbytes
         if kind in (K_PWPAIR, K_PW1, K_SC3, K_PW3):   # csrc/smallm_f32.hip kernels: counted in all_convs,
             continue                              # not a tile instance of the conv_igemm family
-        a = agg.setdefault(tile, [0, 0.0, 0.0])
+        a = agg.setdefault(tile, [0, 0.0, 0.0, 0])
         a[0] += 1
         a[1] += ms
         a[2] += 2.0 * macs
-    tile, (n, ms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
+        a[3] += nbytes
+    tile, (n, ms, fl, alg_bytes) = max(agg.items(), key=lambda kv: kv[1][1])
     ach = fl / (ms * 1e-3) / 1e12
     # HBM bytes per launch cannot be counted from inside this process: they come from the committed
     # rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by scripts/pmc_to_traffic.py with the
@@ -141,9 +143,16 @@ def roofline(sess, frames):
                           % pmc.get('_meta', {}).get('commit', 'round1')
     except Exception:
         pass
+    busy = pmc_busy(hip.tile_name(tile), MFMA_F32_PEAK_TFLOPS)
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+        'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), **busy_fields(busy, ach),
+        'traffic': traffic, 'traffic_source': traffic_src,
+        # algorithmic bytes: every launch's input map, filter bank, bias and result (+ residual) once — SURVEY 8(d); the
+        # measured traffic above it is Infinity-Cache-served re-reads of the activations by each XCD's L2 (~150 FLOP/B:
+        # not the limiter of this kernel)
+        'algorithmic_bytes_per_launch': int(alg_bytes / n),
+        'traffic_to_algorithmic': round(traffic / (alg_bytes / n), 3) if traffic else None,
         'kernel': hip.tile_name(tile), 'launches_per_frame': n,
         'avg_launch_us': round(ms / n * 1e3, 2), 'algorithmic_gflop_per_frame': round(fl / 1e9, 3),
         'all_convs': {'gflop_per_frame': round(conv_flops / 1e9, 3), 'us_per_frame': round(conv_ms * 1e3, 1),
@@ -151,6 +160,28 @@ def roofline(sess, frames):
                       'frac': round(conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
         'frame_op_spans_us': round(total_ms * 1e3, 1),
     }
+
+
+def pmc_busy(kernel, peak):
+    """Clock and matrix-pipe utilisation of `kernel` from the committed `rocprofv3 --pmc SQ_BUSY_CYCLES
+    SQ_VALU_MFMA_BUSY_CYCLES` pass (profiles/pmc_busy.json, scripts/pmc_busy.py): the sustained clock under this kernel's
+    load is SQ_BUSY_CYCLES / duration, and `peak_sustained` = the nominal peak scaled by it (the nominal peak assumes
+    2.4 GHz; MFMA-dense kernels run at 1.8-2.1 GHz).  None when that kernel was not profiled."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_busy.json')) as f:
+            pj = json.load(f)
+        e = pj['kernels'][kernel]
+        return {'clock_ghz': e['clock_ghz'], 'mfma_busy': e['mfma_busy_frac'], 'peak_sustained': round(peak * e['clock_ghz'] / 2.4, 1),
+                'source': 'profiles/pmc_busy.json@%s' % pj.get('_meta', {}).get('commit', '')}
+    except Exception:
+        return None
+
+
+def busy_fields(busy, ach):
+    if not busy:
+        return {'peak_sustained': None}
+    return {'peak_sustained': busy['peak_sustained'], 'frac_of_sustained': round(ach / busy['peak_sustained'], 4),
+            'clock_ghz': busy['clock_ghz'], 'mfma_busy': busy['mfma_busy'], 'busy_source': busy['source']}
 
 
 def xcorr_bandwidth(device, sizes=(2048, 128), iters=20):
@@ -208,7 +239,8 @@ def hbm_ceiling_probe(device, gib=2, iters=10):
         torch.cuda.synchronize()
         out[name] = round(moved / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9, 1)
     out['unit'] = 'GB/s'
-    out['what'] = '%d GiB buffers, 16 B per lane; mix_4r_1w = GroupDW byte mix (one interleaved read stream, non-temporal stores)' % gib
+    out['what'] = ('%d GiB buffers, 16 B per lane; read = 8 non-temporal loads in flight per lane; copy = 32 KiB block spans, non-temporal '
+                   'loads and stores; mix_4r_1w = GroupDW byte mix (one interleaved read stream, non-temporal stores)' % gib)
     return out
 
 
@@ -316,6 +348,7 @@ def cpu_baseline(budget_s=14.0):
                               'sample': '%d frames in %.1f s, torch.set_num_threads(1)' % (n1, dt1)}}
 
 
+LP_DOMINANT_KERNEL = 'conv_igemm_bf16<256, 256, 4, 4, false, 0, 2, 16>'     # as scripts/pmc_busy.py keys it
 BF16_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF is 2:1 sparse)
 BACKBONE_GFLOP = 28.192642        # one 255^2 crop through stem..layer3
 
@@ -375,7 +408,10 @@ def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, 
                     'fp32 accumulate, one hipGraph' % (batch, size, size),
         'value': round(batch * n / dt, 1), 'unit': 'crops/s', 'steps': n, 'ms_per_step': round(dt / n * 1e3, 3),
         'roofline': {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(ach / BF16_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': tsrc,
+                     'frac': round(ach / BF16_PEAK_TFLOPS, 4),
+                     # clock / matrix-pipe utilisation of the step's dominant MFMA kernel (the 256 x 256 tile of the K >= 2304 convs)
+                     **busy_fields(pmc_busy(LP_DOMINANT_KERNEL, BF16_PEAK_TFLOPS), ach),
+                     'traffic': traffic, 'traffic_source': tsrc,
                      'algorithmic_bytes_per_step': int(alg_bytes),
                      'traffic_to_algorithmic': round(traffic / alg_bytes, 3) if traffic else None,
                      'hbm_gbs_at_algorithmic_bytes': round(alg_bytes / (dt / n) / 1e9, 1),
@@ -445,6 +481,18 @@ def measure_lockstep_f32(model, device, batch=4, size=255, steps=0, min_seconds=
                         'resident' % batch,
             'value': round(batch * n / dt, 1), 'unit': 'frames/s', 'batch': batch, 'steps': n,
             'ms_per_step': round(dt / n * 1e3, 4), 'dtype': 'f32'}
+
+
+def measure_track_271(model, device, warmup=30, min_seconds=1.0):
+    """The headline frame at the reference's other instance size (271 x 271 search crops, 27 x 27 response: SURVEY 8f rank 4,
+    experiments/test/USOT.yaml's online-update sizes): same per-frame device path and loop as `value`."""
+    sess, crops, p = open_stream(model, device, seed=900, size=271)
+    conf = Confidences()
+    run_frames(sess, crops, p, conf, warmup)
+    n, dt = _timed(lambda: run_frames(sess, crops, p, conf, 1), min_seconds)
+    return {'workload': 'configs[1] at instance size 271: batch=1 fp32 frame (backbone + heads N_q=7 + decode + PrRoIPool), 27x27 response',
+            'value': round(n / dt, 1), 'unit': 'frames/s', 'steps': n, 'ms_per_step': round(dt / n * 1e3, 4), 'dtype': 'f32',
+            'search': 271}
 
 
 def track_mixed(a, rank, world, device):
@@ -598,6 +646,8 @@ def main():
                             'lock step, N_q=7, one hipGraph', 'value': round(32 * n / t, 1), 'unit': 'frames/s',
                 'steps': n, 'ms_per_step': round(t / n * 1e3, 3), 'dtype': 'fp16+f32'}
             line['lockstep_f32_b4'] = measure_lockstep_f32(model, device, 4, a.size)
+            if a.size != 271:
+                line['track_271'] = measure_track_271(model, device)
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line))

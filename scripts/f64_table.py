@@ -7,7 +7,7 @@ import f64_gate
 from usot_amd import synth
 from usot_amd.model import USOT
 gold = f64_gate.load()
-for fam in ('zero_dc', 'dc'):
+for fam in synth.FAMILIES:
     m = USOT(); m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True, family=fam), strict=True); m.eval(); m = m.to('cuda:0')
     rows = f64_gate.table(gold, fam, f64_gate.run_model(m))
     print(f64_gate.fmt(fam, rows))

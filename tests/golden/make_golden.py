@@ -571,7 +571,18 @@ def do_model64():
         for nm, ten in zip(('cls', 'bbox', 'cls_mem'), res):
             out['track_mem_b2/' + nm] = ten.numpy()
         return out
-    for fam in ('zero_dc', 'dc'):
+    path = os.path.join(GOLD, 'golden_model_f64.npz')
+    if os.path.exists(path) and os.environ.get('USOT_GOLDEN_REGEN') != '1':
+        # families already in the fixture are kept as committed (only missing ones are computed): adding the third family
+        # in round 4 must not touch the entries rounds 2-3 were gated on
+        with np.load(path) as z:
+            g.update({k: z[k] for k in z.files})
+    for fam in synth.FAMILIES:
+        if any(k.startswith(fam + '/') for k in g):
+            print('%s: kept (%d arrays)' % (fam, sum(k.startswith(fam + '/') for k in g)))
+            continue
+        if not os.path.exists(synth.calib_file(fam)):
+            do_calib(fam)
         net, _ = build(calibrated=True, family=fam)
         net.eval()
         net.pr_pool = False
@@ -580,7 +591,7 @@ def do_model64():
             o64 = run(net.double(), lambda a: a.double())
         for k in o32:
             put(fam, k, o32[k], o64[k])
-    np.savez_compressed(os.path.join(GOLD, 'golden_model_f64.npz'), **g)
+    np.savez_compressed(path, **g)
     print('float64 goldens: %d arrays, %.1f KB' % (len(g), os.path.getsize(os.path.join(GOLD, 'golden_model_f64.npz')) / 1024))
 
 

@@ -33,9 +33,15 @@ def check(name, gold, arr, rtol, atol_scale=1.0):
         ref, got = gold[name + '/full'], a
     else:
         ref, got = gold[name + '/samp'], a.reshape(-1)[sample_index(name, a.size)]
-        st = gold[name + '/stats']
+        st = gold[name + '/stats']                      # mean, mean|.|, std, max|.| of the WHOLE tensor (float64)
         f = a.reshape(-1)
         assert abs(f.mean(dtype=np.float64) - st[0]) <= rtol * (abs(st[1]) + 1e-12) * 4, (name, 'mean')
+        # whole-tensor second moment and extreme value: an error confined to elements the 2 048 sample points miss (one bad
+        # tile, one bad channel) moves these.  Element-wise errors <= rtol x max(|ref|, mean|ref|) bound the change of the std by
+        # rtol x sqrt(std^2 + 2 mean|.|^2) (triangle inequality on the centred vectors) and of the maximum by rtol x max|.|.
+        assert abs(f.std(dtype=np.float64) - st[2]) <= rtol * np.sqrt(st[2] ** 2 + 2 * st[1] ** 2) * 2 + 1e-12, \
+            (name, 'std', float(f.std(dtype=np.float64)), float(st[2]))
+        assert abs(float(np.abs(f).max()) - st[3]) <= rtol * st[3] * 2 + 1e-12, (name, 'max|.|', float(np.abs(f).max()), float(st[3]))
     scale = np.maximum(np.abs(ref), atol_scale * np.abs(ref).mean() + 1e-30)
     err = float(np.max(np.abs(got - ref) / scale))
     assert err <= rtol, '%s: scaled error %.3e > %.1e' % (name, err, rtol)

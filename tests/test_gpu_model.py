@@ -257,7 +257,7 @@ def test_second_weight_family_vs_float64(family, capsys):
             print('\n[family %-7s] %-7s HIP vs f64 %.2e | reference f32 vs f64 %.2e | HIP vs reference f32 %.2e' % (family, nm, a, b, c), end='')
 
 
-@pytest.mark.parametrize('family', ['zero_dc', 'dc'])
+@pytest.mark.parametrize('family', list(synth.FAMILIES))
 def test_every_fixture_within_1p5x_of_the_references_own_float32_error(family, capsys):
     """THE acceptance rule for float32 kernels (tests/golden/f64_gate.py): on both weight families, every whole-model
     fixture (backbone stages at 127 / 255 / 271 / batch 2, template, offline and memory tracking at 255 / 271 / batch 2)
@@ -295,7 +295,7 @@ def test_engine_option_variants_keep_parity(variant, capsys):
     from usot_amd import engine
     assert set(variant) <= set(engine.DEFAULT_OPTIONS)
     gold = f64_gate.load()
-    for family in ('zero_dc', 'dc'):
+    for family in synth.FAMILIES:             # 'alt' (round 4): independently seeded, the rule was not derived on it
         m = USOT()
         m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True, family=family), strict=True)
         m.eval()

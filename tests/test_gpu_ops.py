@@ -976,6 +976,10 @@ def test_bw_probe_kernels_move_the_right_bytes():
     hip.check(L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, 1), 'copy')
     assert torch.equal(dst, src)
     dst.zero_()
+    ragged = n - 3 * 4096                                   # not a multiple of the copy's 32 KiB block span
+    hip.check(L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), ragged, 1), 'copy (ragged)')
+    assert torch.equal(dst[:ragged // 4], src[:ragged // 4]) and float(dst[ragged // 4:].abs().max()) == 0.0
+    dst.zero_()
     hip.check(L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, 2), 'mix')
     v = src.view(-1, 4, 64, 4)                              # [group][row of the group][element][4 floats]
     want = (v[:, 0] + v[:, 1]) + (v[:, 2] + v[:, 3])
@@ -1031,7 +1035,8 @@ def test_conv_kstream_lp(N, H, W, Cin, Cout, stride, pad, dil, act, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
-@pytest.mark.parametrize('M,act,bias', [(961 * 3, 1, True), (256 * 5, 0, True), (61504, 1, True), (300, 0, False)])
+@pytest.mark.parametrize('M,act,bias', [(961 * 3, 1, True), (256 * 5, 0, True), (61504, 1, True), (300, 0, False),
+                                        (70000, 1, True)])      # > 256 panels: the persistent loop's second trip
 def test_pw_kstream_lp_reducing_conv(M, act, bias, dtype):
     """Accumulator-stationary 1x1 convolution 1024 -> 256 (csrc/pw_kstream.hip: X fragments straight from global memory three
     k-chunks ahead, W slabs through LDS) against the tiled low-precision conv on the same operands: same products, fp32

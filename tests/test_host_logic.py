@@ -238,3 +238,22 @@ def test_stem_fragment_packing_is_a_plain_convolution():
                     for t8 in range(8):
                         acc += float(lp[cb, ks, q * 16 + l15, t8]) * float(xp[ci, 2 * sy + kh, 2 * sx + t8])
             assert abs(acc - float(ref[co, sy, sx])) < 1e-4 * max(1.0, abs(float(ref[co, sy, sx])))
+
+
+def test_conf_tail_split_option_is_validated():
+    """engine.merged_options refuses a (tail, ksplit) pair that would build an empty or unsplit tail convolution."""
+    from usot_amd import engine, hip
+    assert engine.merged_options({'conf_tail_split': None})['conf_tail_split'] is None
+    assert engine.merged_options({'conf_tail_split': (2, 3)})['conf_tail_split'] == (2, 3)
+    for bad in ((0, 2), (1, 1), (1, 0), (1,), 'x', (1.5, 2), (True, 2)):
+        with pytest.raises(hip.HipError):
+            engine.merged_options({'conf_tail_split': bad})
+
+
+def test_raw_pixel_range_check_guards_the_fp16_stem():
+    """The bf16 backbone's fp16-arithmetic stem is adequate for raw 0..255 crops only (engine.looks_like_raw_pixels)."""
+    import torch
+    from usot_amd import engine, synth
+    assert engine.looks_like_raw_pixels(torch.from_numpy(synth.crop(1, 1, 127)))
+    assert not engine.looks_like_raw_pixels(torch.rand(1, 3, 127, 127))                 # [0, 1]-normalised
+    assert not engine.looks_like_raw_pixels(torch.randn(1, 3, 127, 127) * 50)           # mean/std-normalised, signed

@@ -15,14 +15,21 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// Round 4 (scripts/probes/copy_probe.hip, 2 GiB, random and constant fills alike): a read needs EIGHT non-temporal 16-byte
+// loads in flight per lane to reach this box's ceiling (6.25-6.37 TB/s; four plain loads: 5.5-5.8), and a copy block-contiguous
+// 32 KiB spans with non-temporal loads AND stores (5.40-5.49 TB/s from 512 blocks up; the plain grid-stride copy this probe
+// used before reads 4.5-4.8 at 2048-8192 blocks and 5.45 only at exactly four resident blocks per CU).
 __global__ __launch_bounds__(256) void bw_read_kernel(const f4 *__restrict__ x, float *sink, long n4)
 {
     f4 a = {0.f, 0.f, 0.f, 0.f};
     const long stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const f4 v0 = x[i], v1 = x[i + stride], v2 = x[i + 2 * stride], v3 = x[i + 3 * stride];
-        a += v0 + v1 + v2 + v3;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(x + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
     }
     for (; i < n4; i += stride) a += x[i];
     if (a[0] + a[1] + a[2] + a[3] == 123.456f) sink[0] = a[0];        // keeps the loads live, never true in practice
@@ -30,7 +37,17 @@ __global__ __launch_bounds__(256) void bw_read_kernel(const f4 *__restrict__ x, 
 
 __global__ __launch_bounds__(256) void bw_copy_kernel(const f4 *__restrict__ x, f4 *__restrict__ y, long n4)
 {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) y[i] = x[i];
+    constexpr int U = 8;
+    const long span = 256L * U;                                        // 32 KiB per block and trip
+    long base = (long)blockIdx.x * span;
+    for (; base + span <= n4; base += (long)gridDim.x * span) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(x + base + u * 256 + threadIdx.x);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], y + base + u * 256 + threadIdx.x);
+    }
+    for (long i = base + threadIdx.x; i < n4 && i < base + span; i += 256) y[i] = x[i];
 }
 
 __global__ __launch_bounds__(256) void bw_mix_kernel(const f4 *__restrict__ x, f4 *__restrict__ y, long n4out, long span)
@@ -55,7 +72,7 @@ extern "C" int usot_bw_probe(void *stream, const void *src, void *dst, int64_t b
     hipStream_t s = (hipStream_t)stream;
     const long n4 = bytes / 16;
     if (mode == 0) hipLaunchKernelGGL(bw_read_kernel, dim3(8192), dim3(256), 0, s, (const f4 *)src, (float *)dst, n4);
-    else if (mode == 1) hipLaunchKernelGGL(bw_copy_kernel, dim3(4096), dim3(256), 0, s, (const f4 *)src, (f4 *)dst, n4);
+    else if (mode == 1) hipLaunchKernelGGL(bw_copy_kernel, dim3(2048), dim3(256), 0, s, (const f4 *)src, (f4 *)dst, n4);
     else hipLaunchKernelGGL(bw_mix_kernel, dim3(256), dim3(256), 0, s, (const f4 *)src, (f4 *)dst, n4 / 4, (long)4096);
     USOT_CHECK_LAUNCH();
     return USOT_OK;

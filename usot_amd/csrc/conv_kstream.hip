@@ -58,6 +58,7 @@ __global__ __launch_bounds__(512) void conv_kstream_kernel(const CKStreamK p)
     constexpr int NV = 4 + NI;
     constexpr int HEAD = (CK_BN / 4 > CC * 8 ? CK_BN / 4 : CC * 8);     // bias, and room for M0 = destination - instruction offset
     static_assert(CIN % 64 == 0 && RC % CK_S == 0 && CC >= 2 && CC * 128 + 64 + 16 <= 4096, "shape (instruction offsets are 13-bit signed)");
+    static_assert(HEAD * 16 >= (CC - 1) * 128, "M0 = LDS destination - instruction offset must not go negative (dynamic LDS starts at 0)");
     extern __shared__ __attribute__((aligned(16))) u32x4 ck_lds[];
     u32x4 *slabs = ck_lds + HEAD;
 

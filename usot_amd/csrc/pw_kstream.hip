@@ -56,6 +56,8 @@ __global__ __launch_bounds__(512) void pw_kstream_kernel(const KStreamK p)
     // address as well as to the global one, so M0 carries the destination MINUS that offset: the ring starts HEAD >= NC * 8
     // chunks in, which keeps M0 non-negative
     constexpr int HEAD = (N / 4 > NC * 8 ? N / 4 : NC * 8);
+    static_assert(HEAD * 16 >= (NC - 1) * 128, "M0 = LDS destination - instruction offset must not go negative (dynamic LDS starts at 0)");
+    static_assert((NC - 1) * 128 + 64 < 4096, "the chunk's k offset rides in the 12-bit instruction offset");
     extern __shared__ __attribute__((aligned(16))) u32x4 ks_lds[];
     u32x4 *ks_smem = ks_lds + HEAD;
 

@@ -105,6 +105,18 @@ __device__ __forceinline__ void pn_wait_vm(int n)
     }
 }
 
+// Workgroup barrier of the panel kernel.  Leader and trailer waves run two instantiations of the panel loop, so a barrier is a
+// DIFFERENT call site in each role: the hardware counts arriving waves whatever their PC, but __syncthreads() in divergent
+// control flow is undefined in the HIP model, so the kernel uses the raw instruction and waits for its own LDS operations
+// itself.  INVARIANT (checked by tests/test_gpu_ops.py::test_pw_panel_*: a miscount hangs the launch): both roles execute the
+// same number of pn_barrier() per panel — 1 (prologue) + G (one per interval) + 1 when a second GEMM's ring must drain.
+__device__ __forceinline__ void pn_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int K, int N, int CN, int PB_, bool F16>
 __global__ __launch_bounds__(512) void pw_panel_kernel(const PanelK p)
 {
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(512) void pw_panel_kernel(const PanelK p)
 #pragma unroll
             for (int j = 0; j < PB; ++j) acct[n][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA is invisible to the compiler's wait counts
-        __syncthreads();
+        pn_barrier();
 
         auto gemm = [&](int g) {
             const u32x4 *slab = pn_smem + (g % 3) * C::SLAB;
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(512) void pw_panel_kernel(const PanelK p)
             // (2 PB loads, if any) and stores (2 PB).  A wave of the ragged last panel may have skipped stores: it drains.
             if (!full) pn_wait_vm(0);
             else       pn_wait_vm((p.res ? 2 * PB : 0) + (stored ? 2 * PB : 0));
-            __syncthreads();
+            pn_barrier();
         };
         static_assert(G % 2 == 0 && S == 3, "interval loop unrolled by two over a ring of three slabs");
         // leaders: interval k runs epilogue(k) on the set loaded in interval k-1 (k even: ra) and loads k+1 into the other;
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(512) void pw_panel_kernel(const PanelK p)
         }
         // the next panel's prologue refills slot 0: every wave must be done with the ring (the trailers' last epilogue reads
         // the second GEMM's slab after the loop's last barrier)
-        if (CN > 0 && panel + (int)gridDim.x < p.npanels) __syncthreads();
+        if (CN > 0 && panel + (int)gridDim.x < p.npanels) pn_barrier();
     }
     };
     if (wave >= 4) run(std::true_type{});

@@ -240,6 +240,7 @@ class Builder:
         self.default_batch_tile = 15      # v2 32x64 BK64 when the lead shape has no tuned entry
         self.log = []           # (name, M, N, K, groups, macs) per conv, for benchmarks
         self.lp_bytes = []      # algorithmic HBM bytes of every low-precision conv launch (operands + result, once each)
+        self.f32_bytes = []     # the same for every fp32 entry of `log` (parallel list): bench.py's roofline.algorithmic_bytes_per_launch
         self.geoms = []         # full geometry per conv, for the tuner
 
     def buf(self, *shape, dtype=torch.float32):
@@ -301,17 +302,26 @@ class Builder:
         d, y, oh, ow, log, geom = self.conv_desc(name, pc, x, n, h, w, **kw)
         hip.check(hip.lib().usot_plan_add_conv(self.plan.h, C.byref(d)), 'plan_add_conv ' + name)
         self.log.append(log)
+        self.f32_bytes.append(self._conv_bytes(d))
         self.geoms.append(geom)
         return y, oh, ow
 
-    def conv_batch(self, items):
+    @staticmethod
+    def _conv_bytes(d):
+        """Algorithmic HBM bytes of one fp32 convolution: input map, filter bank, bias, result (+ residual), once each."""
+        g = max(1, d.groups)
+        k = d.KH * d.KW * d.Cin
+        m = d.N * d.OH * d.OW
+        return 4 * g * (d.N * d.H * d.W * d.Cin + d.Cout * k + d.Cout + m * d.Cout * (2 if d.res else 1))
+
+    def conv_batch(self, items, lead_tile=None):
         """Several convolutions of different geometry in ONE launch (usot_conv2d_batch_f32).
-        items: [(name, pc, x, n, h, w, kwargs)], the first one leads (its tuned tile is used).
+        items: [(name, pc, x, n, h, w, kwargs)], the first one leads (its tuned tile is used unless `lead_tile` names one).
         Falls back to separate launches when batching is disabled.  Returns [(y, oh, ow)]."""
         if not self.batch or len(items) == 1:
-            return [self.conv(nm, pc, x, n, h, w, **kw) for nm, pc, x, n, h, w, kw in items]
+            return [self.conv(nm, pc, x, n, h, w, **dict(kw, **({'tile': lead_tile} if lead_tile else {})))
+                    for nm, pc, x, n, h, w, kw in items]
         descs, outs, macs = [], [], 0
-        lead_tile = None
         for nm, pc, x, n, h, w, kw in items:
             d, y, oh, ow, log, geom = self.conv_desc(nm, pc, x, n, h, w, tile=lead_tile, **kw)
             if lead_tile is None:
@@ -326,6 +336,10 @@ class Builder:
         first = items[0]
         self.log.append(('+'.join(i[0] for i in items), descs[0].N * descs[0].OH * descs[0].OW, descs[0].Cout,
                          descs[0].KH * descs[0].KW * descs[0].Cin, len(descs), macs))
+        # siblings that share an input map (shortcut conv + conv1, the three search encoders) read it once
+        shared = len({dd.x for dd in descs}) == 1
+        self.f32_bytes.append(sum(self._conv_bytes(dd) for dd in descs)
+                              - (4 * (len(descs) - 1) * descs[0].N * descs[0].H * descs[0].W * descs[0].Cin if shared else 0))
         return outs
 
     def thin_convs(self, items):
@@ -538,6 +552,7 @@ class Builder:
         hip.check(hip.lib().usot_plan_add_pw_pair(self.plan.h, C.byref(d), 2), 'plan_add_pw_pair(f32) ' + name)
         self.plan.keep += [t2, res, w3p, w1p, c3.b, nxt.b, ws]
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
+        self.f32_bytes.append(4 * (m * (c3.cin + 2 * c3.cout + nxt.cout) + c3.cout * c3.cin + nxt.cout * c3.cout))
         return y, t
 
     def pw_single(self, name, pc, x, n, h, act=ACT_NONE, res=None):
@@ -550,6 +565,7 @@ class Builder:
                   'plan_add_pw_single ' + name)
         self.plan.keep += [x, wp, pc.b, res]
         self.log.append((name, m, pc.cout, pc.cin, 1, m * pc.cout * pc.cin))
+        self.f32_bytes.append(4 * (m * (pc.cin + pc.cout * (2 if res is not None else 1)) + pc.cout * pc.cin))
         return y, h, h
 
     def stream3x3(self, name, pc, x, n, h, w, act=ACT_NONE):
@@ -562,6 +578,7 @@ class Builder:
                   'plan_add_stream_conv3x3 ' + name)
         self.plan.keep += [x, wp, pc.b]
         self.log.append((name, n * oh * ow, pc.cout, 9 * pc.cin, 1, n * oh * ow * pc.cout * 9 * pc.cin))
+        self.f32_bytes.append(4 * (n * h * w * pc.cin + n * oh * ow * pc.cout + pc.cout * 9 * pc.cin))
         return y, oh, ow
 
     def conv3x3(self, name, pc, x, n, h, w, act=ACT_NONE):
@@ -595,6 +612,8 @@ class Builder:
                   'plan_add_pw_triple ' + name)
         self.plan.keep += [t1, res, w2p, w3p, w1p, c2.b, c3.b, nxt.b]
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c2.cout * 9 * c2.cin + c3.cout * c3.cin + nxt.cout * c3.cout)))
+        self.f32_bytes.append(4 * (n * h * h * c2.cin + m * (2 * c3.cout + nxt.cout)
+                                   + c2.cout * 9 * c2.cin + c3.cout * c3.cin + nxt.cout * c3.cout))
         return y, t
 
     def cvt_lp(self, src, dtype):
@@ -635,17 +654,21 @@ class Builder:
                                                                           x_gs=gs, y_gs=b * S * S, w_rows=1))])
         return bbox, cls2, S
 
-    def backbone_bf16(self, x, n, size, dtype=torch.bfloat16, neck_f32=False):
+    def backbone_bf16(self, x, n, size, dtype=torch.bfloat16, neck_f32=False, raw_pixels=True):
         """x NCHW fp32 [n,3,s,s] -> neck output NHWC bf16|fp16 (or fp32 with neck_f32)
         [n,hf,hf,256].  Stem + max-pool are one MFMA kernel (usot_stem_pool_lp): the crop is
-        rounded to the storage type as it is staged, the 125x125 stem map never leaves LDS."""
+        rounded to the storage type as it is staged, the 125x125 stem map never leaves LDS.
+        INPUT CONTRACT: raw BGR pixels in 0..255 (lib/utils/track_utils.py:24-27 feeds them unnormalised).  The bf16 backbone's
+        fp16-arithmetic stem (`stem_f16_math`) rounds crop - STEM_MU to 11 significant bits, which is adequate for that range
+        only (a [0,1]-normalised crop would be quantised in steps of 2^-4 around -104); raw_pixels=False - the caller saw
+        another range - keeps the hi + lo bf16 stem, which carries 16 bits of the crop whatever its scale."""
         W, L = self.W, hip.lib()
         dt = 1 if dtype == torch.float16 else 0
         oh = (size - 7) // 2 + 1
         ph = (oh - 1) // 2 + 1
         p0 = self.buf(n, ph, ph, 64, dtype=dtype)
         wdt = dtype
-        if dtype == torch.bfloat16 and self.opt['stem_f16_math'] and W.stem_fits_f16():
+        if dtype == torch.bfloat16 and self.opt['stem_f16_math'] and raw_pixels and W.stem_fits_f16():
             wdt, dt = torch.float16, 2                 # fp16 arithmetic, bf16 storage
         wf, wb = W.stem_lp(wdt)
         hip.check(L.usot_plan_add_stem_pool_lp(self.plan.h, hip.ptr(x), hip.ptr(wf), hip.ptr(wb), hip.ptr(p0),
@@ -747,11 +770,12 @@ class Builder:
                 head_n = b * m - tail
                 cv = self.buf(b * m, S, S, 512)
                 kw = dict(act=ACT_CONF, act2=ACT_RELU, act_split=256)
+                # both parts on the tile tuned for the WHOLE convolution (passed explicitly: the tuning table is shared by
+                # every later plan of this engine and is not written to while a plan is built)
                 full_tile = self.tuning.get((b * m * S * S, 512, W.conf.kh * W.conf.kw * W.conf.cin, 1), (0, 1))[0]
-                if full_tile:                             # both parts on the tile tuned for the whole convolution
-                    self.tuning.setdefault((head_n * S * S, 512, W.conf.kh * W.conf.kw * W.conf.cin, 1), (full_tile, 1))
                 self.conv_batch([('conf_fusion', W.conf, dwm[:head_n], head_n, S, S, dict(y=cv[:head_n], force_ks=1, **kw)),
-                                 ('conf_fusion.tail', W.conf, dwm[head_n:], tail, S, S, dict(y=cv[head_n:], force_ks=ks, **kw))])
+                                 ('conf_fusion.tail', W.conf, dwm[head_n:], tail, S, S, dict(y=cv[head_n:], force_ks=ks, **kw))],
+                                lead_tile=full_tile or None)
             else:
                 cv, _, _ = self.conv('conf_fusion', W.conf, dwm, b * m, S, S, act=ACT_CONF, act2=ACT_RELU, act_split=256)
             hip.check(L.usot_plan_add_conf_reduce(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256),
@@ -790,6 +814,13 @@ class Builder:
         if has_mem:
             self.join(1, 2)
         return bbox, cls2, S
+
+
+def looks_like_raw_pixels(x):
+    """True when a crop batch is in the reference's input convention, raw 0..255 pixel values (one min / max reduction, done
+    ONCE when a low-precision plan is built): the range the fp16-arithmetic stem of the bf16 backbone is adequate for."""
+    lo, hi = float(x.min()), float(x.max())
+    return lo >= 0.0 and 8.0 < hi <= 256.0
 
 
 def _as_dev_f32(t, device):
@@ -934,6 +965,10 @@ def merged_options(overrides=None):
         if k not in DEFAULT_OPTIONS:
             raise hip.HipError('unknown engine option %r (known: %s)' % (k, ', '.join(sorted(DEFAULT_OPTIONS))))
         opt[k] = v
+    ts = opt.get('conf_tail_split')
+    if ts is not None and not (isinstance(ts, (tuple, list)) and len(ts) == 2 and all(isinstance(v, int) and not isinstance(v, bool) for v in ts)
+                               and ts[0] >= 1 and ts[1] >= 2):
+        raise hip.HipError('conf_tail_split must be None or (tail maps >= 1, ksplit >= 2); got %r' % (ts,))
     return opt
 
 
@@ -992,7 +1027,7 @@ class Engine:
         if key not in self._feat:
             bld = Builder(self.W, self.tuning, 0, self.opt)
             xin = bld.buf(n, 3, s, s)
-            xf, h = bld.backbone_bf16(xin, n, s, dtype=dtype)
+            xf, h = bld.backbone_bf16(xin, n, s, dtype=dtype, raw_pixels=looks_like_raw_pixels(x))
             self._finish(bld.plan)
             self._feat[key] = dict(x=xin, xf=xf, h=h, plan=bld.plan, log=bld.log, p3=bld.p3, lp_bytes=bld.lp_bytes)
         p = self._feat[key]
@@ -1105,12 +1140,13 @@ class Engine:
             bld = Builder(self.W, self.tuning, 0, self.opt)
             xin = bld.buf(b, 3, size, size)
             mem = bld.buf(b * m, 7, 7, 256)
+            raw = looks_like_raw_pixels(x)
             if heads_lp:
-                xl, hf = bld.backbone_bf16(xin, b, size, dtype=dtype, neck_f32=False)
+                xl, hf = bld.backbone_bf16(xin, b, size, dtype=dtype, neck_f32=False, raw_pixels=raw)
                 bbox, cls2, S = bld.heads_lp(xl, b, hf, self._zenc[b]['zk'], mem, m, dtype)
                 xf = xl                                   # returned as the neck map (low precision)
             else:
-                xf, hf = bld.backbone_bf16(xin, b, size, dtype=dtype, neck_f32=True)
+                xf, hf = bld.backbone_bf16(xin, b, size, dtype=dtype, neck_f32=True, raw_pixels=raw)
                 bbox, cls2, S = bld.heads(xf, b, hf, self._zenc[b]['zk'], mem, m)
             self._finish(bld.plan)
             self._track[key] = dict(x=xin, xf=xf, hf=hf, mem=mem, bbox=bbox, cls2=cls2, S=S, plan=bld.plan, log=bld.log)
@@ -1219,6 +1255,7 @@ class Session:
         pl.keep += mk + new_enc + self.bank_enc + [self.slot_dev]
         pl.keep += [self.bank, self.ctl, self.window, self.out8, tsz_dev, idx_dev] + self.zk
         self.xf, self.cls2, self.bbox, self.plan, self.log = xf, cls2, bbox, pl, bld.log
+        self.f32_bytes = bld.f32_bytes
         # warm-up must not leave a stray row in the bank: point the scatter at a scratch row
         self._set_ctl([0, 1] + [2] * (nq - 2), self.cap - 1, (64.0, 64.0))
         self._ctl_f64[6] = -1.0
@@ -1314,6 +1351,12 @@ class Session:
         x1, y1, x2, y2, pscore).  The decode kernel publishes the results and then the tag: poll it
         rather than sleeping in hipStreamSynchronize (the PrRoIPool + bank append behind it are
         ordered before the next frame by the stream)."""
+        try:
+            return self._collect()
+        finally:
+            self._x_ref = None                      # an in-place crop may be reused from here on (also after a timed-out frame)
+
+    def _collect(self):
         out, tag = self._out_np, self._tag
         # spin for SPIN_SECONDS (several frame times), then give the core away between polls.  The budget is wall-clock: a
         # fixed 20 000 polls turned out to be 0.905 ms on this host (45 ns per numpy compare), i.e. it ran out right around
@@ -1337,7 +1380,6 @@ class Session:
                     raise hip.HipError('frame %r never published its result block (tag reads %r): '
                                        'the frame graph did not run to the decode kernel' % (tag, float(out[8])))
         self.n += 1
-        self._x_ref = None                          # an in-place crop may be reused from here on
         return out[:8].copy()
 
     def append_feature(self, feat):

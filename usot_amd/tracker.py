@@ -262,7 +262,11 @@ class USOTTracker(object):
                 out = sess.frame_from_image(im, target_pos, python2round(s_x), state['avg_chans'], picks,
                                             target_sz * scale_z)
             else:
-                out = sess.frame(x_crop, picks, target_sz * scale_z)
+                # a crop the tracker built itself is owned by this call until collect() returns: when it already is a dense
+                # float32 tensor on the session's device it is read where it lies (no device-to-device snapshot)
+                own = (x_crop.is_cuda and x_crop.device == sess.e.device and x_crop.dtype == torch.float32
+                       and x_crop.is_contiguous() and x_crop.numel() == sess.x.numel())
+                out = sess.frame(x_crop, picks, target_sz * scale_z, inplace=own)
             pos, sz = self._apply_box(p, out[3:7], out[2], out[1], target_pos, target_sz * scale_z, scale_z)
             score = np.float32(out[1])
             # the frame graph has already appended the pooled feature to the session's bank, which
