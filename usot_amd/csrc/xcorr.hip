@@ -549,16 +549,23 @@ struct GdwDma {
     static constexpr int LDS_BYTES = NSLOT * SLOTF * 4 + 1024;     // + overrun pad of the last strip
 };
 
+// NT: non-temporal load policy for data every workgroup reads exactly once (the search rows): MI355X_MICROARCH.md price list,
+// 'nt-weights' — issued -> landed 18 % shorter at unchanged issue cost
+template <bool NT = false>
 __device__ __forceinline__ void gdw_dma16(const float *src, const float *lds_dst)
 {
     const uint32_t lds = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_dst);
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
 }
 
-template <int OWT>
+template <int OWT, bool NT = false>
 __global__ __launch_bounds__(512) void groupdw_dma_kernel(const GdwK p)
 {
     using G = GdwDma<OWT>;
@@ -603,12 +610,12 @@ __global__ __launch_bounds__(512) void groupdw_dma_kernel(const GdwK p)
         auto issue = [&](int r, int slot) {
             float *dst = rows + slot * SLOTF;
             const long o0 = r * rs0, o1 = min(r, H1 - 1) * rs1, o2 = r * rs2;
-            if (oa0) gdw_dma16(pa0 + o0, dst + ka * 256);
-            if (ob0) gdw_dma16(pb0 + o0, dst + kb * 256);
-            if (oa0) gdw_dma16(pa1 + o1, dst + W0 * 64 + ka * 256);
-            if (ob0) gdw_dma16(pb1 + o1, dst + W0 * 64 + kb * 256);
-            if (oa2) gdw_dma16(pa2 + o2, dst + 2 * W0 * 64 + ka * 256);
-            if (od2) gdw_dma16(pd2 + o2, dst + 2 * W0 * 64 + kd * 256);
+            if (oa0) gdw_dma16<NT>(pa0 + o0, dst + ka * 256);
+            if (ob0) gdw_dma16<NT>(pb0 + o0, dst + kb * 256);
+            if (oa0) gdw_dma16<NT>(pa1 + o1, dst + W0 * 64 + ka * 256);
+            if (ob0) gdw_dma16<NT>(pb1 + o1, dst + W0 * 64 + kb * 256);
+            if (oa2) gdw_dma16<NT>(pa2 + o2, dst + 2 * W0 * 64 + ka * 256);
+            if (od2) gdw_dma16<NT>(pd2 + o2, dst + 2 * W0 * 64 + kd * 256);
         };
         issue(0, 0);
         if (H0 > 1) {
@@ -723,6 +730,222 @@ __global__ __launch_bounds__(512) void groupdw_dma_kernel(const GdwK p)
         if (r + 2 < H0) step(I2{}, r + 2, next());
         if (r + 3 < H0) step(I3{}, r + 3, next());
         if (r + 4 < H0) step(I4{}, r + 4, next());
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// (1c) the LDS-DMA kernel, PERSISTENT (round 4).  groupdw_dma_kernel pays, per (sample, channel group) unit of ~80 us, a start-up
+// in which nothing streams — 55 strided tap loads per compute lane (one HBM round trip), the first two row-sets (another) — and
+// a workgroup turn-over (the dispatcher refills a slot only after its workgroup has drained): at 16 rounds of 512 workgroups
+// that is ~5 % of the launch during which a slot's share of the HBM queue is empty.  Here the grid is the resident set
+// (2 workgroups per CU) and a workgroup walks its units as ONE flat row-set sequence: while the compute waves finish rows
+// H0-2 and H0-1 of a unit the loaders are already fetching row-sets 0 and 1 of the next one, and its taps: the loaders also
+// DMA the next unit's 55 x 64 taps into an LDS tap image (15 KiB) during the current unit, so the compute waves change units
+// with 55 LDS reads instead of a global round trip.  Same arithmetic in the same order as groupdw_dma_kernel: bit-identical.
+// LDS per workgroup: 3 row-set slots (65 280 B) + 1 KiB overrun pad + tap image 60 rows x 256 B = 81 664 B -> two per CU.
+template <int OWT>
+struct GdwDmaP {
+    using G = GdwDma<OWT>;
+    static constexpr int TAP_ROWS = 28 + 16 + 16;                   // 25 | 15 | 15 taps in whole 4-tap DMA pieces
+    static constexpr int TAP_OFF = G::NSLOT * G::SLOTF + 256;       // floats: behind the ring and its overrun pad
+    static constexpr int LDS_BYTES = (TAP_OFF + TAP_ROWS * 64) * 4;
+};
+
+template <int OWT, bool NT>
+__global__ __launch_bounds__(512, 4) void groupdw_dmap_kernel(const GdwK p, int nunits)
+{
+    using G = GdwDma<OWT>;
+    using GP = GdwDmaP<OWT>;
+    constexpr int W0 = G::W0, W2 = G::W2, SLOTF = G::SLOTF;
+    extern __shared__ __attribute__((aligned(16))) float rows[];     // [NSLOT][SLOTF] | pad | taps[60][64]
+    float *taps = rows + GP::TAP_OFF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H0 = p.OH + 4, H1 = p.OH + 2;
+    const int ncg = p.C >> 6;
+
+    // unit -> (segment, sample within the segment, channel group); false when the unit does not exist (odd sample count)
+    struct Unit { int sg, s, cgi; };
+    auto decode = [&](int u, Unit &o) -> bool {
+        int cgi, s;
+        if (p.C == 256) {
+            const int x8 = u & 7;
+            cgi = x8 & 3;
+            s = (u >> 3) * 2 + (x8 >> 2);
+        } else {
+            cgi = u % ncg;
+            s = u / ncg;
+        }
+        if (s >= p.total) return false;
+        int sg = 0;
+        while (sg + 1 < p.nseg && s >= p.seg[sg].S) { s -= p.seg[sg].S; ++sg; }
+        o.sg = sg; o.s = s; o.cgi = cgi;
+        return true;
+    };
+    auto next_valid = [&](int u, Unit &o) -> int {                   // first existing unit at or after u in this workgroup's walk
+        while (u < nunits && !decode(u, o)) u += gridDim.x;
+        return u;
+    };
+
+    if (wave >= 4) {
+        // ---------------- loader waves ----------------
+        const int lw = wave - 4;
+        const int sub = lane >> 4, c4 = (lane & 15) * 4;
+        const int ka = lw, kb = lw + 4;
+        const int kd = kb < G::N2 ? kb : ka;
+        const bool oa0 = ka * 4 + sub < W0, ob0 = kb * 4 + sub < W0, oa2 = ka * 4 + sub < W2, od2 = kd * 4 + sub < W2;
+        // row-set r of unit v into `slot`
+        auto issue_rows = [&](const Unit &v, int r, int slot) {
+            const GdwSeg &g = p.seg[v.sg];
+            const int xs = v.s / g.x_rep;
+            const float *x0 = g.x[0] + (long)xs * H0 * W0 * g.x_cs[0] + g.x_co[0] + v.cgi * 64 + c4;
+            const float *x1 = g.x[1] + (long)xs * H1 * W0 * g.x_cs[1] + g.x_co[1] + v.cgi * 64 + c4;
+            const float *x2 = g.x[2] + (long)xs * H0 * W2 * g.x_cs[2] + g.x_co[2] + v.cgi * 64 + c4;
+            const long o0 = ((long)r * W0) * g.x_cs[0], o1 = ((long)min(r, H1 - 1) * W0) * g.x_cs[1], o2 = ((long)r * W2) * g.x_cs[2];
+            float *dst = rows + slot * SLOTF;
+            if (oa0) gdw_dma16<NT>(x0 + o0 + (long)(ka * 4 + sub) * g.x_cs[0], dst + ka * 256);
+            if (ob0) gdw_dma16<NT>(x0 + o0 + (long)(kb * 4 + sub) * g.x_cs[0], dst + kb * 256);
+            if (oa0) gdw_dma16<NT>(x1 + o1 + (long)(ka * 4 + sub) * g.x_cs[1], dst + W0 * 64 + ka * 256);
+            if (ob0) gdw_dma16<NT>(x1 + o1 + (long)(kb * 4 + sub) * g.x_cs[1], dst + W0 * 64 + kb * 256);
+            if (oa2) gdw_dma16<NT>(x2 + o2 + (long)(ka * 4 + sub) * g.x_cs[2], dst + 2 * W0 * 64 + ka * 256);
+            if (od2) gdw_dma16<NT>(x2 + o2 + (long)(kd * 4 + sub) * g.x_cs[2], dst + 2 * W0 * 64 + kd * 256);
+        };
+        // the unit's taps -> LDS tap image: rows 0..24 (5x5), 28..42 (3x5), 44..58 (5x3); a piece = 4 taps x 64 channels.
+        // 7 + 4 + 4 pieces over four loaders.  Always issued BEFORE a row-set's pieces: the wait behind those
+        // (vmcnt(PER): only the newest PER operations outstanding, in-order retirement) then covers the taps too.
+        auto issue_taps = [&](const Unit &v) {
+            const GdwSeg &g = p.seg[v.sg];
+            const float *z0 = g.z[0] + (long)v.s * 25 * g.z_cs[0] + g.z_co[0] + v.cgi * 64 + c4;
+            const float *z1 = g.z[1] + (long)v.s * 15 * g.z_cs[1] + g.z_co[1] + v.cgi * 64 + c4;
+            const float *z2 = g.z[2] + (long)v.s * 15 * g.z_cs[2] + g.z_co[2] + v.cgi * 64 + c4;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int pc = lw + 4 * k;                            // 5x5 pieces 0..6
+                if (pc < 7 && pc * 4 + sub < 25) gdw_dma16<false>(z0 + (long)(pc * 4 + sub) * g.z_cs[0], taps + pc * 256);
+            }
+            if (lw * 4 + sub < 15) {
+                gdw_dma16<false>(z1 + (long)(lw * 4 + sub) * g.z_cs[1], taps + (28 + lw * 4) * 64);
+                gdw_dma16<false>(z2 + (long)(lw * 4 + sub) * g.z_cs[2], taps + (44 + lw * 4) * 64);
+            }
+        };
+        Unit u, un;
+        int ui = next_valid(blockIdx.x, u);
+        if (ui >= nunits) return;
+        issue_taps(u);
+        issue_rows(u, 0, 0);
+        issue_rows(u, 1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(G::PER) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int slot2 = 2;
+        while (ui < nunits) {
+            const int uni = next_valid(ui + gridDim.x, un);
+            const bool more_units = uni < nunits;
+            for (int r = 0; r < H0; ++r) {
+                if (r == 1 && more_units) issue_taps(un);           // every compute wave read this unit's taps before barrier (u, 0)
+                bool more = true;
+                if (r + 2 < H0) issue_rows(u, r + 2, slot2);
+                else if (more_units) issue_rows(un, r + 2 - H0, slot2);
+                else more = false;
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(G::PER) : "memory");
+                else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                slot2 = slot2 == 2 ? 0 : slot2 + 1;
+                __builtin_amdgcn_s_barrier();
+            }
+            ui = uni;
+            u = un;
+        }
+        return;
+    }
+
+    // ---------------- compute waves ----------------
+    const int j0 = wave * 7;
+    const int nvalid = min(7, p.OW - j0);
+    const float *strip = rows + j0 * 64 + lane;
+    Unit u;
+    int ui = next_valid(blockIdx.x, u);
+    if (ui >= nunits) return;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int slot = 0;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    while (ui < nunits) {
+        const GdwSeg &g = p.seg[u.sg];
+        float k0[25], k1[15], k2[15];
+#pragma unroll
+        for (int t = 0; t < 25; ++t) k0[t] = g.wsm[0] * taps[t * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 15; ++t) k1[t] = g.wsm[1] * taps[(28 + t) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 15; ++t) k2[t] = g.wsm[2] * taps[(44 + t) * 64 + lane];
+        float A[5][7];
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) A[a][j] = 0.f;
+        float *o = g.out + ((long)u.s * p.OH * p.OW + j0) * p.C + u.cgi * 64 + lane;
+        auto step = [&](auto rho_c, int r, int sl) {
+            constexpr int RHO = decltype(rho_c)::value;
+            const float *rs = strip + sl * SLOTF;
+            {
+                float xv[11];
+#pragma unroll
+                for (int q = 0; q < 11; ++q) xv[q] = rs[q * 64];
+#pragma unroll
+                for (int a = 0; a < 5; ++a)
+#pragma unroll
+                    for (int v = 0; v < 5; ++v)
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) A[(RHO - a + 5) % 5][j] = fmaf(xv[j + v], k0[a * 5 + v], A[(RHO - a + 5) % 5][j]);
+            }
+            if (r < H1) {
+                float xv[11];
+#pragma unroll
+                for (int q = 0; q < 11; ++q) xv[q] = rs[(W0 + q) * 64];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int v = 0; v < 5; ++v)
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) A[(RHO - a + 5) % 5][j] = fmaf(xv[j + v], k1[a * 5 + v], A[(RHO - a + 5) % 5][j]);
+            }
+            {
+                float xv[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) xv[q] = rs[(2 * W0 + q) * 64];
+#pragma unroll
+                for (int a = 0; a < 5; ++a)
+#pragma unroll
+                    for (int v = 0; v < 3; ++v)
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) A[(RHO - a + 5) % 5][j] = fmaf(xv[j + v], k2[a * 3 + v], A[(RHO - a + 5) % 5][j]);
+            }
+            constexpr int DONE = (RHO + 1) % 5;
+            if (r >= 4) {
+                float *orow = o + (long)(r - 4) * p.OW * p.C;
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    if (j < nvalid) orow[(long)j * p.C] = A[DONE][j];
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) A[DONE][j] = 0.f;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        auto next = [&]() { const int cur = slot; slot = slot == 2 ? 0 : slot + 1; return cur; };
+        for (int r = 0; r < H0; r += 5) {
+            step(I0{}, r, next());
+            if (r + 1 < H0) step(I1{}, r + 1, next());
+            if (r + 2 < H0) step(I2{}, r + 2, next());
+            if (r + 3 < H0) step(I3{}, r + 3, next());
+            if (r + 4 < H0) step(I4{}, r + 4, next());
+        }
+        ui = next_valid(ui + gridDim.x, u);
     }
 }
 
@@ -877,8 +1100,41 @@ extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, 
     // 1 strips, 5/50/52 5x5 patches (register budgets), 2 column threads, 3 LDS row streaming, 4 ring
     const int mode = d[0].cols_per_thread != 0 ? d[0].cols_per_thread : groupdw_auto_mode(total, p.OW);
     hipStream_t s = (hipStream_t)stream;
-    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6 && mode != 50 && mode != 52 && mode != 6) return USOT_EINVAL;
-    if (mode == 6) {            // LDS-DMA: workgroup per (sample, 64-channel group), loader wave + 4 strip waves
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6 && mode != 50 && mode != 52 && mode != 7 && mode != 8 && mode != 9) return USOT_EINVAL;
+    if (mode == 8 || mode == 9) {   // persistent LDS-DMA: the resident set of workgroups walks the (sample, channel group) units
+        if (p.OW != 25 && p.OW != 27) return USOT_EINVAL;
+        for (int sidx = 0; sidx < nseg; ++sidx)
+            for (int b = 0; b < 3; ++b)        // 16-byte DMA pieces of search rows AND taps
+                if (((uintptr_t)p.seg[sidx].x[b] & 15) || (p.seg[sidx].x_cs[b] & 3) || (p.seg[sidx].x_co[b] & 3) ||
+                    ((uintptr_t)p.seg[sidx].z[b] & 15) || (p.seg[sidx].z_cs[b] & 3) || (p.seg[sidx].z_co[b] & 3)) return USOT_EINVAL;
+        p.total = total;
+        p.nty = p.ntx = 1;
+        const long nunits = p.C == 256 ? 8L * ((total + 1) / 2) : (long)(p.C / 64) * total;
+        if (nunits > 0x7fffffffL) return USOT_EINVAL;
+        static int slots = 0;
+        if (!slots) {
+            (void)hipFuncSetAttribute((const void *)groupdw_dmap_kernel<25, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDmaP<25>::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)groupdw_dmap_kernel<25, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDmaP<25>::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)groupdw_dmap_kernel<27, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDmaP<27>::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)groupdw_dmap_kernel<27, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDmaP<27>::LDS_BYTES);
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            slots = 2 * cus;                   // two workgroups per CU (LDS: 2 x 81 664 B of 160 KiB; 128 VGPRs x 16 waves)
+            slots -= slots % 8;                // a multiple of 8 keeps a workgroup's units on one XCD / channel-group parity
+        }
+        const int grid = (int)(nunits < slots ? nunits : slots);
+        const size_t lds = p.OW == 25 ? GdwDmaP<25>::LDS_BYTES : GdwDmaP<27>::LDS_BYTES;
+        if (p.OW == 25) {
+            if (mode == 9) hipLaunchKernelGGL((groupdw_dmap_kernel<25, true>), dim3(grid), dim3(512), lds, s, p, (int)nunits);
+            else           hipLaunchKernelGGL((groupdw_dmap_kernel<25, false>), dim3(grid), dim3(512), lds, s, p, (int)nunits);
+        } else {
+            if (mode == 9) hipLaunchKernelGGL((groupdw_dmap_kernel<27, true>), dim3(grid), dim3(512), lds, s, p, (int)nunits);
+            else           hipLaunchKernelGGL((groupdw_dmap_kernel<27, false>), dim3(grid), dim3(512), lds, s, p, (int)nunits);
+        }
+        USOT_CHECK_LAUNCH();
+        return USOT_OK;
+    }
+    if (mode == 6 || mode == 7) {            // LDS-DMA: workgroup per (sample, 64-channel group), loader wave + 4 strip waves
         if (p.OW != 25 && p.OW != 27) return USOT_EINVAL;
         for (int sidx = 0; sidx < nseg; ++sidx)
             for (int b = 0; b < 3; ++b)        // 16-byte DMA pieces
@@ -888,12 +1144,19 @@ extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, 
         const long nb = p.C == 256 ? 8L * ((total + 1) / 2) : (long)(p.C / 64) * total;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<25>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<25>::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<27>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<27>::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<25, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<25>::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<27, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<27>::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<25, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<25>::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<27, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<27>::LDS_BYTES);
             attr_set = true;
         }
-        if (p.OW == 25) hipLaunchKernelGGL(groupdw_dma_kernel<25>, dim3((unsigned)nb), dim3(512), GdwDma<25>::LDS_BYTES, s, p);
-        else            hipLaunchKernelGGL(groupdw_dma_kernel<27>, dim3((unsigned)nb), dim3(512), GdwDma<27>::LDS_BYTES, s, p);
+        if (p.OW == 25) {
+            if (mode == 7) hipLaunchKernelGGL((groupdw_dma_kernel<25, true>), dim3((unsigned)nb), dim3(512), GdwDma<25>::LDS_BYTES, s, p);
+            else           hipLaunchKernelGGL((groupdw_dma_kernel<25, false>), dim3((unsigned)nb), dim3(512), GdwDma<25>::LDS_BYTES, s, p);
+        } else {
+            if (mode == 7) hipLaunchKernelGGL((groupdw_dma_kernel<27, true>), dim3((unsigned)nb), dim3(512), GdwDma<27>::LDS_BYTES, s, p);
+            else           hipLaunchKernelGGL((groupdw_dma_kernel<27, false>), dim3((unsigned)nb), dim3(512), GdwDma<27>::LDS_BYTES, s, p);
+        }
         USOT_CHECK_LAUNCH();
         return USOT_OK;
     }
