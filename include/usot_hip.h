@@ -161,6 +161,23 @@ int usot_conv3x3_halo_supported(int Cin, int Cout);
 int usot_plan_add_conv3x3_halo(void *plan, const void *x, const void *w, const float *bias, void *y,
                                int N, int H, int W, int Cin, int Cout, int act, int dtype);
 
+/* Layer1's FIRST bottleneck of the batched low-precision backbone plus the next block's conv1 in ONE launch
+ * (csrc/bneck_lp.hip; modules.py:37-58 with the 1x1 downsample of modules.py:108-113): the 64-channel intermediates stay in
+ * LDS, the shortcut conv is the second half of conv3's k axis.  NHWC dense, storage type dtype 0 = bf16 | 1 = fp16:
+ * x [N][H][W][64]; w1 [64][64]; w2 [64][576] (k = (kh*3 + kw)*64 + ci); w3c [256][128] = [conv3 | downsample] along k;
+ * wn [64][256] (the next block's conv1); biases fp32 (BN folded; b3c = conv3's + the downsample's);
+ * y [N][H][W][256] = relu(conv3(relu(conv2(relu(conv1 x)))) + downsample(x)), t [N][H][W][64] = relu(conv1'(y)).
+ * At least eight 8 x 16 tiles (N * ceil(H/8) * ceil(W/16)).  Shapes: usot_bneck_first_supported(Cin, Cmid, Cout, Cnext). */
+typedef struct usot_bneck_desc {
+    const void *x, *w1, *w2, *w3c, *wn;
+    const float *b1, *b2, *b3c, *bn;
+    void *y, *t;
+    int32_t N, H, W;
+} usot_bneck_desc;
+int usot_bneck_first_lp(void *stream, const usot_bneck_desc *d, int dtype);
+int usot_bneck_first_supported(int Cin, int Cmid, int Cout, int Cnext);
+int usot_plan_add_bneck_first(void *plan, const usot_bneck_desc *d, int dtype);
+
 /* Channel-reducing 1x1 convolution of the batched low-precision backbone with the accumulators stationary and K streaming
  * (csrc/pw_kstream.hip; layer3's conv1 + BN + ReLU 1024 -> 256, modules.py:40-42, and the neck's 1x1 + BN, connect.py:294-300):
  * y[M][N] = act(x[M][K] . w^T + bias), x / w ([N][K]) / y in the storage type (dtype 0 = bf16, 1 = fp16), bias fp32 or NULL,

@@ -1,26 +1,40 @@
+"""Big-K low-precision convolutions of the batch-64 backbone on a list of tile ids: time per launch (20 back-to-back
+launches, HIP events), TFLOP/s, and bit-equality of every tile's output with the first one's.
+    lp_tiles.py 21,32,33,34 [reps]"""
 import sys, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from usot_amd import hip
-dev='cuda:0'
-def run(name, N, H, Cin, Cout, k, pad, tiles):
+dev = 'cuda:0'
+
+
+def run(name, N, H, Cin, Cout, k, pad, tiles, stride=1, dil=1, reps=20):
     x = torch.randn(N, H, H, Cin, device=dev).to(torch.bfloat16)
-    w = (torch.randn(Cout, k*k*Cin, device=dev) * 0.02).to(torch.bfloat16); b = torch.randn(Cout, device=dev)
-    out=[]
+    w = (torch.randn(Cout, k * k * Cin, device=dev) * 0.02).to(torch.bfloat16); b = torch.randn(Cout, device=dev)
+    out, ref = [], None
     for tile in tiles:
-        f = lambda: hip.conv2d_bf16(x, w, b, KH=k, KW=k, pad=(pad, pad), act=hip.ACT_RELU, tile=tile)
+        f = lambda: hip.conv2d_bf16(x, w, b, KH=k, KW=k, stride=stride, pad=(pad, pad), dil=(dil, dil), act=hip.ACT_RELU, tile=tile)
         try:
-            for _ in range(3): f()
+            for _ in range(3): y = f()
         except Exception as e:
-            out.append('%d:err' % tile); continue
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20): f()
-        e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 20 * 1e3
-        out.append('%d:%.0fus/%.0fTF' % (tile, us, 2.0 * N * H * H * Cout * k * k * Cin / us / 1e6))
-    print(name, ' '.join(out))
+            out.append('%d:err(%s)' % (tile, str(e)[:40])); continue
+        torch.cuda.synchronize()
+        if ref is None: ref = y.clone()
+        same = bool(torch.equal(y, ref))
+        best = 1e9
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps): f()
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / reps * 1e3)
+        oh = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        out.append('%d:%.1fus/%.0fTF%s' % (tile, best, 2.0 * N * oh * oh * Cout * k * k * Cin / best / 1e6, '' if same else '/DIFF'))
+    print(name, ' '.join(out), flush=True)
+
+
 tiles = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else [21, 18, 22, 19, 15, 20, 16, 10, 17, 26]
 run('b7.ds 3x3 512->1024', 64, 31, 512, 1024, 3, 1, tiles)
-run('L3 conv2 3x3 256->256', 64, 31, 256, 256, 3, 1, tiles)
+run('L3 conv2 3x3 256->256 d2', 64, 31, 256, 256, 3, 2, tiles, dil=2)
+run('b3.ds 3x3/s2 256->512', 64, 63, 256, 512, 3, 0, tiles, stride=2)
 run('L3 conv1 1x1 1024->256', 64, 31, 1024, 256, 1, 0, tiles)

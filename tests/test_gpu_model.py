@@ -323,8 +323,9 @@ def test_engine_options_are_enumerable_and_checked():
         engine.merged_options({'no_such_switch': 1})
 
 
-@pytest.mark.parametrize('lp_options', [{}, {'kstream_3x3_lp': {(512, 1024), (256, 256), (256, 512)}, 'halo_3x3_lp': set(), 'kstream_1x1_lp': set()}],
-                         ids=['default', 'kstream3x3_no_halo_no_kstream1x1'])
+@pytest.mark.parametrize('lp_options', [{}, {'kstream_3x3_lp': {(512, 1024), (256, 256), (256, 512)}, 'halo_3x3_lp': set(), 'kstream_1x1_lp': set(),
+                                             'bneck_first_lp': False}],
+                         ids=['default', 'kstream3x3_no_halo_no_kstream1x1_no_bneck'])
 def test_backbone_bf16_batch64_tracks_fp32(net, oracle_sd, lp_options):
     """BASELINE configs[2] at its real batch: 64 crops through the bf16 MFMA backbone + neck; a strided
     subset of the batch is checked against the float32 oracle (the oracle needs ~1 s per crop).  Second configuration: the
@@ -349,9 +350,15 @@ def test_backbone_bf16_batch64_tracks_fp32(net, oracle_sd, lp_options):
     assert err.mean() / scale < 6e-2, err.mean() / scale
     for i in range(len(pick)):
         assert np.corrcoef(got[pick[i]].reshape(-1), ref[i].reshape(-1))[0, 1] > 0.999
-    # batch independence: crop 21 alone gives the same features as inside the batch of 64
+    # batch independence: crop 21 alone gives the same features as inside the batch of 64 — up to the rounding points of the
+    # two lowerings: at batch 1 layer1's first bottleneck runs as four launches (shortcut map rounded to bf16 on its own), at
+    # batch 64 as ONE (csrc/bneck_lp.hip: the shortcut conv shares conv3's accumulator); with that fusion switched off the
+    # two plans run the same kernels on the crop's pixels and agree to 2e-2 of the map's maximum, with it to 5e-2 (measured
+    # 2.4e-2: the size of the bf16 backbone's own error against float32)
     alone = net.engine.features_bf16(x[21:22].to(DEV)).float().cpu().numpy()
-    assert np.abs(alone[0] - got[21]).max() <= 2e-2 * np.abs(got[21]).max()
+    from usot_amd import engine as _eng
+    fused_first = lp_options.get('bneck_first_lp', _eng.DEFAULT_OPTIONS['bneck_first_lp'])
+    assert np.abs(alone[0] - got[21]).max() <= (5e-2 if fused_first else 2e-2) * np.abs(got[21]).max()
 
 
 def test_head_pieces_vs_reference_golden(net, gold_model):

@@ -573,7 +573,7 @@ def test_conv_fp16_and_f32_out(case):
 
 
 @pytest.mark.parametrize('case', BF16_CASES)
-@pytest.mark.parametrize("tile", list(range(0, 32)))
+@pytest.mark.parametrize("tile", list(range(0, 36)))
 def test_conv_bf16(case, tile):
     """bf16 MFMA conv vs an fp32 conv on the SAME bf16-rounded operands: the only differences
     are fp32 summation order and the final bf16 rounding (2^-8 relative)."""
@@ -1092,3 +1092,50 @@ def test_conv3x3_halo_lp(N, H, W, act, dtype):
     ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
     assert float(((got.float() - y2.float()).abs() / y2.float().abs().clamp_min(0.25)).max()) <= ulp
     assert hip.lib().usot_conv3x3_halo_lp(hip.stream(), hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), hip.ptr(y), N, H, W, 128, 128, act, dt) != 0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('N,H,W', [(2, 63, 63), (9, 8, 16), (3, 17, 33), (1, 5, 130), (40, 9, 17)])
+def test_bneck_first_lp(N, H, W, dtype):
+    """Layer1's first bottleneck + the next conv1 in one launch (csrc/bneck_lp.hip; modules.py:37-58,108-113) against the
+    same chain in float64 on the same rounded operands, rounding t1, t2 and y to the storage type where the kernel does
+    (the shortcut conv is NOT rounded on its own: it shares conv3's accumulator).  Full, ragged and sub-tile images, more
+    tiles than workgroups... (40, 9, 17): 160 tiles; nothing written outside y and t."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x = rnd(N, H, W, 64).relu().to(dtype)
+    w1 = (rnd(64, 64) / 8).to(dtype); b1 = rnd(64) * 0.1
+    w2 = (rnd(64, 3, 3, 64) / 24).to(dtype); b2 = rnd(64) * 0.1
+    w3 = (rnd(256, 64) / 8).to(dtype); wd = (rnd(256, 64) / 8).to(dtype); b3c = rnd(256) * 0.1
+    wn = (rnd(64, 256) / 16).to(dtype); bn = rnd(64) * 0.1
+    rq = lambda v: v.to(dtype).double()
+    xd_ = x.double()
+    t1 = rq((xd_ @ w1.double().t() + b1.double()).relu())
+    t2 = F.conv2d(t1.permute(0, 3, 1, 2), w2.double().permute(0, 3, 1, 2), b2.double(), padding=1).permute(0, 2, 3, 1)
+    t2 = rq(t2.relu())
+    y_ref = (t2 @ w3.double().t() + xd_ @ wd.double().t() + b3c.double()).relu()
+    yr = rq(y_ref)
+    t_ref = (yr @ wn.double().t() + bn.double()).relu()
+    dev = lambda v: v.contiguous().to(DEV)
+    xd, w1d, w2d, w3cd, wnd = dev(x), dev(w1), dev(w2.reshape(64, 576)), dev(torch.cat([w3, wd], 1)), dev(wn)
+    b1d, b2d, b3d, bnd = dev(b1), dev(b2), dev(b3c), dev(bn)
+    M = N * H * W
+    y = torch.full((M + 1, 256), 5.0, dtype=dtype, device=DEV)
+    t = torch.full((M + 1, 64), 7.0, dtype=dtype, device=DEV)
+    dt = 1 if dtype == torch.float16 else 0
+    assert hip.lib().usot_bneck_first_supported(64, 64, 256, 64) == 1 and hip.lib().usot_bneck_first_supported(256, 64, 256, 64) == 0
+    d = hip.bneck_desc(*[hip.ptr(v) for v in (xd, w1d, b1d, w2d, b2d, w3cd, b3d, wnd, bnd, y, t)], N, H, W)
+    hip.check(hip.lib().usot_bneck_first_lp(hip.stream(), C.byref(d), dt), 'bneck_first')
+    torch.cuda.synchronize()
+    assert torch.all(y[M:] == 5.0) and torch.all(t[M:] == 7.0)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    got_y = y[:M].reshape(N, H, W, 256).float().cpu().double()
+    got_t = t[:M].reshape(N, H, W, 64).float().cpu().double()
+    # y: one rounding of the storage type on top of the float64 chain, plus what a flipped rounding of t1 / t2 moves (a few ulp
+    # of inputs of size ~1 through 64-term sums with |w| ~ 1/8)
+    ey = float(((got_y - y_ref).abs() / y_ref.abs().clamp_min(1.0)).max())
+    et = float(((got_t - t_ref).abs() / t_ref.abs().clamp_min(1.0)).max())
+    assert ey <= 3 * ulp, ey
+    assert et <= 4 * ulp, et
+    assert hip.lib().usot_bneck_first_lp(hip.stream(), C.byref(hip.bneck_desc(*[hip.ptr(v) for v in (xd, w1d, b1d, w2d, b2d, w3cd, b3d, wnd, bnd, y, t)], 1, 4, 16)), dt) != 0   # < 8 tiles

@@ -37,6 +37,8 @@ struct ConvB {
     int out_f32;       // store the result as fp32 (the neck output that feeds the fp32 heads)
     int M, K, KT, cchunks, MT, NT, P;
     int nfast;         // tile order: 1 = the N-tiles of one pixel tile are adjacent (same XCD, back to back)
+    const uint16_t *zero;   // 16 zero bytes: the source of padding taps for the LDS-DMA paths (a kernel argument, so that its
+                            // address lives in SGPRs: as a __device__ symbol its GOT load was re-issued inside the k-loop)
 };
 
 __device__ __forceinline__ int xcd_remap_b(int b, int total)
@@ -91,10 +93,16 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 // MF = MFMA tile edge: 16 (v_mfma_f32_16x16x32) or 32 (v_mfma_f32_32x32x16: twice the FLOPs per instruction for the
 // same two 16-byte fragments, i.e. half the ds_read_b128 traffic per FLOP, and a higher issue ceiling — 2.38 vs
 // 2.08 PFLOP/s in the MFMA microbenchmarks of MI355X_MICROARCH.md)
-template <int BM, int BN, int WM, int WN, bool F16, int D = 1, int ST = 2, int MF = 16>   // D = 0: LDS-DMA staging (below)
+// PF (D = 0, ST = 2, MF = 16 only; round 4): bit 0 = the two-stage loop with inline-asm DMA, one raw s_barrier per k-tile and a
+// COUNTED s_waitcnt vmcnt (so that the prefetches below may stay in flight across the barrier); bit 1 = pull the filter lines of
+// k-tile t + 3 into this XCD's L2 while tile t is multiplied (a 4-byte LDS-DMA per 128-byte line into a dummy LDS page: no
+// register destination, nothing to wait for); bit 2 = the same for the activation lines; bit 3 = the fragment reads of the
+// k-tile's first half are issued BEFORE the DMA instructions of the next tile (their LDS latency then overlaps the DMA issue).
+template <int BM, int BN, int WM, int WN, bool F16, int D = 1, int ST = 2, int MF = 16, int PF = 0>   // D = 0: LDS-DMA staging (below)
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm_bf16(const ConvB pin)
 {
     ConvB p = pin;
+    static_assert(PF == 0 || (D == 0 && ST == 2 && MF == 16), "PF variants are two-stage LDS-DMA kernels on the 16x16x32 MFMA");
     static_assert(WM * WN == 4 || WM * WN == 8 || WM * WN == 16, "4, 8 or 16 wavefronts");
     static_assert(ST == 2 || (ST == 3 && D == 0), "3 stages need the LDS-DMA path");
     static_assert(MF == 16 || (MF == 32 && (BM / WM) % 32 == 0 && (BN / WN) % 32 == 0), "32x32 MFMA tiles");
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
         const int c0 = cur_cc * BKB;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
-            const uint16_t *src = xin[i] ? xp[i] + c0 : (const uint16_t *)g_zero16;
+            const uint16_t *src = xin[i] ? xp[i] + c0 : p.zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(sX + (buf * BM + wave * 8 + RPP * i) * LDC),
                                              16, 0, 0);
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
         const int c0 = cur_cc * BKB;
 #pragma unroll
         for (int i = 0; i < XI; ++i)
-            dma16(xin[i] ? xp[i] + c0 : (const uint16_t *)g_zero16, sX + (buf * BM + wave * 8 + RPP * i) * LDC);
+            dma16(xin[i] ? xp[i] + c0 : p.zero, sX + (buf * BM + wave * 8 + RPP * i) * LDC);
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             dma16(wp[i], sW + (buf * BN + wave * 8 + RPP * i) * LDC);
@@ -353,7 +361,145 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
     };
 
     const int nt = p.KT;
-    if constexpr (D == 0 && ST == 3) {
+    if constexpr (PF != 0) {
+        // ---- round 4: two stages, asm DMA, counted vmcnt, L2 prefetch of the operand lines three k-tiles ahead ----
+        static_assert(BM % RPP == 0 && BN % RPP == 0, "LDS-DMA stages whole 8-row groups");
+        constexpr int NW = WM * WN;
+        constexpr int PD = 3;                                  // prefetch distance in k-tiles
+        constexpr int NPF = ((PF & 2) ? 1 : 0) + ((PF & 4) ? 1 : 0);
+        // dummy LDS page behind the two stages: a prefetch is a 4-byte-per-lane LDS-DMA whose data nobody reads
+        const uint32_t pf_lds = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem4 + (uint32_t)(2 * (BM + BN) * LDC * 16));
+        auto pf4 = [&](const uint16_t *src) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(pf_lds) : "memory");
+        };
+        // filter lines: a wave covers BN / NW rows of the tile's bank, 64 / (BN / NW) lanes per 128-byte line
+        constexpr int WRW = BN / NW, XRW = BM / NW;
+        static_assert(WRW <= 64 && XRW <= 64 && 64 % WRW == 0 && 64 % XRW == 0, "prefetch lane map");
+        const uint16_t *wpf = nullptr;
+        if constexpr ((PF & 2) != 0) {
+            int co = bn0 + wave * WRW + lane / (64 / WRW);
+            if (co >= p.Cout) co = p.Cout - 1;
+            wpf = p.w + (long)co * p.K + (nt > PD ? PD * BKB : 0);
+        }
+        // activation lines of k-tile t + PD: pixel row, tap and channel chunk tracked separately from the DMA's
+        int pih0 = 0, piw0 = 0, pf_cc = 0, pf_kh = 0, pf_kw = 0;
+        uint32_t pnb = 0;
+        if constexpr ((PF & 4) != 0) {
+            int m = bm0 + wave * XRW + lane / (64 / XRW);
+            if (m >= p.M) m = p.M - 1;
+            const int n = m / p.P, pix = m - n * p.P;
+            const int oh = pix / p.OW, ow = pix - oh * p.OW;
+            pih0 = oh * p.stride - p.pad_h;
+            piw0 = ow * p.stride - p.pad_w;
+            pnb = (uint32_t)n * (uint32_t)(p.H * p.W) * (uint32_t)p.Cin;       // < 2^31 elements (checked by the launcher)
+            const int tap = PD / p.cchunks;
+            pf_cc = PD - tap * p.cchunks;
+            pf_kh = tap / p.KW;
+            pf_kw = tap - pf_kh * p.KW;
+        }
+        auto prefetch = [&](bool more) {                       // more: a k-tile t + PD + 1 exists
+            if constexpr ((PF & 2) != 0) {
+                pf4(wpf);
+                wpf += more ? BKB : 0;
+            }
+            if constexpr ((PF & 4) != 0) {
+                const int ih = pih0 + pf_kh * p.dil_h, iw = piw0 + pf_kw * p.dil_w;
+                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const uint32_t off = pnb + (uint32_t)(ih * p.W + iw) * (uint32_t)p.Cin + (uint32_t)(pf_cc * BKB);
+                pf4(p.x + (ok ? off : 0u));
+                if (more && ++pf_cc == p.cchunks) {
+                    pf_cc = 0;
+                    if (++pf_kw == p.KW) { pf_kw = 0; ++pf_kh; }
+                }
+            }
+        };
+        // DMA with the LDS destination as a plain 32-bit LDS address (the generic -> LDS pointer casts of dma16 cost ~40 scalar /
+        // vector instructions per k-tile in front of the four DMA instructions)
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem4;
+        const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(wave * 8 * LDC * 16));
+        auto dma16u = [&](const uint16_t *src, uint32_t lds) {
+#ifdef USOT_LPABL_NOLOAD
+            return;
+#endif
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+        };
+        auto issue_tile_pf = [&](int buf, bool advance) {
+            const int c0 = cur_cc * BKB;
+            const uint32_t bx = ldsw + (uint32_t)(buf * BM * LDC * 16), bw = ldsw + (uint32_t)((2 * BM + buf * BN) * LDC * 16);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) dma16u(xin[i] ? xp[i] + c0 : p.zero, bx + (uint32_t)(RPP * i * LDC * 16));
+#pragma unroll
+            for (int i = 0; i < WI; ++i) {
+                dma16u(wp[i], bw + (uint32_t)(RPP * i * LDC * 16));
+                wp[i] += advance ? BKB : 0;
+            }
+            if (advance && ++cur_cc == p.cchunks) {
+                cur_cc = 0;
+                set_tap(++cur_tap);
+            }
+        };
+        auto frag_base = [&](int cur, const u32x4 *&cX, const u32x4 *&cW) {
+            cX = sX + (cur * BM + wm * TM * 16 + l15) * LDC;
+            cW = sW + (cur * BN + wn * TN * 16 + l15) * LDC;
+        };
+        auto read_half = [&](const u32x4 *cX, const u32x4 *cW, int ks, u32x4 (&wf)[TN], u32x4 (&xf)[TM]) {
+            const int sq = swz(l15);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) wf[i] = cW[i * 16 * LDC + ((ks * 4 + quad) ^ sq)];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) xf[j] = cX[j * 16 * LDC + ((ks * 4 + quad) ^ sq)];
+        };
+        auto mma_half = [&](const u32x4 (&wf)[TN], const u32x4 (&xf)[TM]) {
+#ifdef USOT_LPABL_NOMMA
+            return;
+#endif
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    if constexpr (F16)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[i]),
+                                                                           __builtin_bit_cast(f16x8, xf[j]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]),
+                                                                            __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
+                }
+        };
+        // prologue: tile 0 by DMA, the lines of tiles 1 and 2 (the DMAs of iterations 0 and 1) towards L2 behind it
+        issue_tile_pf(0, nt > 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int t = 0; t < nt; ++t) {
+            const int cur = t & 1;
+            const bool pf = t + PD < nt;
+            const u32x4 *cX, *cW;
+            frag_base(cur, cX, cW);
+            if constexpr ((PF & 8) != 0) {
+                u32x4 wf[TN], xf[TM];
+                read_half(cX, cW, 0, wf, xf);
+                if (t + 1 < nt) issue_tile_pf(cur ^ 1, t + 2 < nt);
+                if (NPF > 0 && pf) prefetch(t + PD + 1 < nt);
+                mma_half(wf, xf);
+                read_half(cX, cW, 1, wf, xf);
+                mma_half(wf, xf);
+            } else {
+                if (t + 1 < nt) issue_tile_pf(cur ^ 1, t + 2 < nt);
+                if (NPF > 0 && pf) prefetch(t + PD + 1 < nt);
+                mma_tile(cur);
+            }
+            // the DMA pieces of tile t + 1 are older than this iteration's prefetches: in-order retirement
+            if (NPF > 0 && pf) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(NPF) : "memory");
+            else               asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    } else if constexpr (D == 0 && ST == 3) {
         static_assert(BM % RPP == 0 && BN % RPP == 0, "LDS-DMA stages whole 8-row groups");
         constexpr int NL = XI + WI;                   // DMA instructions per wave per k-tile
         // tiles 0 and 1 in flight; tile t+2 is issued into the stage tile t-1 left (every wave passed
@@ -520,12 +666,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
     });
 }
 
-struct TileB { int bm, bn; void (*fn)(const ConvB); void (*fn16)(const ConvB); int threads, stages; };
+struct TileB { int bm, bn; void (*fn)(const ConvB); void (*fn16)(const ConvB); int threads, stages, pf = 0; };
 #define TB(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false>, conv_igemm_bf16<bm, bn, wm, wn, true>, 256, 2 }
 #define TB2(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 2>, conv_igemm_bf16<bm, bn, wm, wn, true, 2>, 256, 2 }
 #define TB0(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0>, conv_igemm_bf16<bm, bn, wm, wn, true, 0>, 256, 2 }
 #define TB08(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0>, conv_igemm_bf16<bm, bn, wm, wn, true, 0>, wm * wn * 64, 2 }
 #define TB32(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0, 2, 32>, conv_igemm_bf16<bm, bn, wm, wn, true, 0, 2, 32>, wm * wn * 64, 2 }
+#define TBP(bm, bn, wm, wn, pf) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0, 2, 16, pf>, conv_igemm_bf16<bm, bn, wm, wn, true, 0, 2, 16, pf>, wm * wn * 64, 2, pf }
 #define TB3(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0, 3>, conv_igemm_bf16<bm, bn, wm, wn, true, 0, 3>, wm * wn * 64, 3 }
 const TileB kTilesB[] = {
     TB(128, 128, 2, 2),   // 1
@@ -559,6 +706,16 @@ const TileB kTilesB[] = {
     TB32(128, 128, 4, 4), // 29: as 25 (one 32x32 tile per wave)
     TB32(256, 128, 4, 2), // 30: 8 wavefronts x (64 x 64)
     TB32(128, 256, 2, 4), // 31
+    TBP(256, 256, 4, 4, 1),   // 32: tile 21 with the asm two-stage loop (integer LDS addresses, zero page from the kernel arguments)
+    TBP(256, 256, 4, 4, 3),   // 33: + the filter lines of k-tile t + 3 pulled into L2 by a 4-byte-per-line LDS-DMA (slower: below)
+    TBP(256, 256, 4, 4, 7),   // 34: + the activation lines
+    TBP(256, 256, 4, 4, 9),   // 35: tile 32 with the fragment reads of the k-tile's first half before the DMA issue
+    // (Round 4, isolated on layer3's shortcut conv / its conv2 / layer2's shortcut conv, us per launch: tile 21 439 / 60.8 / 120;
+    //  32: 427 / 60.4 / 119; 33: 468 / 65.7 / 134; 34: 504 / 69.0 / 140; 35: 424 / 59.5 / 120.  The prefetch variants test the
+    //  hypothesis "a k-tile waits for the filter lines' Infinity-Cache latency": refuted — every EXTRA vector-memory instruction per
+    //  wave and k-tile costs ~13 cycles of the k-tile (16 more: +200 cycles, 32 more: +430), whatever it fetches, i.e. the
+    //  64 DMA instructions of a 256 x 256 x 64 k-tile account for ~830 of its ~2 970 cycles next to 2 048 cycles of MFMA.  In the
+    //  backbone graph tile 32 is 10 us per step faster than 21 (2 341-2 350 vs 2 345-2 360), tile 35 6-18 us slower.)
     // (4 wavefronts x (128 x 128) on a 256 x 256 tile - a quarter of tile 21's LDS fragment bytes per MFMA, accumulators in
     //  AGPRs - measured 648 TFLOP/s on layer3's shortcut conv against 1 082-1 186 for tiles 21 / 22, 981 on the 32x32x16 MFMA:
     //  one wave per SIMD under hipcc's schedule, 512 registers and spills.  Not kept.)
@@ -865,12 +1022,20 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     p.nfast = 1;
     const long blocks = (long)p.MT * p.NT * p.groups;
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
-    size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * LDC * 16;
+    static const uint16_t *zero_page = nullptr;
+    if (!zero_page) {
+        void *zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess || !zp) return USOT_ELAUNCH;
+        zero_page = (const uint16_t *)zp;
+    }
+    p.zero = zero_page;
+    if (tc.pf && ((long)d->N * d->H * d->W * d->Cin >= 0x7fffffffL)) return USOT_EINVAL;     // 32-bit prefetch offsets
+    size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * LDC * 16 + (tc.pf ? 256 : 0);           // + the prefetches' dummy page
     size_t lds_out = (size_t)tc.bm * (tc.bn + 4) * 4;            // fp32 staging tile of the epilogue
     if (lds_out > 144 * 1024) lds_out = (size_t)tc.bm * (tc.bn / 2 + 4) * 4;   // two channel slices
     if (lds_out > lds) lds = lds_out;
     if (lds > 64 * 1024) {
-        static bool raised[2][32] = {{false}};
+        static bool raised[2][kNumTilesB + 1] = {{false}};
         if (!raised[dtype][tile]) {
             if (hipFuncSetAttribute((const void *)(dtype ? tc.fn16 : tc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return USOT_ELAUNCH;

@@ -535,6 +535,27 @@ class Builder:
         self.lp_bytes.append(2 * (m * (c3.cin + 2 * c3.cout + nxt.cout) + c3.cout * c3.cin + nxt.cout * c3.cout))
         return y, t
 
+    def bneck_first(self, name, c1, c2, c3, ds, nxt, x, n, h, dtype):
+        """Layer1's first bottleneck + the next block's conv1 in ONE launch (csrc/bneck_lp.hip).  Returns (y [n,h,h,256],
+        t [n,h,h,64]): the block's output and the next conv1's (both after ReLU)."""
+        y = self.buf(n, h, h, c3.cout, dtype=dtype)
+        t = self.buf(n, h, h, nxt.cout, dtype=dtype)
+        cache = c3.__dict__.setdefault('_w3c', {})
+        if dtype not in cache:                      # [conv3 | downsample] along k; one bias
+            cache[dtype] = (torch.cat([c3.w, ds.w], 1).to(dtype).contiguous(), (c3.b + ds.b).contiguous())
+        w3c, b3c = cache[dtype]
+        w1, w2, wn = c1.w_lp(dtype), c2.w_lp(dtype), nxt.w_lp(dtype)
+        d = hip.bneck_desc(x.data_ptr(), w1.data_ptr(), c1.b.data_ptr(), w2.data_ptr(), c2.b.data_ptr(), w3c.data_ptr(),
+                           b3c.data_ptr(), wn.data_ptr(), nxt.b.data_ptr(), y.data_ptr(), t.data_ptr(), n, h, h)
+        hip.check(hip.lib().usot_plan_add_bneck_first(self.plan.h, C.byref(d), 1 if dtype == torch.float16 else 0),
+                  'plan_add_bneck_first ' + name)
+        self.plan.keep += [x, w1, w2, w3c, b3c, wn, c1.b, c2.b, nxt.b]
+        m = n * h * h
+        macs = m * (c1.cout * c1.cin + c2.cout * 9 * c2.cin + c3.cout * (c3.cin + ds.cin) + nxt.cout * nxt.cin)
+        self.log.append((name, m, c3.cout, c3.cin, 1, macs))
+        self.lp_bytes.append(2 * (m * (c1.cin + c3.cout + nxt.cout) + w1.numel() + w2.numel() + w3c.numel() + wn.numel()))
+        return y, t
+
     def pw_pair_f32(self, name, c3, nxt, t2, res, n, h, act2=ACT_RELU):
         """fp32: conv3 + residual + ReLU and the next block's conv1 in ONE launch (csrc/smallm_f32.hip).
         Returns (y [n,h,h,c3.cout], t [n,h,h,nxt.cout])."""
@@ -681,6 +702,14 @@ class Builder:
         nb = len(W.blocks)
         for bi, (c1, c2, c3, ds) in enumerate(W.blocks):
             sc = cur
+            nx1 = W.blocks[bi + 1][0] if bi + 1 < nb else None
+            if (fuse and self.opt['bneck_first_lp'] and t1 is None and ds is not None and nx1 is not None
+                    and ds.kh == 1 and ds.stride == 1 and c1.kh == 1 and nx1.kh == 1
+                    and c2.kh == 3 and c2.stride == 1 and tuple(c2.pad) == (1, 1) and tuple(c2.dil) == (1, 1)
+                    and hip.lib().usot_bneck_first_supported(c1.cin, c1.cout, c3.cout, nx1.cout)
+                    and n * ((h + 7) // 8) * ((h + 15) // 16) >= self.opt['bneck_first_min_tiles']):
+                cur, t1 = self.bneck_first('b%d+b%d.conv1' % (bi, bi + 1), c1, c2, c3, ds, nx1, cur, n, h, dtype)
+                continue
             if ds is not None:
                 sc, _, _ = self.conv_bf16('b%d.ds' % bi, ds, cur, n, h, h, dtype=dtype)
             if t1 is None:
@@ -874,6 +903,11 @@ DEFAULT_OPTIONS = {
     # conv3 89 -> 66 us, layer1's 1x1 shortcut 50 -> 38 at batch 64
     'panel_1x1_lp': {(256, 1024), (128, 512), (64, 256)},
     'panel_min_panels': 192,
+    # layer1's FIRST bottleneck (1x1 downsample) + the next block's conv1 as ONE launch of the batched low-precision backbone
+    # (csrc/bneck_lp.hip: t1 / t2 stay in LDS, the shortcut conv rides on conv3's k axis) when the launch has at least
+    # bneck_first_min_tiles 8 x 16 tiles (two per CU)
+    'bneck_first_lp': True,
+    'bneck_first_min_tiles': 512,
     # (Cin, Cout) of the 3x3 / stride-1 / pad-1 convolutions of the low-precision backbone that run as direct convolutions
     # from an LDS halo tile (csrc/conv3x3_halo.hip) when the launch has at least one 16 x 16 tile per CU
     'halo_3x3_lp': {(64, 64)},

@@ -29,7 +29,7 @@ EXPORTS = (
     'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
     'PrRoIPoolingForwardGpu', 'usot_groupdw_auto_variant',
-    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_bw_probe', 'usot_conv_kstream_lp', 'usot_conv_kstream_supported', 'usot_plan_add_conv_kstream', 'usot_pw_kstream_lp', 'usot_pw_kstream_supported', 'usot_plan_add_pw_kstream', 'usot_conv3x3_halo_lp', 'usot_conv3x3_halo_supported', 'usot_plan_add_conv3x3_halo', 'usot_pw_panel_lp', 'usot_pw_panel_supported', 'usot_pw_panel_pixels', 'usot_plan_add_pw_panel', 'usot_pw_panel_pair_lp', 'usot_pw_panel_pair_supported', 'usot_plan_add_pw_panel_pair', 'usot_stem_conv_mu_f32', 'usot_stem_pool_mu_f32', 'usot_plan_add_stem_pool_mu', 'usot_plan_add_stem_mu', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single', 'usot_stream_conv3x3_f32', 'usot_stream_conv3x3_f32_supported', 'usot_plan_add_stream_conv3x3', 'usot_pw_triple_f32', 'usot_pw_triple_f32_supported', 'usot_plan_add_pw_triple',
+    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_bw_probe', 'usot_conv_kstream_lp', 'usot_conv_kstream_supported', 'usot_plan_add_conv_kstream', 'usot_pw_kstream_lp', 'usot_pw_kstream_supported', 'usot_plan_add_pw_kstream', 'usot_conv3x3_halo_lp', 'usot_conv3x3_halo_supported', 'usot_plan_add_conv3x3_halo', 'usot_bneck_first_lp', 'usot_bneck_first_supported', 'usot_plan_add_bneck_first', 'usot_pw_panel_lp', 'usot_pw_panel_supported', 'usot_pw_panel_pixels', 'usot_plan_add_pw_panel', 'usot_pw_panel_pair_lp', 'usot_pw_panel_pair_supported', 'usot_plan_add_pw_panel_pair', 'usot_stem_conv_mu_f32', 'usot_stem_pool_mu_f32', 'usot_plan_add_stem_pool_mu', 'usot_plan_add_stem_mu', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single', 'usot_stream_conv3x3_f32', 'usot_stream_conv3x3_f32_supported', 'usot_plan_add_stream_conv3x3', 'usot_pw_triple_f32', 'usot_pw_triple_f32_supported', 'usot_plan_add_pw_triple',
 )
 
 
@@ -70,6 +70,12 @@ class PwPairDesc(C.Structure):
                 ('ws', C.c_void_p)]
 
 
+class BneckDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w1', C.c_void_p), ('w2', C.c_void_p), ('w3c', C.c_void_p), ('wn', C.c_void_p),
+                ('b1', C.c_void_p), ('b2', C.c_void_p), ('b3c', C.c_void_p), ('bn', C.c_void_p),
+                ('y', C.c_void_p), ('t', C.c_void_p), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32)]
+
+
 _lib = None
 
 
@@ -107,6 +113,9 @@ def lib():
         L.usot_conv3x3_halo_lp.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7
         L.usot_plan_add_conv3x3_halo.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7
         L.usot_conv3x3_halo_supported.argtypes = [C.c_int] * 2
+        L.usot_bneck_first_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.usot_plan_add_bneck_first.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.usot_bneck_first_supported.argtypes = [C.c_int] * 4
         L.usot_bw_probe.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_int]
         L.usot_conv_kstream_lp.argtypes = [C.c_void_p] * 5 + [C.c_int] * 10
         L.usot_plan_add_conv_kstream.argtypes = [C.c_void_p] * 5 + [C.c_int] * 10
@@ -581,6 +590,13 @@ def pw_pair_desc(t2, w3p, b3, res, y, w1, b1, t, M, CM, CO, CN, act2, ws=None):
     d.t2, d.w3p, d.res, d.w1, d.b3, d.b1, d.y, d.t = t2, w3p, res, w1, b3, b1, y, t
     d.M, d.CM, d.CO, d.CN, d.act2 = M, CM, CO, CN, act2
     d.ws = ws
+    return d
+
+
+def bneck_desc(x, w1, b1, w2, b2, w3c, b3c, wn, bn, y, t, N, H, W):
+    d = BneckDesc()
+    d.x, d.w1, d.w2, d.w3c, d.wn, d.b1, d.b2, d.b3c, d.bn, d.y, d.t = x, w1, w2, w3c, wn, b1, b2, b3c, bn, y, t
+    d.N, d.H, d.W = N, H, W
     return d
 
 
