@@ -348,7 +348,7 @@ def cpu_baseline(budget_s=14.0):
                               'sample': '%d frames in %.1f s, torch.set_num_threads(1)' % (n1, dt1)}}
 
 
-LP_DOMINANT_KERNEL = 'conv_igemm_bf16<256, 256, 4, 4, false, 0, 2, 16>'     # as scripts/pmc_busy.py keys it
+LP_DOMINANT_KERNEL = 'conv_igemm_bf16<256, 256, 4, 4, false, 0, 2, 16, 1>'     # as scripts/pmc_busy.py keys it
 BF16_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF is 2:1 sparse)
 BACKBONE_GFLOP = 28.192642        # one 255^2 crop through stem..layer3
 
