@@ -470,6 +470,58 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
                                                                             __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
                 }
         };
+        if constexpr ((PF & 16) != 0) {
+            // ---- THREE stages of the activation tile, two of the filter tile (96 + 64 KB = all of the LDS at 256 x 256): for the
+            // channel-reducing 1x1 convs the activations are the HBM stream (126 MB, read once) and the filters an L2-resident
+            // 512 KB, so the depth goes where the latency is: X two k-tiles ahead (64 KB in flight per CU), W one.
+            static_assert(NPF == 0 && (PF & 8) == 0, "the three-stage form has no prefetch / read-first variant");
+            u32x4 *sW3 = smem4 + 3 * BM * LDC;                      // filters behind THREE activation stages
+            const uint32_t ldsw3 = ldsw + (uint32_t)(3 * BM * LDC * 16);
+            auto issue_x3 = [&](int slot, bool advance) {
+                const int c0 = cur_cc * BKB;
+                const uint32_t bx = ldsw + (uint32_t)(slot * BM * LDC * 16);
+#pragma unroll
+                for (int i = 0; i < XI; ++i) dma16u(xin[i] ? xp[i] + c0 : p.zero, bx + (uint32_t)(RPP * i * LDC * 16));
+                if (advance && ++cur_cc == p.cchunks) {
+                    cur_cc = 0;
+                    set_tap(++cur_tap);
+                }
+            };
+            auto issue_w3 = [&](int buf, bool advance) {
+                const uint32_t bw = ldsw3 + (uint32_t)(buf * BN * LDC * 16);
+#pragma unroll
+                for (int i = 0; i < WI; ++i) {
+                    dma16u(wp[i], bw + (uint32_t)(RPP * i * LDC * 16));
+                    wp[i] += advance ? BKB : 0;
+                }
+            };
+            issue_x3(0, nt > 1);
+            issue_w3(0, nt > 1);
+            if (nt > 1) issue_x3(1, nt > 2);
+            if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(XI) : "memory");
+            else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int xs = 0;
+            for (int t = 0; t < nt; ++t) {
+                const int xs2 = xs == 0 ? 2 : xs - 1;               // (t + 2) % 3
+                // issue order: W(t + 1), then X(t + 2) — the wait below leaves only X(t + 2) outstanding (in-order retirement)
+                if (t + 1 < nt) issue_w3((t & 1) ^ 1, t + 2 < nt);
+                if (t + 2 < nt) issue_x3(xs2, t + 3 < nt);
+                const u32x4 *cX = sX + (xs * BM + wm * TM * 16 + l15) * LDC;
+                const u32x4 *cW = sW3 + ((t & 1) * BN + wn * TN * 16 + l15) * LDC;
+                u32x4 wf[TN], xf[TM];
+                read_half(cX, cW, 0, wf, xf);
+                mma_half(wf, xf);
+                read_half(cX, cW, 1, wf, xf);
+                mma_half(wf, xf);
+                if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(XI) : "memory");
+                else            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                xs = xs == 2 ? 0 : xs + 1;
+            }
+        } else {
         // prologue: tile 0 by DMA, the lines of tiles 1 and 2 (the DMAs of iterations 0 and 1) towards L2 behind it
         issue_tile_pf(0, nt > 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -498,6 +550,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv_igemm
             else               asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+        }
         }
     } else if constexpr (D == 0 && ST == 3) {
         static_assert(BM % RPP == 0 && BN % RPP == 0, "LDS-DMA stages whole 8-row groups");
@@ -710,6 +763,7 @@ const TileB kTilesB[] = {
     TBP(256, 256, 4, 4, 3),   // 33: + the filter lines of k-tile t + 3 pulled into L2 by a 4-byte-per-line LDS-DMA (slower: below)
     TBP(256, 256, 4, 4, 7),   // 34: + the activation lines
     TBP(256, 256, 4, 4, 9),   // 35: tile 32 with the fragment reads of the k-tile's first half before the DMA issue
+    TBP(256, 256, 4, 4, 17),  // 36: THREE activation stages + two filter stages (all 160 KB): the 1024 -> 256 reductions' HBM stream
     // (Round 4, isolated on layer3's shortcut conv / its conv2 / layer2's shortcut conv, us per launch: tile 21 439 / 60.8 / 120;
     //  32: 427 / 60.4 / 119; 33: 468 / 65.7 / 134; 34: 504 / 69.0 / 140; 35: 424 / 59.5 / 120.  The prefetch variants test the
     //  hypothesis "a k-tile waits for the filter lines' Infinity-Cache latency": refuted — every EXTRA vector-memory instruction per
@@ -1030,7 +1084,8 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     }
     p.zero = zero_page;
     if (tc.pf && ((long)d->N * d->H * d->W * d->Cin >= 0x7fffffffL)) return USOT_EINVAL;     // 32-bit prefetch offsets
-    size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * LDC * 16 + (tc.pf ? 256 : 0);           // + the prefetches' dummy page
+    size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * LDC * 16 + ((tc.pf & 6) ? 256 : 0);      // + the prefetches' dummy page
+    if (tc.pf & 16) lds = (size_t)(3 * tc.bm + 2 * tc.bn) * LDC * 16;
     size_t lds_out = (size_t)tc.bm * (tc.bn + 4) * 4;            // fp32 staging tile of the epilogue
     if (lds_out > 144 * 1024) lds_out = (size_t)tc.bm * (tc.bn / 2 + 4) * 4;   // two channel slices
     if (lds_out > lds) lds = lds_out;
