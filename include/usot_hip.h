@@ -177,6 +177,14 @@ typedef struct usot_bneck_desc {
 int usot_bneck_first_lp(void *stream, const usot_bneck_desc *d, int dtype);
 int usot_bneck_first_supported(int Cin, int Cmid, int Cout, int Cnext);
 int usot_plan_add_bneck_first(void *plan, const usot_bneck_desc *d, int dtype);
+/* The REST of a layer1 bottleneck whose conv1 output already exists (the launch above, or this one, made it) + the next block's
+ * conv1, one launch: conv2 3x3 + BN + ReLU, conv3 1x1 + BN + identity residual + ReLU (modules.py:43-58), then conv1' + BN + ReLU
+ * of the following block (modules.py:40-42).  The descriptor's fields are read as: x = t1 [N][H][W][64] (this block's conv1
+ * output), w1 = the RESIDUAL map [N][H][W][256] (the block's input), w2 [64][576], w3c = w3 [256][64], wn [Cnext][256],
+ * b2, b3c (= conv3's bias), bn; b1 unused; y [N][H][W][256], t [N][H][W][Cnext].  Cnext 64 | 128. */
+int usot_bneck_tail_lp(void *stream, const usot_bneck_desc *d, int Cnext, int dtype);
+int usot_bneck_tail_supported(int Cmid, int Cout, int Cnext);
+int usot_plan_add_bneck_tail(void *plan, const usot_bneck_desc *d, int Cnext, int dtype);
 
 /* Channel-reducing 1x1 convolution of the batched low-precision backbone with the accumulators stationary and K streaming
  * (csrc/pw_kstream.hip; layer3's conv1 + BN + ReLU 1024 -> 256, modules.py:40-42, and the neck's 1x1 + BN, connect.py:294-300):

@@ -324,7 +324,7 @@ def test_engine_options_are_enumerable_and_checked():
 
 
 @pytest.mark.parametrize('lp_options', [{}, {'kstream_3x3_lp': {(512, 1024), (256, 256), (256, 512)}, 'halo_3x3_lp': set(), 'kstream_1x1_lp': set(),
-                                             'bneck_first_lp': False}],
+                                             'bneck_first_lp': False, 'bneck_tail_lp': False}],
                          ids=['default', 'kstream3x3_no_halo_no_kstream1x1_no_bneck'])
 def test_backbone_bf16_batch64_tracks_fp32(net, oracle_sd, lp_options):
     """BASELINE configs[2] at its real batch: 64 crops through the bf16 MFMA backbone + neck; a strided

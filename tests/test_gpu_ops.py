@@ -1139,3 +1139,45 @@ def test_bneck_first_lp(N, H, W, dtype):
     assert ey <= 3 * ulp, ey
     assert et <= 4 * ulp, et
     assert hip.lib().usot_bneck_first_lp(hip.stream(), C.byref(hip.bneck_desc(*[hip.ptr(v) for v in (xd, w1d, b1d, w2d, b2d, w3cd, b3d, wnd, bnd, y, t)], 1, 4, 16)), dt) != 0   # < 8 tiles
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('cn', [64, 128])
+@pytest.mark.parametrize('N,H,W', [(2, 63, 63), (9, 8, 16), (3, 17, 33), (1, 5, 130), (40, 9, 17)])
+def test_bneck_tail_lp(N, H, W, cn, dtype):
+    """The rest of a layer1 bottleneck (conv2 + conv3 + identity residual) + the next block's conv1 in one launch
+    (csrc/bneck_lp.hip: bneck_tail_kernel; modules.py:43-58, :40-42) against the same chain in float64 on the same rounded
+    operands, rounding t2 and y to the storage type where the kernel does.  Full, ragged, sub-tile images; both next-conv widths."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W + cn)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    t1 = rnd(N, H, W, 64).relu().to(dtype)
+    res = rnd(N, H, W, 256).relu().to(dtype)
+    w2 = (rnd(64, 3, 3, 64) / 24).to(dtype); b2 = rnd(64) * 0.1
+    w3 = (rnd(256, 64) / 8).to(dtype); b3 = rnd(256) * 0.1
+    wn = (rnd(cn, 256) / 16).to(dtype); bn = rnd(cn) * 0.1
+    rq = lambda v: v.to(dtype).double()
+    t2 = F.conv2d(t1.double().permute(0, 3, 1, 2), w2.double().permute(0, 3, 1, 2), b2.double(), padding=1).permute(0, 2, 3, 1)
+    t2 = rq(t2.relu())
+    y_ref = (t2 @ w3.double().t() + b3.double() + res.double()).relu()
+    t_ref = (rq(y_ref) @ wn.double().t() + bn.double()).relu()
+    dev = lambda v: v.contiguous().to(DEV)
+    t1d, resd, w2d, w3d, wnd, b2d, b3d, bnd = dev(t1), dev(res), dev(w2.reshape(64, 576)), dev(w3), dev(wn), dev(b2), dev(b3), dev(bn)
+    M = N * H * W
+    y = torch.full((M + 1, 256), 5.0, dtype=dtype, device=DEV)
+    t = torch.full((M + 1, cn), 7.0, dtype=dtype, device=DEV)
+    dt = 1 if dtype == torch.float16 else 0
+    assert hip.lib().usot_bneck_tail_supported(64, 256, cn) == 1 and hip.lib().usot_bneck_tail_supported(64, 256, 256) == 0
+    d = hip.bneck_desc(hip.ptr(t1d), hip.ptr(resd), None, hip.ptr(w2d), hip.ptr(b2d), hip.ptr(w3d), hip.ptr(b3d), hip.ptr(wnd), hip.ptr(bnd),
+                       hip.ptr(y), hip.ptr(t), N, H, W)
+    hip.check(hip.lib().usot_bneck_tail_lp(hip.stream(), C.byref(d), cn, dt), 'bneck_tail')
+    torch.cuda.synchronize()
+    assert torch.all(y[M:] == 5.0) and torch.all(t[M:] == 7.0)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    got_y = y[:M].reshape(N, H, W, 256).float().cpu().double()
+    got_t = t[:M].reshape(N, H, W, cn).float().cpu().double()
+    ey = float(((got_y - y_ref).abs() / y_ref.abs().clamp_min(1.0)).max())
+    et = float(((got_t - t_ref).abs() / t_ref.abs().clamp_min(1.0)).max())
+    assert ey <= 3 * ulp, ey
+    assert et <= 4 * ulp, et
+    assert hip.lib().usot_bneck_tail_lp(hip.stream(), C.byref(d), 96, dt) != 0

@@ -82,6 +82,12 @@ template <bool F16> __device__ __forceinline__ f32x4 bk_mfma(u32x4 a, u32x4 b, f
 // phase A's linear runs of 16 pixels can pair column 16 / 17 with column 0 / 1 of the next row (2-way on a few reads)
 __device__ __forceinline__ int bk_swz(int hx) { return (hx >> 1) & 7; }
 
+template <bool F16> __device__ __forceinline__ float bk_unpack(uint32_t h)
+{
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+    else               return __builtin_bit_cast(float, h << 16);
+}
+
 // 8 fp32 -> 8 storage-type values after bias + ReLU
 template <bool F16> __device__ __forceinline__ u32x4 bk_pack8(f32x4 a, f32x4 b, f32x4 ba, f32x4 bb)
 {
@@ -120,21 +126,30 @@ __global__ __launch_bounds__(512) void bneck_first_kernel(const BneckK p)
         tx = r2 - ty * p.tiles_x;
     };
     // x halo tile of `tile` -> slot: linear position L = piece * 60 + lane (lanes 0..59), pixel P = L >> 3, physical chunk pc =
-    // L & 7 holds logical chunk pc ^ swz(P)
+    // L & 7 holds logical chunk pc ^ swz(column).  The lane's halo coordinates and chunk are the same for every tile: packed
+    // once (hy | hx << 8 | chunk byte offset << 16) — the per-tile address is then a dozen integer operations per piece, not
+    // the division-laden sixty hipcc makes of the straight code (the kernel is instruction-issue-bound: ~1 500 instructions per
+    // wave and tile on two waves per SIMD, scripts/bneck_probe.py: 6.5 us per tile with MFMAs, DMA and stores compiled out)
+    uint32_t xpk[XPIECES / 8];
+#pragma unroll
+    for (int i = 0; i < XPIECES / 8; ++i) {
+        const int L = (i * 8 + wave) * 60 + lane;
+        const int P = L >> 3, pc = L & 7;
+        const int hy = P / HC, hx = P - hy * HC;
+        xpk[i] = (uint32_t)hy | ((uint32_t)hx << 8) | ((uint32_t)((pc ^ bk_swz(hx)) << 4) << 16);
+    }
     auto issue_x = [&](int tile, int slot) {
         int n, ty, tx;
         tile_xy(tile, n, ty, tx);
         const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+        const char *xn = (const char *)(p.x + (long)n * p.H * p.W * 64);
 #pragma unroll
         for (int i = 0; i < XPIECES / 8; ++i) {
-            const int piece = i * 8 + wave;
-            const int L = piece * 60 + lane;
-            const int P = L >> 3, pc = L & 7;
-            const int hy = P / HC, hx = P - hy * HC;
-            const int iy = y0 + hy, ix = x0 + hx;
+            const int iy = y0 + (int)(xpk[i] & 0xffu), ix = x0 + (int)((xpk[i] >> 8) & 0xffu);
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const uint16_t *src = ok ? p.x + (((long)n * p.H + iy) * p.W + ix) * 64 + ((pc ^ bk_swz(hx)) << 3) : p.zero;
-            if (lane < 60) dma16(src, lds0 + (uint32_t)((L_XR + slot * XSLOT + piece * 60) * 16));
+            const uint32_t off = (uint32_t)(iy * p.W + ix) * 128u + (xpk[i] >> 16);     // < 2^31: checked by the launcher
+            const void *src = ok ? (const void *)(xn + off) : (const void *)p.zero;
+            if (lane < 60) dma16(src, lds0 + (uint32_t)((L_XR + slot * XSLOT + (i * 8 + wave) * 60) * 16));
         }
     };
 
@@ -306,6 +321,7 @@ __global__ __launch_bounds__(512) void bneck_first_kernel(const BneckK p)
             }
             const f32x4 ba = *(const f32x4 *)(sb + 128 + wave * 32 + q * 8), bb = *(const f32x4 *)(sb + 128 + wave * 32 + q * 8 + 4);
             const int ox = tx * TW + l15;
+            char *yb = (char *)(p.y + (((long)n * p.H + ty * TH) * p.W + ox) * 256 + wave * 32 + q * 8);   // row ty*8 of the tile
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) {
                 const int oy = ty * TH + hp * 4 + pb;
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(512) void bneck_first_kernel(const BneckK p)
 #else
                 if (oy < p.H && ox < p.W)
 #endif
-                    *(u32x4 *)(p.y + (((long)n * p.H + oy) * p.W + ox) * 256 + wave * 32 + q * 8) = yo[hp * 4 + pb];
+                    *(u32x4 *)(yb + (uint32_t)((hp * 4 + pb) * p.W) * 512u) = yo[hp * 4 + pb];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -341,6 +357,7 @@ __global__ __launch_bounds__(512) void bneck_first_kernel(const BneckK p)
                 for (int j = 0; j < 2; ++j) acc[j] = bk_mfma<F16>(an[ks], b[j], acc[j]);
             }
             const int ox = tx * TW + l15;
+            char *tb = (char *)(p.t + (((long)n * p.H + ty * TH) * p.W + ox) * 64 + cb * 16 + q * 4);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int oy = ty * TH + half * 4 + ph * 2 + j;
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(512) void bneck_first_kernel(const BneckK p)
 #else
                 if (oy < p.H && ox < p.W)
 #endif
-                    *(u32x2 *)(p.t + (((long)n * p.H + oy) * p.W + ox) * 64 + cb * 16 + q * 4) = o;
+                    *(u32x2 *)(tb + (uint32_t)((half * 4 + ph * 2 + j) * p.W) * 128u) = o;
             }
         }
 #endif
@@ -364,6 +381,245 @@ __global__ __launch_bounds__(512) void bneck_first_kernel(const BneckK p)
             const int r0 = p.H - (ty * TH + ph * 2);
             stores_prev = min(8, max(0, p.H - ty * TH)) + min(2, max(0, r0)) + min(2, max(0, r0 - 4));
         }
+        tile = next;
+        slot ^= 1;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The REST of a layer1 bottleneck whose conv1 the previous launch already made (bneck_first_kernel's phase D, or this
+// kernel's): conv2 3x3 + BN + ReLU, conv3 1x1 + BN + identity residual + ReLU and the NEXT block's conv1 + BN + ReLU
+// (modules.py:43-58 and :40-42 of the following block; CN = 64 inside layer1, 128 for layer2's first block) — phases B, C, D
+// of the kernel above with the t1 halo tile coming from global memory (zero outside the image = conv2's padding) and the
+// residual read from global memory into registers at the top of the tile.  Before: conv3x3_halo (32 + 32 MB) + the
+// pixel-stationary pair (32 + 130 + 130 + 32 MB); here t2 never leaves LDS: 32 x 1.4 + 130 + 130 + 32 MB, one launch.
+//   LDS: t1 halo [2 slots][180 pixels][8 + 2 pad chunks] | t2 [128][10] | y half [64][33] | w3 fragments [8][2][2][64] | biases
+struct BneckTK {
+    const uint16_t *t1, *res, *w2, *w3, *wn;
+    const float *b2, *b3, *bn;
+    uint16_t *y, *t;
+    const uint16_t *zero;
+    int N, H, W, tiles_x, tiles_y, ntiles;
+};
+
+constexpr int T1SLOT = HPIX * TPS;          // 1800 chunks
+constexpr int T1PIECES = (T1SLOT + 63) / 64;        // 29 DMA instructions (the last one 8 lanes)
+constexpr int M_T1 = 0;                     // [2][T1SLOT]
+constexpr int M_T2 = M_T1 + 2 * T1SLOT;     // [128][TPS]
+constexpr int M_YH = M_T2 + 128 * TPS;      // [64][YPS]
+constexpr int M_W3F = M_YH + 64 * YPS;      // [w 8][i 2][ks 2][64]
+constexpr int M_BIAS = M_W3F + 2048;        // b2[64] b3[256] bn[128] floats = 112 chunks
+constexpr int M_END = M_BIAS + 112;
+constexpr int BT_LDS = M_END * 16;          // 146 432 B
+static_assert(W2CH <= M_W3F, "w2 staging fits in front of the w3 fragments");
+static_assert(BT_LDS <= 160 * 1024, "LDS");
+
+template <bool F16, int CN>
+__global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckTK p)
+{
+    static_assert(CN == 64 || CN == 128, "next conv1: 256 -> 64 | 128");
+    constexpr int NCB = CN / 16;                    // channel blocks of the next conv1
+    constexpr int WPC = 8 / NCB;                    // waves per channel block (2 | 1)
+    constexpr int NPX = 4 / WPC;                    // pixel blocks per wave and y half (2 | 4)
+    extern __shared__ __attribute__((aligned(16))) u32x4 sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)sm;
+    auto dma16 = [&](const void *src, uint32_t lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
+    };
+    const int grid8 = gridDim.x >> 3;
+    auto tile_of = [&](int k) { return (k * 8 + ((int)blockIdx.x & 7)) * grid8 + ((int)blockIdx.x >> 3); };
+    auto tile_xy = [&](int tile, int &n, int &ty, int &tx) {
+        n = tile / (p.tiles_x * p.tiles_y);
+        const int r2 = tile - n * p.tiles_x * p.tiles_y;
+        ty = r2 / p.tiles_x;
+        tx = r2 - ty * p.tiles_x;
+    };
+    // t1 halo tile -> slot: position L = piece * 64 + lane = pixel P = L / 10, chunk pc = L % 10 (8, 9: pad, not written)
+    uint32_t tpk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int L = (i * 8 + wave) * 64 + lane;
+        const int P = L / TPS, pc = L - P * TPS;
+        const int hy = P / HC, hx = P - hy * HC;
+        tpk[i] = (L < T1SLOT && pc < 8) ? ((uint32_t)hy | ((uint32_t)hx << 8) | ((uint32_t)(pc << 4) << 16)) : 0xffffffffu;
+    }
+    auto issue_t1 = [&](int tile, int slot) {
+        int n, ty, tx;
+        tile_xy(tile, n, ty, tx);
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+        const char *tn = (const char *)(p.t1 + (long)n * p.H * p.W * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = y0 + (int)(tpk[i] & 0xffu), ix = x0 + (int)((tpk[i] >> 8) & 0xffu);
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const uint32_t off = (uint32_t)(iy * p.W + ix) * 128u + ((tpk[i] >> 16) & 0xffu);
+            const void *src = ok ? (const void *)(tn + off) : (const void *)p.zero;
+            if (tpk[i] != 0xffffffffu) dma16(src, lds0 + (uint32_t)((M_T1 + slot * T1SLOT + (i * 8 + wave) * 64) * 16));
+        }
+    };
+
+    int kit = 0;
+    int tile = tile_of(0);
+    if (tile >= p.ntiles) return;
+    // ---- one-time staging: w2 fragments through LDS (as above), w3 fragments (stay in LDS), biases
+#pragma unroll
+    for (int i = 0; i < W2CH / 512; ++i) {
+        const int c = i * 512 + tid;
+        const int ln = c & 63, fs = c >> 6, s = fs % 18, cbb = fs / 18;
+        dma16(p.w2 + (long)(cbb * 16 + (ln & 15)) * 576 + s * 32 + (ln >> 4) * 8, lds0 + (uint32_t)((i * 512 + wave * 64) * 16));
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                 // w3: fragment (w, i, ks) = chunk ((w*2 + i)*2 + ks)*64 + ln
+        const int c = it * 512 + tid;
+        const int ln = c & 63, f = c >> 6, ks = f & 1, i = (f >> 1) & 1, w = f >> 2;
+        const int ch = w * 32 + ((ln & 15) >> 2) * 8 + i * 4 + (ln & 3);
+        dma16(p.w3 + ch * 64 + ks * 32 + (ln >> 4) * 8, lds0 + (uint32_t)((M_W3F + it * 512 + wave * 64) * 16));
+    }
+    {
+        float *sbw = (float *)(sm + M_BIAS);
+        if (tid < 64) sbw[tid] = p.b2[tid];
+        if (tid < 256) sbw[64 + tid] = p.b3[tid];
+        if (tid < CN) sbw[320 + tid] = p.bn[tid];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int cb = wave & 3, rh = wave >> 2;        // phase B: channel block, row half
+    u32x4 af2[18];
+#pragma unroll
+    for (int s = 0; s < 18; ++s) af2[s] = sm[(cb * 18 + s) * 64 + lane];
+    const int dcb = wave / WPC, dph = wave % WPC;   // phase D: channel block, which NPX pixel blocks of a y half
+    u32x4 an[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) an[ks] = *(const u32x4 *)(p.wn + (dcb * 16 + l15) * 256 + ks * 32 + q * 8);
+    __syncthreads();
+    issue_t1(tile, 0);
+    const float *sb = (const float *)(sm + M_BIAS);
+    int slot = 0;
+
+    for (;; ++kit) {
+        int n, ty, tx;
+        tile_xy(tile, n, ty, tx);
+        const int next = tile_of(kit + 1);
+        // this tile's halo was issued one tile ago; the residual loads issued behind it were waited for in phase C, so — vmcnt
+        // retires in order — the DMA has landed for this wave.  The first tile waits explicitly.
+        if (kit == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                             // #1: t1(tile) visible; the other slot, t2 and the y half are free
+        if (next < p.ntiles) issue_t1(next, slot ^ 1);
+        // residual: lane (l15, q) of wave w = channels w*32 + q*8 .. +7 of pixel (row pb, column l15): one 16-byte load per row
+        const int ox = tx * TW + l15;
+        const long pix0 = ((long)n * p.H + ty * TH) * p.W + ox;
+        const char *rb = (const char *)(p.res + pix0 * 256 + wave * 32 + q * 8);
+        u32x4 rr[8];
+#pragma unroll
+        for (int pb = 0; pb < 8; ++pb) {
+            rr[pb] = u32x4{0u, 0u, 0u, 0u};
+            if (ty * TH + pb < p.H && ox < p.W) rr[pb] = *(const u32x4 *)(rb + (uint32_t)(pb * p.W) * 512u);
+        }
+        const u32x4 *t1s = sm + M_T1 + slot * T1SLOT;
+        u32x4 *t2 = sm + M_T2, *yh = sm + M_YH;
+
+        // ---------------- B: conv2.  wave (cb, rh): channels cb*16 .. +15 x tile rows rh*4 .. rh*4 + 3
+        {
+            f32x4 acc2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const u32x4 *hb = t1s + ((rh * 4) * HC + l15) * TPS + q;
+            u32x4 bf[2][4];
+            auto read_b = [&](int s, u32x4 (&b)[4]) {
+                const int t = s >> 1, ks = s & 1, kh = t / 3, kw = t - kh * 3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = hb[((j + kh) * HC + kw) * TPS + ks * 4];
+            };
+            read_b(0, bf[0]);
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {
+                if (s + 1 < 18) read_b(s + 1, bf[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc2[j] = bk_mfma<F16>(af2[s], bf[s & 1][j], acc2[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const f32x4 bv = *(const f32x4 *)(sb + cb * 16 + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc2[j] + bv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                u32x2 o;
+                o[0] = usot_pack2_lp<F16>(v[0], v[1]); o[1] = usot_pack2_lp<F16>(v[2], v[3]);
+                *(u32x2 *)((char *)(t2 + ((rh * 4 + j) * 16 + l15) * TPS) + cb * 32 + q * 8) = o;
+            }
+        }
+        __syncthreads();                             // #2: t2 complete
+
+        // ---------------- C + D, 64 pixels (four tile rows) at a time
+        const f32x4 ba = *(const f32x4 *)(sb + 64 + wave * 32 + q * 8), bb = *(const f32x4 *)(sb + 64 + wave * 32 + q * 8 + 4);
+        const f32x4 bnv = *(const f32x4 *)(sb + 320 + dcb * 16 + q * 4);
+        char *yb = (char *)(p.y + pix0 * 256 + wave * 32 + q * 8);
+        char *tb = (char *)(p.t + pix0 * CN + dcb * 16 + q * 4);
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) acc[i][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 a[2], b[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = sm[M_W3F + ((wave * 2 + i) * 2 + ks) * 64 + lane];
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) b[pb] = t2[((hp * 4 + pb) * 16 + l15) * TPS + ks * 4 + q];
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i][pb] = bk_mfma<F16>(a[i], b[pb], acc[i][pb]);
+            }
+            if (hp == 1) __syncthreads();            // #5: phase D of the first half has read the y half
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const int row = hp * 4 + pb;
+                const u32x4 r = rr[row];
+                f32x4 v0 = acc[0][pb] + ba, v1 = acc[1][pb] + bb;
+                v0[0] += bk_unpack<F16>(r[0] & 0xffffu); v0[1] += bk_unpack<F16>(r[0] >> 16);
+                v0[2] += bk_unpack<F16>(r[1] & 0xffffu); v0[3] += bk_unpack<F16>(r[1] >> 16);
+                v1[0] += bk_unpack<F16>(r[2] & 0xffffu); v1[1] += bk_unpack<F16>(r[2] >> 16);
+                v1[2] += bk_unpack<F16>(r[3] & 0xffffu); v1[3] += bk_unpack<F16>(r[3] >> 16);
+                const u32x4 o = bk_pack8<F16>(v0, v1, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f});
+                if (ty * TH + row < p.H && ox < p.W) *(u32x4 *)(yb + (uint32_t)(row * p.W) * 512u) = o;
+                yh[(pb * 16 + l15) * YPS + wave * 4 + q] = o;
+            }
+            __syncthreads();                         // #3 / #6: the y half is complete
+            f32x4 accd[NPX];
+#pragma unroll
+            for (int j = 0; j < NPX; ++j) accd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                u32x4 b[NPX];
+#pragma unroll
+                for (int j = 0; j < NPX; ++j) b[j] = yh[((dph * NPX + j) * 16 + l15) * YPS + ks * 4 + q];
+#pragma unroll
+                for (int j = 0; j < NPX; ++j) accd[j] = bk_mfma<F16>(an[ks], b[j], accd[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NPX; ++j) {
+                const int row = hp * 4 + dph * NPX + j;
+                f32x4 v = accd[j] + bnv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                u32x2 o;
+                o[0] = usot_pack2_lp<F16>(v[0], v[1]); o[1] = usot_pack2_lp<F16>(v[2], v[3]);
+                if (ty * TH + row < p.H && ox < p.W) *(u32x2 *)(tb + (uint32_t)(row * p.W) * (uint32_t)(CN * 2)) = o;
+            }
+        }
+        if (next >= p.ntiles) break;
         tile = next;
         slot ^= 1;
     }
@@ -393,7 +649,7 @@ extern "C" int usot_bneck_first_lp(void *stream, const usot_bneck_desc *d, int d
     p.N = d->N; p.H = d->H; p.W = d->W;
     p.tiles_x = usot_cdiv(d->W, TW); p.tiles_y = usot_cdiv(d->H, TH);
     const long nt = (long)p.tiles_x * p.tiles_y * d->N;
-    if (nt > 0x7fffffffL) return USOT_EINVAL;
+    if (nt > 0x7fffffffL || (long)d->H * d->W * 128 >= 0x7fffffffL) return USOT_EINVAL;      // 32-bit offsets inside an image
     p.ntiles = (int)nt;
     static const uint16_t *zero_page = nullptr;
     static int cus = 0;
@@ -420,6 +676,64 @@ extern "C" int usot_bneck_first_lp(void *stream, const usot_bneck_desc *d, int d
     if (grid < 8) return USOT_EINVAL;               // fewer than eight tiles: not this kernel's regime
     if (dtype) hipLaunchKernelGGL(bneck_first_kernel<true>, dim3(grid), dim3(512), BK_LDS, (hipStream_t)stream, p);
     else       hipLaunchKernelGGL(bneck_first_kernel<false>, dim3(grid), dim3(512), BK_LDS, (hipStream_t)stream, p);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+extern "C" int usot_bneck_tail_supported(int Cmid, int Cout, int Cnext)
+{
+    return Cmid == 64 && Cout == 256 && (Cnext == 64 || Cnext == 128);
+}
+
+/* The rest of a layer1 bottleneck after its conv1 + the next block's conv1 in one launch (bneck_tail_kernel above).  NHWC dense,
+ * storage type dtype 0 = bf16 | 1 = fp16: d->x = t1 [N][H][W][64] (this block's conv1 output, after ReLU), d->w1 = the residual
+ * [N][H][W][256] (the block's input), d->w2 [64][576], d->w3c = w3 [256][64], d->wn [Cnext][256]; biases d->b2, d->b3c (= b3),
+ * d->bn (d->b1 unused); y [N][H][W][256] = relu(conv3(relu(conv2 t1)) + residual), t [N][H][W][Cnext] = relu(conv1'(y)). */
+extern "C" int usot_bneck_tail_lp(void *stream, const usot_bneck_desc *d, int Cnext, int dtype)
+{
+    if (!d || !d->x || !d->w1 || !d->w2 || !d->w3c || !d->wn || !d->b2 || !d->b3c || !d->bn || !d->y || !d->t) return USOT_EINVAL;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || (dtype != 0 && dtype != 1) || !usot_bneck_tail_supported(64, 256, Cnext)) return USOT_EINVAL;
+    if (((uintptr_t)d->x | (uintptr_t)d->w1 | (uintptr_t)d->w2 | (uintptr_t)d->w3c | (uintptr_t)d->wn |
+         (uintptr_t)d->b2 | (uintptr_t)d->b3c | (uintptr_t)d->bn | (uintptr_t)d->y | (uintptr_t)d->t) & 15) return USOT_EINVAL;
+    BneckTK p;
+    p.t1 = (const uint16_t *)d->x; p.res = (const uint16_t *)d->w1; p.w2 = (const uint16_t *)d->w2;
+    p.w3 = (const uint16_t *)d->w3c; p.wn = (const uint16_t *)d->wn;
+    p.b2 = d->b2; p.b3 = d->b3c; p.bn = d->bn;
+    p.y = (uint16_t *)d->y; p.t = (uint16_t *)d->t;
+    p.N = d->N; p.H = d->H; p.W = d->W;
+    p.tiles_x = usot_cdiv(d->W, TW); p.tiles_y = usot_cdiv(d->H, TH);
+    const long nt = (long)p.tiles_x * p.tiles_y * d->N;
+    if (nt > 0x7fffffffL || (long)d->H * d->W * 512 >= 0x7fffffffL) return USOT_EINVAL;      // 32-bit offsets inside an image
+    p.ntiles = (int)nt;
+    static const uint16_t *zero_page = nullptr;
+    static int cus = 0;
+    if (!zero_page) {
+        void *zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(bk_zero16)) != hipSuccess || !zp) return USOT_ELAUNCH;
+        zero_page = (const uint16_t *)zp;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    p.zero = zero_page;
+    const int v = (dtype ? 2 : 0) + (Cnext == 128 ? 1 : 0);
+    const void *fns[4] = {(const void *)bneck_tail_kernel<false, 64>, (const void *)bneck_tail_kernel<false, 128>,
+                          (const void *)bneck_tail_kernel<true, 64>, (const void *)bneck_tail_kernel<true, 128>};
+    static bool raised[4] = {false, false, false, false};
+    if (!raised[v]) {
+        if (hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS) != hipSuccess) return USOT_ELAUNCH;
+        raised[v] = true;
+    }
+    int grid = cus - (cus & 7);
+    if (grid > p.ntiles) grid = p.ntiles - (p.ntiles & 7);
+    if (grid < 8) return USOT_EINVAL;
+    switch (v) {
+    case 0: hipLaunchKernelGGL((bneck_tail_kernel<false, 64>), dim3(grid), dim3(512), BT_LDS, (hipStream_t)stream, p); break;
+    case 1: hipLaunchKernelGGL((bneck_tail_kernel<false, 128>), dim3(grid), dim3(512), BT_LDS, (hipStream_t)stream, p); break;
+    case 2: hipLaunchKernelGGL((bneck_tail_kernel<true, 64>), dim3(grid), dim3(512), BT_LDS, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL((bneck_tail_kernel<true, 128>), dim3(grid), dim3(512), BT_LDS, (hipStream_t)stream, p); break;
+    }
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }

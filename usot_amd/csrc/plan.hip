@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3, K_PW3, K_PANEL, K_PANELP, K_HALO, K_KSTREAM, K_CKSTREAM, K_BNECK1 };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3, K_PW3, K_PANEL, K_PANELP, K_HALO, K_KSTREAM, K_CKSTREAM, K_BNECK1, K_BNECKT };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -116,6 +116,7 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
                                       op.i[4], op.i[5], op.i[6]);
             break;
         case K_BNECK1: rc = usot_bneck_first_lp(s, &op.bneck, op.i[6]); break;
+        case K_BNECKT: rc = usot_bneck_tail_lp(s, &op.bneck, op.i[5], op.i[6]); break;
         case K_CKSTREAM:
             rc = usot_conv_kstream_lp(s, op.p[0], op.p[1], (const float *)op.p[2], (void *)op.p[3], op.i[0], op.i[1], op.i[2], op.i[3],
                                       op.i[4], op.i[5], op.i[7], (int)op.l[0], (int)op.l[1], op.i[6]);
@@ -310,6 +311,17 @@ extern "C" int usot_plan_add_bneck_first(void *plan, const usot_bneck_desc *d, i
     Op *op = push(plan, K_BNECK1);
     if (!op) return USOT_ESTATE;
     op->bneck = *d;
+    op->i[6] = dtype;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_bneck_tail(void *plan, const usot_bneck_desc *d, int Cnext, int dtype)
+{
+    if (!d || (dtype != 0 && dtype != 1) || !usot_bneck_tail_supported(64, 256, Cnext)) return USOT_EINVAL;
+    Op *op = push(plan, K_BNECKT);
+    if (!op) return USOT_ESTATE;
+    op->bneck = *d;
+    op->i[5] = Cnext;
     op->i[6] = dtype;
     return USOT_OK;
 }

@@ -556,6 +556,22 @@ class Builder:
         self.lp_bytes.append(2 * (m * (c1.cin + c3.cout + nxt.cout) + w1.numel() + w2.numel() + w3c.numel() + wn.numel()))
         return y, t
 
+    def bneck_tail(self, name, c2, c3, nxt, t1, res, n, h, dtype):
+        """The rest of a layer1 bottleneck after its conv1 + the next block's conv1 in ONE launch (csrc/bneck_lp.hip:
+        bneck_tail_kernel).  t1: this block's conv1 output, res: the block's input.  Returns (y, t) as bneck_first."""
+        y = self.buf(n, h, h, c3.cout, dtype=dtype)
+        t = self.buf(n, h, h, nxt.cout, dtype=dtype)
+        w2, w3, wn = c2.w_lp(dtype), c3.w_lp(dtype), nxt.w_lp(dtype)
+        d = hip.bneck_desc(t1.data_ptr(), res.data_ptr(), None, w2.data_ptr(), c2.b.data_ptr(), w3.data_ptr(),
+                           c3.b.data_ptr(), wn.data_ptr(), nxt.b.data_ptr(), y.data_ptr(), t.data_ptr(), n, h, h)
+        hip.check(hip.lib().usot_plan_add_bneck_tail(self.plan.h, C.byref(d), nxt.cout, 1 if dtype == torch.float16 else 0),
+                  'plan_add_bneck_tail ' + name)
+        self.plan.keep += [t1, res, w2, w3, wn, c2.b, c3.b, nxt.b]
+        m = n * h * h
+        self.log.append((name, m, c3.cout, c3.cin, 1, m * (c2.cout * 9 * c2.cin + c3.cout * c3.cin + nxt.cout * nxt.cin)))
+        self.lp_bytes.append(2 * (m * (c2.cin + 2 * c3.cout + nxt.cout) + w2.numel() + w3.numel() + wn.numel()))
+        return y, t
+
     def pw_pair_f32(self, name, c3, nxt, t2, res, n, h, act2=ACT_RELU):
         """fp32: conv3 + residual + ReLU and the next block's conv1 in ONE launch (csrc/smallm_f32.hip).
         Returns (y [n,h,h,c3.cout], t [n,h,h,nxt.cout])."""
@@ -709,6 +725,12 @@ class Builder:
                     and hip.lib().usot_bneck_first_supported(c1.cin, c1.cout, c3.cout, nx1.cout)
                     and n * ((h + 7) // 8) * ((h + 15) // 16) >= self.opt['bneck_first_min_tiles']):
                 cur, t1 = self.bneck_first('b%d+b%d.conv1' % (bi, bi + 1), c1, c2, c3, ds, nx1, cur, n, h, dtype)
+                continue
+            if (fuse and self.opt['bneck_tail_lp'] and t1 is not None and ds is None and nx1 is not None and nx1.kh == 1
+                    and nx1.stride == 1 and c2.kh == 3 and c2.stride == 1 and tuple(c2.pad) == (1, 1) and tuple(c2.dil) == (1, 1)
+                    and c2.cin == 64 and hip.lib().usot_bneck_tail_supported(c2.cout, c3.cout, nx1.cout)
+                    and n * ((h + 7) // 8) * ((h + 15) // 16) >= self.opt['bneck_first_min_tiles']):
+                cur, t1 = self.bneck_tail('b%d.conv2+conv3+b%d.conv1' % (bi, bi + 1), c2, c3, nx1, t1, cur, n, h, dtype)
                 continue
             if ds is not None:
                 sc, _, _ = self.conv_bf16('b%d.ds' % bi, ds, cur, n, h, h, dtype=dtype)
@@ -908,6 +930,8 @@ DEFAULT_OPTIONS = {
     # bneck_first_min_tiles 8 x 16 tiles (two per CU)
     'bneck_first_lp': True,
     'bneck_first_min_tiles': 512,
+    # ... and the REST of layer1's other bottlenecks (conv2 + conv3 + residual) + the following conv1 likewise (bneck_tail_kernel)
+    'bneck_tail_lp': True,
     # (Cin, Cout) of the 3x3 / stride-1 / pad-1 convolutions of the low-precision backbone that run as direct convolutions
     # from an LDS halo tile (csrc/conv3x3_halo.hip) when the launch has at least one 16 x 16 tile per CU
     'halo_3x3_lp': {(64, 64)},
