@@ -1098,7 +1098,15 @@ extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, 
     }
     // variant: 0 -> auto (5x1 strips for a frame's 9 samples, ring for >= 64 samples);
     // 1 strips, 5/50/52 5x5 patches (register budgets), 2 column threads, 3 LDS row streaming, 4 ring
-    const int mode = d[0].cols_per_thread != 0 ? d[0].cols_per_thread : groupdw_auto_mode(total, p.OW);
+    int mode = d[0].cols_per_thread != 0 ? d[0].cols_per_thread : groupdw_auto_mode(total, p.OW);
+    if (d[0].cols_per_thread == 0 && mode == 6) {
+        // search rows that ONE sample reads once stream with the non-temporal policy (round 4, scripts/xcorr_probe2.py: 128 samples
+        // 90 -> 82 us, 512: 336 -> 332, 2048: equal; MI355X_MICROARCH.md 'nt-weights'); maps shared by x_rep samples (the memory
+        // branch of a frame batch) keep the default policy: their re-reads are L2 hits
+        bool once = true;
+        for (int sidx = 0; sidx < nseg; ++sidx) once = once && d[sidx].x_rep == 1;
+        if (once) mode = 7;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6 && mode != 50 && mode != 52 && mode != 7 && mode != 8 && mode != 9) return USOT_EINVAL;
     if (mode == 8 || mode == 9) {   // persistent LDS-DMA: the resident set of workgroups walks the (sample, channel group) units
