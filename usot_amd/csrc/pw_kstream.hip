@@ -19,6 +19,12 @@
 #include "usot_hip.h"
 #include "common.h"
 
+#ifdef USOT_KS_NT          // non-temporal policy for the activation stream (read once): scripts/probes/stride_probe.hip reads 6.9 vs 6.2 TB/s
+#define USOT_KS_NTS " nt"
+#else
+#define USOT_KS_NTS ""
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -102,10 +108,10 @@ __global__ __launch_bounds__(512) void pw_kstream_kernel(const KStreamK p)
             constexpr int c = decltype(cc)::value, s = decltype(sc)::value;
             u32x4 (&xs)[2][2] = xf[s];                           // (asm operands alone do not capture in a generic lambda)
             const uint16_t *x0 = xrow[0], *x1 = xrow[1];
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xs[0][0]) : "v"(x0), "n"(c * 128) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xs[0][1]) : "v"(x1), "n"(c * 128) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xs[1][0]) : "v"(x0), "n"(c * 128 + 64) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xs[1][1]) : "v"(x1), "n"(c * 128 + 64) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" USOT_KS_NTS : "=v"(xs[0][0]) : "v"(x0), "n"(c * 128) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" USOT_KS_NTS : "=v"(xs[0][1]) : "v"(x1), "n"(c * 128) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" USOT_KS_NTS : "=v"(xs[1][0]) : "v"(x0), "n"(c * 128 + 64) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" USOT_KS_NTS : "=v"(xs[1][1]) : "v"(x1), "n"(c * 128 + 64) : "memory");
         };
         f32x4 acc[NB][2];
 #pragma unroll
