@@ -34,10 +34,11 @@ def run(name, N, H, Cin, Cout, k, pad, tiles, stride=1, dil=1, reps=20):
 
 
 tiles = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else [21, 18, 22, 19, 15, 20, 16, 10, 17, 26]
-run('b7.ds 3x3 512->1024', 64, 31, 512, 1024, 3, 1, tiles)
-run('L3 conv2 3x3 256->256 d2', 64, 31, 256, 256, 3, 2, tiles, dil=2)
-run('b3.ds 3x3/s2 256->512', 64, 63, 256, 512, 3, 0, tiles, stride=2)
-run('L3 conv1 1x1 1024->256', 64, 31, 1024, 256, 1, 0, tiles)
+if len(sys.argv) <= 2:
+  run('b7.ds 3x3 512->1024', 64, 31, 512, 1024, 3, 1, tiles)
+  run('L3 conv2 3x3 256->256 d2', 64, 31, 256, 256, 3, 2, tiles, dil=2)
+  run('b3.ds 3x3/s2 256->512', 64, 63, 256, 512, 3, 0, tiles, stride=2)
+  run('L3 conv1 1x1 1024->256', 64, 31, 1024, 256, 1, 0, tiles)
 
 
 def run_cold_1x1(tiles, reps=30):
@@ -83,3 +84,6 @@ def run_cold_1x1(tiles, reps=30):
 
 if len(sys.argv) > 2 and sys.argv[2] == 'cold':
     run_cold_1x1(tiles)
+if len(sys.argv) > 2 and sys.argv[2] == 'layer2':
+    run('L2 conv2 3x3 128->128', 64, 31, 128, 128, 3, 1, tiles)
+    run('b3.conv2 3x3/s2 128->128', 64, 63, 128, 128, 3, 0, tiles, stride=2)

@@ -573,7 +573,7 @@ def test_conv_fp16_and_f32_out(case):
 
 
 @pytest.mark.parametrize('case', BF16_CASES)
-@pytest.mark.parametrize("tile", list(range(0, 37)))
+@pytest.mark.parametrize("tile", list(range(0, 38)))
 def test_conv_bf16(case, tile):
     """bf16 MFMA conv vs an fp32 conv on the SAME bf16-rounded operands: the only differences
     are fp32 summation order and the final bf16 rounding (2^-8 relative)."""

@@ -764,6 +764,7 @@ const TileB kTilesB[] = {
     TBP(256, 256, 4, 4, 7),   // 34: + the activation lines
     TBP(256, 256, 4, 4, 9),   // 35: tile 32 with the fragment reads of the k-tile's first half before the DMA issue
     TBP(256, 256, 4, 4, 17),  // 36: THREE activation stages + two filter stages (all 160 KB): the 1024 -> 256 reductions' HBM stream
+    TBP(128, 128, 4, 4, 1),   // 37: tile 25 on the asm loop (layer2's 3x3 convs, N = 128: 27.0 -> 25.9 us isolated; 256 x 128 forms 25.4 / 28.4)
     // (Round 4, isolated on layer3's shortcut conv / its conv2 / layer2's shortcut conv, us per launch: tile 21 439 / 60.8 / 120;
     //  32: 427 / 60.4 / 119; 33: 468 / 65.7 / 134; 34: 504 / 69.0 / 140; 35: 424 / 59.5 / 120.  The prefetch variants test the
     //  hypothesis "a k-tile waits for the filter lines' Infinity-Cache latency": refuted — every EXTRA vector-memory instruction per
