@@ -806,9 +806,11 @@ def test_conv_lp_groups_and_activations(dtype, tile):
     assert float(((y.float().permute(0, 3, 1, 2).cpu() - ref).abs() / ref.abs()).max()) < 1.5 * ulp
 
 
-@pytest.mark.parametrize('n,hw', [(1, 25), (2, 27), (1, 7)])
+@pytest.mark.parametrize('n,hw', [(1, 25), (2, 27), (1, 7), (16, 25), (33, 27)])
 def test_thin_conv3x3_prediction_heads(n, hw):
-    """usot_thin_conv3x3_f32: bbox_pred (4 ch, exp) + cls/cls_mem preds (two 1-ch groups) in one launch."""
+    """usot_thin_conv3x3_f32: bbox_pred (4 ch, exp) + cls/cls_mem preds (two 1-ch groups) in one launch.  From 1024 output rows
+    (n >= 14 at 25 x 25) the launcher switches to the wavefront-per-ROW form (filters in registers, sliding window): same taps,
+    same order, same fused multiply-adds — bit-identical to the wavefront-per-pixel form (forced with tile = 70)."""
     import ctypes as C
     g = torch.Generator().manual_seed(n * 100 + hw)
     x = torch.randn(3, n, 256, hw, hw, generator=g)                       # three tower outputs
@@ -832,6 +834,13 @@ def test_thin_conv3x3_prediction_heads(n, hw):
     for gi in range(2):
         ref = F.conv2d(x[1 + gi], wc[gi:gi + 1], bc[gi:gi + 1], 1, 1)
         assert rel_err(yc[gi].cpu().numpy(), ref.numpy()) < 1e-5
+    yb2, yc2 = torch.zeros_like(yb), torch.zeros_like(yc)
+    descs2 = [hip.conv_desc(xd[0].data_ptr(), wbd.data_ptr(), bbd.data_ptr(), yb2.data_ptr(), N=n, H=hw, W=hw, Cin=256, OH=hw, OW=hw,
+                            Cout=4, KH=3, KW=3, pad=(1, 1), act=hip.ACT_EXP, y_nchw=1, tile=70),
+              hip.conv_desc(xd[1].data_ptr(), wcd.data_ptr(), bcd.data_ptr(), yc2.data_ptr(), N=n, H=hw, W=hw, Cin=256, OH=hw, OW=hw,
+                            Cout=1, KH=3, KW=3, pad=(1, 1), y_nchw=1, groups=2, x_gs=gs, w_gs=2304, b_gs=1, y_gs=n * hw * hw, tile=70)]
+    hip.check(hip.lib().usot_thin_conv3x3_f32(hip.stream(), (hip.ConvDesc * 2)(*descs2), 2), 'thin per pixel')
+    assert torch.equal(yb, yb2) and torch.equal(yc, yc2)
     bad = hip.conv_desc(xd[0].data_ptr(), wbd.data_ptr(), bbd.data_ptr(), yb.data_ptr(), N=n, H=hw, W=hw, Cin=256, OH=hw, OW=hw,
                         Cout=4, KH=3, KW=3, pad=(0, 0), y_nchw=1)
     assert hip.lib().usot_thin_conv3x3_f32(hip.stream(), C.byref(bad), 1) != 0

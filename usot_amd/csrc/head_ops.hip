@@ -357,6 +357,89 @@ __global__ __launch_bounds__(256) void thin_conv3x3_kernel(const ThinK k)
     }
 }
 
+// The same arithmetic for BATCHES (round 4): one wavefront per output pixel re-reads 9 x 1 KB of activations and 9 x CO KB of
+// filters per pixel — at 32 streams (20 000 pixels x 3 problems) that is 0.5 GB + 1 GB of L1 / L2 traffic and 180 us.  Here a
+// wavefront owns a ROW of output pixels: the filters live in registers (lane = 4 input channels: 9 x CO float4), a 3 x 3
+// window of float4 slides along the row (three new loads per pixel instead of nine), the next column is loaded before the
+// current pixel is accumulated.  Per lane the same taps in the same order with the same fused multiply-adds, then the same
+// butterfly: bit-identical to thin_pixel (out-of-image taps contribute +0 either way).  Cin = 256 (one float4 per lane).
+template <int CO>
+__device__ __forceinline__ void thin_row(const ThinK &k, int pi, int g, int nrow, int lane)
+{
+    const int P = k.H * k.W;
+    const int n = nrow / k.H, oh = nrow - n * k.H;
+    const float *xg = k.x[pi] + (long)g * k.x_gs[pi] + (long)n * P * k.Cin + lane * 4;
+    const float *wg = k.w[pi] + (long)g * k.w_gs[pi] + lane * 4;
+    f32x4 wv[CO][9];
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[c][t] = *(const f32x4 *)(wg + ((long)c * 9 + t) * k.Cin);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto column = [&](int iw, f32x4 (&col)[3]) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int ih = oh + dy - 1;
+            const bool ok = (unsigned)ih < (unsigned)k.H && (unsigned)iw < (unsigned)k.W;
+            col[dy] = ok ? *(const f32x4 *)(xg + ((long)ih * k.W + iw) * k.Cin) : zero;
+        }
+    };
+    f32x4 c0[3], c1[3], c2[3], c3[3];
+    c0[0] = c0[1] = c0[2] = zero;                   // column -1
+    column(0, c1);
+    column(1, c2);
+    const float *bg = k.bias[pi] ? k.bias[pi] + (long)g * k.b_gs[pi] : nullptr;
+    float *yg = k.y[pi] + (long)g * k.y_gs[pi];
+    for (int ow = 0; ow < k.W; ++ow) {
+        column(ow + 2, c3);                          // in flight under this pixel's arithmetic
+        float acc[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const f32x4 xv = (t % 3 == 0) ? c0[t / 3] : ((t % 3 == 1) ? c1[t / 3] : c2[t / 3]);
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                const f32x4 w4 = wv[c][t];
+                acc[c] = fmaf(xv[0], w4[0], fmaf(xv[1], w4[1], fmaf(xv[2], w4[2], fmaf(xv[3], w4[3], acc[c]))));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c)
+                yg[((long)n * CO + c) * P + oh * k.W + ow] = thin_act(acc[c] + (bg ? bg[c] : 0.f), k.act[pi]);   // NCHW
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) { c0[dy] = c1[dy]; c1[dy] = c2[dy]; c2[dy] = c3[dy]; }
+    }
+}
+
+// work item = (problem, group, image, output row); k.start counts rows here
+__global__ __launch_bounds__(256) void thin_conv3x3_rows_kernel(const ThinK k)
+{
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= k.start[k.n]) return;
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < k.n && item >= k.start[q]) pi = q;
+    const int local = item - k.start[pi];
+    const int per_g = k.N * k.H;
+    const int g = local / per_g, nrow = local - g * per_g;
+    switch (k.cout[pi]) {
+    case 1: thin_row<1>(k, pi, g, nrow, lane); break;
+    case 2: thin_row<2>(k, pi, g, nrow, lane); break;
+    case 3: thin_row<3>(k, pi, g, nrow, lane); break;
+    default: thin_row<4>(k, pi, g, nrow, lane); break;
+    }
+}
+
 // up to four banks with different row lengths, same row indices, one launch (blockIdx.y = bank)
 struct RowsK {
     const float *src[4];
@@ -787,6 +870,22 @@ extern "C" int usot_thin_conv3x3_f32(void *stream, const usot_conv_desc *d, int 
         if (i < n) total += groups * c.N * c.H * c.W;
     }
     for (int i = n; i < 5; ++i) k.start[i] = total;
+    // batches: a wavefront per output ROW with the filters in registers (thin_row) once the rows alone fill the chip
+    // (>= 1024 wavefronts: 8 streams of 25 rows x 6 problem-groups); one frame keeps the wavefront-per-pixel form
+    long rows = 0;
+    for (int i = 0; i < n; ++i) rows += (long)k.groups[i] * k.N * k.H;
+    if (k.Cin == 256 && rows >= 1024 && d[0].tile != 70) {
+        int tr = 0;
+        for (int i = 0; i < 4; ++i) {
+            k.start[i] = tr;
+            if (i < n) tr += k.groups[i] * k.N * k.H;
+        }
+        k.start[4] = tr;
+        for (int i = n; i < 4; ++i) k.start[i] = tr;
+        hipLaunchKernelGGL(thin_conv3x3_rows_kernel, dim3((unsigned)((tr + 3) / 4)), dim3(256), 0, (hipStream_t)stream, k);
+        USOT_CHECK_LAUNCH();
+        return USOT_OK;
+    }
     hipLaunchKernelGGL(thin_conv3x3_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, k);
     USOT_CHECK_LAUNCH();
     return USOT_OK;

@@ -670,7 +670,14 @@ class Builder:
               for g in range(3)]
         S = hf - 6
         tin = self.buf(3, b, S, S, 256)               # tower inputs: [reg, cls, memory]
-        mk = self.encode_kernel(mem_nhwc, b * m, 256, 'mem')
+        if self.opt['enc_k_lp']:
+            # the memory features' kernel-side encoders on the low-precision MFMA too (fp32 output for the fp32 correlations):
+            # at 32 streams x 7 memory features the fp32 launch was 197 us of the 3.1 ms batch (74 TFLOP/s)
+            ml = self.cvt_lp(mem_nhwc, dtype)
+            mk = [self.conv_bf16('enc_k%d.mem' % g, W.enc_k[g], ml, b * m, 7, 7, cout=256, act=ACT_RELU, dtype=dtype, out_f32=True)[0]
+                  for g in range(3)]
+        else:
+            mk = self.encode_kernel(mem_nhwc, b * m, 256, 'mem')
         dwm = self.buf(b * m, S, S, 256)
         self.groupdw_flush([self.groupdw(es, zk, tin[0], W.reg_wsm, b, 1, S, S, 256, 512),
                             self.groupdw(es, zk, tin[1], W.cls_wsm, b, 1, S, S, 0, 512),
@@ -930,6 +937,8 @@ DEFAULT_OPTIONS = {
     # bneck_first_min_tiles 8 x 16 tiles (two per CU)
     'bneck_first_lp': True,
     'bneck_first_min_tiles': 512,
+    # heads_lp (configs[4]): the memory features' kernel-side encoders (connect.py:55-74 `_k` branches) on the low-precision MFMA
+    'enc_k_lp': True,
     # ... and the REST of layer1's other bottlenecks (conv2 + conv3 + residual) + the following conv1 likewise (bneck_tail_kernel)
     'bneck_tail_lp': True,
     # (Cin, Cout) of the 3x3 / stride-1 / pad-1 convolutions of the low-precision backbone that run as direct convolutions
