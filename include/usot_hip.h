@@ -295,12 +295,17 @@ int usot_groupdw_auto_variant(int total_samples, int OW);
 /* up to three segments of identical geometry (the cls, reg and memory GroupDWs of a frame)
  * in ONE launch */
 int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, int nseg);
+/* ... with the OUTPUT maps stored as fp16 (out_dtype 1) or bf16 (2) — d[i].out then points to 16-bit elements; the same fp32
+ * arithmetic, one rounding at the store (the batched mixed-precision heads of BASELINE configs[4] feed these maps to fp16
+ * convolutions).  25- and 27-wide responses only. */
+int usot_groupdw_multi_lp(void *stream, const usot_groupdw_desc *d, int nseg, int out_dtype);
 
 /* ---- Conf_Fusion reduction (connect.py:132-142): cv NHWC [B*M][P][2C] holding
  * conf = exp(clamp) in channels [0,C) and value in [C,2C) -> out [B][P][C] =
  * sum_m conf*value / sum_m conf.                                                       */
 int usot_conf_fusion_reduce_f32(void *stream, const float *cv, float *out,
                                 int B, int M, int P, int C);
+int usot_conf_fusion_reduce_lp(void *stream, const float *cv, void *out, int B, int M, int P, int C, int out_dtype);   /* out fp16 (1) | bf16 (2) */
 
 /* ---- Precise RoI Pooling forward.  Replaces PrRoIPoolingForwardGpu
  * (prroi_pooling_gpu_impl.cuh:20-28 / .cu:149-212,387-402) with explicit strides so the
@@ -416,6 +421,7 @@ int usot_plan_add_cvt_bf16(void *plan, const float *src, void *dst, int64_t n);
 int usot_plan_add_maxpool_bf16(void *plan, const void *x, void *y, int N, int H, int W, int C, int OH, int OW);
 int usot_plan_add_groupdw(void *plan, const usot_groupdw_desc *d);
 int usot_plan_add_groupdw_multi(void *plan, const usot_groupdw_desc *d, int nseg);
+int usot_plan_add_groupdw_multi_lp(void *plan, const usot_groupdw_desc *d, int nseg, int out_dtype);
 /* fused fp32 stem + max-pool on the fp32 MFMA (the 125x125 stem map never reaches HBM); wfrag from
  * usot_amd/engine.py: pack_stem_f32 */
 int usot_stem_pool_f32(void *stream, const float *x, const float *wfrag, const float *bias, float *y,
@@ -443,6 +449,7 @@ int usot_plan_add_stem_mu(void *plan, const float *x, const float *w, const floa
 int usot_plan_add_maxpool(void *plan, const float *x, float *y, int N, int H, int W, int C,
                           int OH, int OW);
 int usot_plan_add_conf_reduce(void *plan, const float *cv, float *out, int B, int M, int P, int C);
+int usot_plan_add_conf_reduce_lp(void *plan, const float *cv, void *out, int B, int M, int P, int C, int out_dtype);
 int usot_plan_add_prroi(void *plan, const float *feat, const float *rois, float *out,
                         int R, int C, int H, int W, int PH, int PW, float scale,
                         int64_t f_sb, int64_t f_sc, int64_t f_sh, int64_t f_sw,

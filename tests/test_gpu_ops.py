@@ -1190,3 +1190,42 @@ def test_bneck_tail_lp(N, H, W, cn, dtype):
     assert ey <= 3 * ulp, ey
     assert et <= 4 * ulp, et
     assert hip.lib().usot_bneck_tail_lp(hip.stream(), C.byref(d), 96, dt) != 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['fp16', 'bf16'])
+@pytest.mark.parametrize('ow', [25, 27])
+def test_groupdw_and_conf_reduce_low_precision_outputs(ow, dtype):
+    """usot_groupdw_multi_lp / usot_conf_fusion_reduce_lp (the batched mixed-precision heads, BASELINE configs[4]): the same fp32
+    arithmetic with the output maps stored as fp16 | bf16: equal to the fp32 launch followed by a conversion except where the fp32
+    value is an exact rounding TIE of the storage type (hipcc folds the last fused multiply-add and the conversion into one
+    v_fma_mixlo: a single rounding of the exact sum, where fp32-then-fp16 rounds twice; measured 6e-5 of the elements, one ulp)."""
+
+    def same_up_to_ties(got, ref32):
+        want = ref32.to(got.dtype)
+        ne = got != want
+        ulp = 2.0 ** (-10 if got.dtype == torch.float16 else -7)
+        err = ((got.float() - ref32).abs() / ref32.abs().clamp_min(1e-3)).max()
+        return int(ne.sum()) <= 1e-3 * got.numel() and float(err) <= 0.51 * ulp * 1.01
+    import ctypes as C
+    g = torch.Generator().manual_seed(ow)
+    geo = ((5, 5), (3, 5), (5, 3))
+    S, rep = 70, 7
+    xs = [torch.randn(S // rep, ow + hk - 1, ow + wk - 1, 256, generator=g).to(DEV) for hk, wk in geo]
+    zs = [torch.randn(S, hk, wk, 256, generator=g).to(DEV) for hk, wk in geo]
+    w = np.array([0.2, 0.3, 0.5], np.float32)
+    ref = hip.groupdw(xs, zs, w, x_rep=rep, cols=6)
+    out = torch.full((S * ow * ow * 256 + 8,), 3.0, dtype=dtype, device=DEV)
+    d = hip.groupdw_desc([t.data_ptr() for t in xs], [t.data_ptr() for t in zs], out.data_ptr(), w, S=S, x_rep=rep, OH=ow, OW=ow, Cc=256,
+                         x_cs=[256] * 3, x_co=[0] * 3, z_cs=[256] * 3, z_co=[0] * 3)
+    dt = 1 if dtype == torch.float16 else 2
+    hip.check(hip.lib().usot_groupdw_multi_lp(hip.stream(), C.byref(d), 1, dt), 'groupdw_multi_lp')
+    torch.cuda.synchronize()
+    assert same_up_to_ties(out[:-8].reshape(ref.shape), ref) and torch.all(out[-8:] == 3.0)
+    assert hip.lib().usot_groupdw_multi_lp(hip.stream(), C.byref(d), 1, 0) != 0
+    B, M, P = 3, 7, ow * ow
+    cv = torch.rand(B * M, ow, ow, 512, generator=g).to(DEV) + 0.1
+    r32 = hip.conf_fusion_reduce(cv, B, M)
+    o = torch.full((B * P * 256 + 8,), 3.0, dtype=dtype, device=DEV)
+    hip.check(hip.lib().usot_conf_fusion_reduce_lp(hip.stream(), hip.ptr(cv), hip.ptr(o), B, M, P, 256, dt), 'conf_reduce_lp')
+    torch.cuda.synchronize()
+    assert same_up_to_ties(o[:-8].reshape(r32.shape), r32) and torch.all(o[-8:] == 3.0)

@@ -11,6 +11,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- Conf_Fusion (connect.py:132-142): out = sum_m conf_m * value_m / sum_m conf_m -------
+template <int OT>        // OT: 0 = fp32 output, 1 = fp16, 2 = bf16 (`out` then points to 16-bit elements)
 __global__ __launch_bounds__(256) void conf_fusion_reduce_kernel(
     const float *__restrict__ cv, float *__restrict__ out, int B, int M, int P, int C4)
 {
@@ -30,7 +31,18 @@ __global__ __launch_bounds__(256) void conf_fusion_reduce_kernel(
             const f32x4 v4 = *(const f32x4 *)(base + m * mstride + C4 * 4);
             num += (c4 / den) * v4;
         }
-        *(f32x4 *)(out + idx * 4) = num;
+        if constexpr (OT == 0) {
+            *(f32x4 *)(out + idx * 4) = num;
+        } else {
+            uint16_t h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                h[e] = OT == 1 ? __builtin_bit_cast(uint16_t, (_Float16)num[e]) : __builtin_bit_cast(uint16_t, (__bf16)num[e]);
+            uint2 o2;
+            o2.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+            o2.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+            *(uint2 *)((uint16_t *)out + idx * 4) = o2;
+        }
     }
 }
 
@@ -642,8 +654,21 @@ extern "C" int usot_conf_fusion_reduce_f32(void *stream, const float *cv, float 
     if (((uintptr_t)cv % 16) || ((uintptr_t)out % 16)) return USOT_EINVAL;
     const long total = (long)B * P * (C / 4);
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(conf_fusion_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(conf_fusion_reduce_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        cv, out, B, M, P, C / 4);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+/* the same reduction with the result stored as fp16 (out_dtype 1) or bf16 (2): fp32 arithmetic, one rounding */
+extern "C" int usot_conf_fusion_reduce_lp(void *stream, const float *cv, void *out, int B, int M, int P, int C, int out_dtype)
+{
+    if (!cv || !out || B <= 0 || M <= 0 || P <= 0 || C <= 0 || (C & 3) || (out_dtype != 1 && out_dtype != 2)) return USOT_EINVAL;
+    if (((uintptr_t)cv % 16) || ((uintptr_t)out % 8)) return USOT_EINVAL;
+    const long total = (long)B * P * (C / 4);
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (out_dtype == 1) hipLaunchKernelGGL(conf_fusion_reduce_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cv, (float *)out, B, M, P, C / 4);
+    else                hipLaunchKernelGGL(conf_fusion_reduce_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cv, (float *)out, B, M, P, C / 4);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }

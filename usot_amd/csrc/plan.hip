@@ -78,7 +78,7 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
                 rc = usot_conv2d_batch_f32(s, tmp, op.nconv);
             }
             break;
-        case K_GDW:  rc = usot_groupdw_multi_f32(s, op.gdw, op.ngdw); break;
+        case K_GDW:  rc = op.i[6] ? usot_groupdw_multi_lp(s, op.gdw, op.ngdw, op.i[6]) : usot_groupdw_multi_f32(s, op.gdw, op.ngdw); break;
         case K_STEM:
             rc = usot_stem_conv_mu_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2],
                                        (float *)op.p[3], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.f[1], op.f[2], op.f[3]);
@@ -88,8 +88,9 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
                                        op.i[3], op.i[4], op.i[5]);
             break;
         case K_CONF:
-            rc = usot_conf_fusion_reduce_f32(s, (const float *)op.p[0], (float *)op.p[1], op.i[0], op.i[1],
-                                             op.i[2], op.i[3]);
+            rc = op.i[6] ? usot_conf_fusion_reduce_lp(s, (const float *)op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[6])
+                         : usot_conf_fusion_reduce_f32(s, (const float *)op.p[0], (float *)op.p[1], op.i[0], op.i[1],
+                                                       op.i[2], op.i[3]);
             break;
         case K_PRROI:
             rc = usot_prroi_pool_forward_f32(s, (const float *)op.p[0], (const float *)op.p[1], (float *)op.p[2],
@@ -493,6 +494,27 @@ extern "C" int usot_plan_add_groupdw_multi(void *plan, const usot_groupdw_desc *
     if (!op) return USOT_ESTATE;
     for (int i = 0; i < nseg; ++i) op->gdw[i] = d[i];
     op->ngdw = nseg;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_groupdw_multi_lp(void *plan, const usot_groupdw_desc *d, int nseg, int out_dtype)
+{
+    if (!d || nseg < 1 || nseg > 3 || (out_dtype != 1 && out_dtype != 2)) return USOT_EINVAL;
+    Op *op = push(plan, K_GDW);
+    if (!op) return USOT_ESTATE;
+    for (int i = 0; i < nseg; ++i) op->gdw[i] = d[i];
+    op->ngdw = nseg;
+    op->i[6] = out_dtype;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_conf_reduce_lp(void *plan, const float *cv, void *out, int B, int M, int P, int C, int out_dtype)
+{
+    if (out_dtype != 1 && out_dtype != 2) return USOT_EINVAL;
+    Op *op = push(plan, K_CONF);
+    if (!op) return USOT_ESTATE;
+    op->p[0] = cv; op->p[1] = out;
+    op->i[0] = B; op->i[1] = M; op->i[2] = P; op->i[3] = C; op->i[6] = out_dtype;
     return USOT_OK;
 }
 

@@ -565,7 +565,10 @@ __device__ __forceinline__ void gdw_dma16(const float *src, const float *lds_dst
                      : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
 }
 
-template <int OWT, bool NT = false>
+// OT: storage type of the OUTPUT (0 = fp32; 1 = fp16, 2 = bf16: `out` then points to 16-bit elements — the batched mixed-precision
+// heads feed these maps to fp16 convolutions, and a separate conversion pass cost 37 + 21 us per batch of 32; same fp32
+// arithmetic, one rounding at the store = what that pass produced)
+template <int OWT, bool NT = false, int OT = 0>
 __global__ __launch_bounds__(512) void groupdw_dma_kernel(const GdwK p)
 {
     using G = GdwDma<OWT>;
@@ -706,10 +709,18 @@ __global__ __launch_bounds__(512) void groupdw_dma_kernel(const GdwK p)
         // output row r-4 is complete; its ring slot is (RHO + 1) % 5 and becomes output row r+1
         constexpr int DONE = (RHO + 1) % 5;
         if (r >= 4) {
-            float *orow = o + (long)(r - 4) * p.OW * p.C;
+            if constexpr (OT == 0) {
+                float *orow = o + (long)(r - 4) * p.OW * p.C;
 #pragma unroll
-            for (int j = 0; j < 7; ++j)
-                if (j < nvalid) orow[(long)j * p.C] = A[DONE][j];
+                for (int j = 0; j < 7; ++j)
+                    if (j < nvalid) orow[(long)j * p.C] = A[DONE][j];
+            } else {
+                uint16_t *orow = (uint16_t *)g.out + (o - g.out) + (long)(r - 4) * p.OW * p.C;
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    if (j < nvalid)
+                        orow[(long)j * p.C] = OT == 1 ? __builtin_bit_cast(uint16_t, (_Float16)A[DONE][j]) : __builtin_bit_cast(uint16_t, (__bf16)A[DONE][j]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 7; ++j) A[DONE][j] = 0.f;
@@ -1074,7 +1085,7 @@ extern "C" int usot_groupdw_auto_variant(int total_samples, int OW)
     return groupdw_auto_mode(total_samples, OW);
 }
 
-extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, int nseg)
+static int groupdw_multi_impl(void *stream, const usot_groupdw_desc *d, int nseg, int out_dtype)
 {
     if (!d || nseg < 1 || nseg > 3) return USOT_EINVAL;
     static const int hk[3] = {5, 3, 5}, wk[3] = {5, 5, 3};
@@ -1099,7 +1110,12 @@ extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, 
     // variant: 0 -> auto (5x1 strips for a frame's 9 samples, ring for >= 64 samples);
     // 1 strips, 5/50/52 5x5 patches (register budgets), 2 column threads, 3 LDS row streaming, 4 ring
     int mode = d[0].cols_per_thread != 0 ? d[0].cols_per_thread : groupdw_auto_mode(total, p.OW);
-    if (d[0].cols_per_thread == 0 && mode == 6) {
+    if (out_dtype) {                     // 16-bit outputs: the LDS-DMA kernel only (25- / 27-wide responses)
+        if (out_dtype != 1 && out_dtype != 2) return USOT_EINVAL;
+        if (p.OW != 25 && p.OW != 27) return USOT_EINVAL;
+        mode = 6;
+    }
+    if (d[0].cols_per_thread == 0 && mode == 6 && !out_dtype) {
         // search rows that ONE sample reads once stream with the non-temporal policy (round 4, scripts/xcorr_probe2.py: 128 samples
         // 90 -> 82 us, 512: 336 -> 332, 2048: equal; MI355X_MICROARCH.md 'nt-weights'); maps shared by x_rep samples (the memory
         // branch of a frame batch) keep the default policy: their re-reads are L2 hits
@@ -1157,6 +1173,25 @@ extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, 
             (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<25, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<25>::LDS_BYTES);
             (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<27, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<27>::LDS_BYTES);
             attr_set = true;
+        }
+        if (out_dtype) {
+            static bool attr_lp = false;
+            if (!attr_lp) {
+                (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<25, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<25>::LDS_BYTES);
+                (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<27, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<27>::LDS_BYTES);
+                (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<25, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<25>::LDS_BYTES);
+                (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<27, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<27>::LDS_BYTES);
+                attr_lp = true;
+            }
+            if (p.OW == 25) {
+                if (out_dtype == 1) hipLaunchKernelGGL((groupdw_dma_kernel<25, false, 1>), dim3((unsigned)nb), dim3(512), GdwDma<25>::LDS_BYTES, s, p);
+                else                hipLaunchKernelGGL((groupdw_dma_kernel<25, false, 2>), dim3((unsigned)nb), dim3(512), GdwDma<25>::LDS_BYTES, s, p);
+            } else {
+                if (out_dtype == 1) hipLaunchKernelGGL((groupdw_dma_kernel<27, false, 1>), dim3((unsigned)nb), dim3(512), GdwDma<27>::LDS_BYTES, s, p);
+                else                hipLaunchKernelGGL((groupdw_dma_kernel<27, false, 2>), dim3((unsigned)nb), dim3(512), GdwDma<27>::LDS_BYTES, s, p);
+            }
+            USOT_CHECK_LAUNCH();
+            return USOT_OK;
         }
         if (p.OW == 25) {
             if (mode == 7) hipLaunchKernelGGL((groupdw_dma_kernel<25, true>), dim3((unsigned)nb), dim3(512), GdwDma<25>::LDS_BYTES, s, p);
@@ -1220,4 +1255,17 @@ extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, 
 extern "C" int usot_groupdw_f32(void *stream, const usot_groupdw_desc *d)
 {
     return usot_groupdw_multi_f32(stream, d, 1);
+}
+
+extern "C" int usot_groupdw_multi_f32(void *stream, const usot_groupdw_desc *d, int nseg)
+{
+    return groupdw_multi_impl(stream, d, nseg, 0);
+}
+
+/* the same launch with the OUTPUT maps stored as fp16 (out_dtype 1) or bf16 (2): d[i].out points to 16-bit elements.  fp32
+ * arithmetic, one rounding at the store.  25- and 27-wide responses (the LDS-DMA kernel). */
+extern "C" int usot_groupdw_multi_lp(void *stream, const usot_groupdw_desc *d, int nseg, int out_dtype)
+{
+    if (out_dtype != 1 && out_dtype != 2) return USOT_EINVAL;
+    return groupdw_multi_impl(stream, d, nseg, out_dtype);
 }

@@ -669,7 +669,11 @@ class Builder:
         es = [self.conv_bf16('enc_s%d' % g, W.enc_s[g], xf_lp, b, hf, hf, act=ACT_RELU, dtype=dtype, out_f32=True)[0]
               for g in range(3)]
         S = hf - 6
-        tin = self.buf(3, b, S, S, 256)               # tower inputs: [reg, cls, memory]
+        # lp_head_maps: GroupDW and the Conf_Fusion reduction store their maps in the storage type themselves (fp32 arithmetic,
+        # one rounding at the store: the values the separate conversion passes produced, 37 + 21 us per batch of 32 less)
+        direct = self.opt['lp_head_maps'] and S in (25, 27) and b * (2 + m) >= 64
+        odt = 1 if dtype == torch.float16 else 2
+        tin = self.buf(3, b, S, S, 256, dtype=dtype if direct else torch.float32)     # tower inputs: [reg, cls, memory]
         if self.opt['enc_k_lp']:
             # the memory features' kernel-side encoders on the low-precision MFMA too (fp32 output for the fp32 correlations):
             # at 32 streams x 7 memory features the fp32 launch was 197 us of the 3.1 ms batch (74 TFLOP/s)
@@ -678,16 +682,25 @@ class Builder:
                   for g in range(3)]
         else:
             mk = self.encode_kernel(mem_nhwc, b * m, 256, 'mem')
-        dwm = self.buf(b * m, S, S, 256)
-        self.groupdw_flush([self.groupdw(es, zk, tin[0], W.reg_wsm, b, 1, S, S, 256, 512),
-                            self.groupdw(es, zk, tin[1], W.cls_wsm, b, 1, S, S, 0, 512),
-                            self.groupdw(es, mk, dwm, W.cls_wsm, b * m, m, S, S, 0, 256)])
-        cv, _, _ = self.conv_bf16('conf_fusion', W.conf, self.cvt_lp(dwm, dtype), b * m, S, S, act=ACT_CONF, act2=ACT_RELU,
+        dwm = self.buf(b * m, S, S, 256, dtype=dtype if direct else torch.float32)
+        segs = [self.groupdw(es, zk, tin[0], W.reg_wsm, b, 1, S, S, 256, 512),
+                self.groupdw(es, zk, tin[1], W.cls_wsm, b, 1, S, S, 0, 512),
+                self.groupdw(es, mk, dwm, W.cls_wsm, b * m, m, S, S, 0, 256)]
+        if direct:
+            arr = (hip.GroupDWDesc * 3)(*segs)
+            hip.check(L.usot_plan_add_groupdw_multi_lp(self.plan.h, arr, 3, odt), 'plan_add_groupdw_multi_lp')
+        else:
+            self.groupdw_flush(segs)
+        cv, _, _ = self.conv_bf16('conf_fusion', W.conf, dwm if direct else self.cvt_lp(dwm, dtype), b * m, S, S, act=ACT_CONF, act2=ACT_RELU,
                                   act_split=256, dtype=dtype, out_f32=True)
-        hip.check(L.usot_plan_add_conf_reduce(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256),
-                  'plan_add_conf_reduce')
+        if direct:
+            hip.check(L.usot_plan_add_conf_reduce_lp(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256, odt),
+                      'plan_add_conf_reduce_lp')
+        else:
+            hip.check(L.usot_plan_add_conf_reduce(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256),
+                      'plan_add_conf_reduce')
         gs = b * S * S * 256
-        cur = self.cvt_lp(tin, dtype)
+        cur = tin if direct else self.cvt_lp(tin, dtype)
         for i in range(4):
             cur, _, _ = self.conv_bf16('tower%d' % i, W.tower[i], cur, b, S, S, cout=256, act=ACT_RELU, groups=3, x_gs=gs,
                                        dtype=dtype, out_f32=(i == 3))
@@ -939,6 +952,8 @@ DEFAULT_OPTIONS = {
     'bneck_first_min_tiles': 512,
     # heads_lp (configs[4]): the memory features' kernel-side encoders (connect.py:55-74 `_k` branches) on the low-precision MFMA
     'enc_k_lp': True,
+    # heads_lp: GroupDW and the Conf_Fusion reduction write their output maps in the storage type (no conversion passes)
+    'lp_head_maps': True,
     # ... and the REST of layer1's other bottlenecks (conv2 + conv3 + residual) + the following conv1 likewise (bneck_tail_kernel)
     'bneck_tail_lp': True,
     # (Cin, Cout) of the 3x3 / stride-1 / pad-1 convolutions of the low-precision backbone that run as direct convolutions

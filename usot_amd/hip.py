@@ -22,7 +22,7 @@ EXPORTS = (
     'usot_plan_add_maxpool', 'usot_plan_add_groupdw', 'usot_plan_add_conf_reduce',
     'usot_plan_add_prroi', 'usot_plan_add_permute', 'usot_plan_add_decode', 'usot_plan_run',
     'usot_plan_fork', 'usot_plan_join', 'usot_plan_capture', 'usot_plan_size',
-    'usot_groupdw_multi_f32', 'usot_plan_add_groupdw_multi', 'usot_conv2d_batch_f32', 'usot_plan_add_conv_batch', 'usot_conv2d_bf16', 'usot_conv_bf16_tile_count', 'usot_cvt_f32_to_bf16', 'usot_maxpool3x3s2_bf16',
+    'usot_groupdw_multi_f32', 'usot_plan_add_groupdw_multi', 'usot_groupdw_multi_lp', 'usot_plan_add_groupdw_multi_lp', 'usot_conf_fusion_reduce_lp', 'usot_plan_add_conf_reduce_lp', 'usot_conv2d_batch_f32', 'usot_plan_add_conv_batch', 'usot_conv2d_bf16', 'usot_conv_bf16_tile_count', 'usot_cvt_f32_to_bf16', 'usot_maxpool3x3s2_bf16',
     'usot_plan_add_conv_bf16', 'usot_plan_add_cvt_bf16', 'usot_plan_add_maxpool_bf16',
     'usot_conv2d_lp', 'usot_cvt_f32_to_lp', 'usot_maxpool3x3s2_lp', 'usot_plan_add_conv_lp', 'usot_plan_add_cvt_lp',
     'usot_plan_add_maxpool_lp', 'usot_stem_pool_lp', 'usot_plan_add_stem_pool_lp',
@@ -183,6 +183,10 @@ def lib():
         L.usot_groupdw_f32.argtypes = [C.c_void_p, C.c_void_p]
         L.usot_groupdw_multi_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_plan_add_groupdw_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.usot_plan_add_groupdw_multi_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.usot_groupdw_multi_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.usot_conf_fusion_reduce_lp.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5
+        L.usot_plan_add_conf_reduce_lp.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5
         L.usot_stem_conv_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5
         L.usot_maxpool3x3s2_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6
         L.usot_xcorr_depthwise_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5
