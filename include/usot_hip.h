@@ -142,6 +142,7 @@ int usot_pw_panel_lp(void *stream, const void *x, const void *w, const float *bi
                      int M, int K, int N, int act, int dtype);
 int usot_pw_panel_supported(int K, int N);
 int usot_pw_panel_pixels(int CM, int CO, int CN);      /* pixels per panel = per workgroup (CN = 0: single conv); 0 = unsupported */
+int usot_pw_panel_min_pixels(int K, int N);           /* the smallest panel of the single convolution (used below 192 default panels) */
 int usot_plan_add_pw_panel(void *plan, const void *x, const void *w, const float *bias, const void *res, void *y,
                            int M, int K, int N, int act, int dtype);
 /* ... and the fused pair of usot_pw_pair_lp in that form: Y's sixteen channels per lane, rounded, are the B fragments of

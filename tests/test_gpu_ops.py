@@ -897,7 +897,9 @@ def test_stem_pool_f32(size, n):
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 @pytest.mark.parametrize('K,N,M,res,act', [(256, 1024, 256 * 3, True, 1), (256, 1024, 1000, True, 1), (256, 1024, 77, False, 0),
-                                           (128, 512, 256 * 2 + 5, True, 1), (64, 256, 512 * 2 + 130, False, 0), (64, 256, 512, True, 1)])
+                                           (128, 512, 256 * 2 + 5, True, 1), (64, 256, 512 * 2 + 130, False, 0), (64, 256, 512, True, 1),
+                                           # >= 192 panels of 256 pixels: the two-pixel-blocks-per-wave form (below: 128-pixel panels)
+                                           (256, 1024, 192 * 256 + 19, True, 1), (128, 512, 193 * 256, True, 1)])
 def test_pw_panel_lp_expansion_conv(K, N, M, res, act, dtype):
     """Pixel-stationary 1x1 expansion conv (csrc/pw_panel.hip) vs the SAME rounded operands in float64: full and ragged panels
     (M not a multiple of the panel, fewer pixels than one wave's block), with / without residual and ReLU; and bit-equal to the

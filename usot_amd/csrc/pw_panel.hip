@@ -425,8 +425,11 @@ extern "C" int usot_pw_panel_lp(void *stream, const void *x, const void *w, cons
     p.x = (const uint16_t *)x; p.w = (const uint16_t *)w; p.res = (const uint16_t *)res; p.bias = bias; p.y = (uint16_t *)y;
     p.M = M; p.act = act;
     hipStream_t s = (hipStream_t)stream;
-    if (K == 256) return panel_launch<256, 1024, 0, 2>(s, p, dtype);
-    if (K == 128) return panel_launch<128, 512, 0, 2>(s, p, dtype);
+    // fewer than 192 panels of 256 pixels (batch 32 at layer2 / layer3 resolution: 121) would leave half the chip idle: panels of
+    // 128 pixels then (one pixel block per wave; round 4)
+    const bool small = (M + 255) / 256 < 192;
+    if (K == 256) return small ? panel_launch<256, 1024, 0, 1>(s, p, dtype) : panel_launch<256, 1024, 0, 2>(s, p, dtype);
+    if (K == 128) return small ? panel_launch<128, 512, 0, 1>(s, p, dtype) : panel_launch<128, 512, 0, 2>(s, p, dtype);
     return panel_launch<64, 256, 0, 4>(s, p, dtype);
 }
 
@@ -441,6 +444,13 @@ extern "C" int usot_pw_panel_pixels(int CM, int CO, int CN)
     if (!usot_pw_panel_pair_supported(CM, CO, CN)) return 0;
     if (CM == 128) return CN == 128 ? PanelCfg<128, 512, 128, 2>::BM : PanelCfg<128, 512, 256, 1>::BM;
     return CN == 64 ? PanelCfg<64, 256, 64, 2>::BM : PanelCfg<64, 256, 128, 2>::BM;
+}
+
+/* the smallest panel the single convolution runs on (the launcher switches to it below 192 panels of the default size) */
+extern "C" int usot_pw_panel_min_pixels(int K, int N)
+{
+    if (!usot_pw_panel_supported(K, N)) return 0;
+    return K == 64 ? PanelCfg<64, 256, 0, 4>::BM : 128;
 }
 
 extern "C" int usot_pw_panel_pair_supported(int CM, int CO, int CN)

@@ -458,7 +458,7 @@ class Builder:
         if (tile == 0 and pc.kh == 1 and pc.kw == 1 and pc.stride == 1 and groups == 1 and not out_f32 and cout == pc.cout
                 and act in (ACT_NONE, ACT_RELU) and act_split == 0 and (k, cout) in self.opt['panel_1x1_lp']
                 and hip.lib().usot_pw_panel_supported(k, cout)
-                and n * oh * ow >= self.opt['panel_min_panels'] * hip.lib().usot_pw_panel_pixels(k, cout, 0)):
+                and n * oh * ow >= self.opt['panel_min_panels'] * hip.lib().usot_pw_panel_min_pixels(k, cout)):
             hip.check(hip.lib().usot_plan_add_pw_panel(self.plan.h, hip.ptr(x), hip.ptr(wb), hip.ptr(pc.b),
                                                        hip.ptr(res) if res is not None else None, hip.ptr(y), n * oh * ow, k, cout,
                                                        act, 1 if dtype == torch.float16 else 0), 'plan_add_pw_panel ' + name)
