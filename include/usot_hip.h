@@ -306,7 +306,7 @@ int usot_groupdw_multi_lp(void *stream, const usot_groupdw_desc *d, int nseg, in
  * sum_m conf*value / sum_m conf.                                                       */
 int usot_conf_fusion_reduce_f32(void *stream, const float *cv, float *out,
                                 int B, int M, int P, int C);
-int usot_conf_fusion_reduce_lp(void *stream, const float *cv, void *out, int B, int M, int P, int C, int out_dtype);   /* out fp16 (1) | bf16 (2) */
+int usot_conf_fusion_reduce_lp(void *stream, const void *cv, int in_dtype, void *out, int B, int M, int P, int C, int out_dtype);   /* cv fp32 (0) | fp16 (1) | bf16 (2); out fp16 (1) | bf16 (2) */
 
 /* ---- Precise RoI Pooling forward.  Replaces PrRoIPoolingForwardGpu
  * (prroi_pooling_gpu_impl.cuh:20-28 / .cu:149-212,387-402) with explicit strides so the
@@ -450,7 +450,7 @@ int usot_plan_add_stem_mu(void *plan, const float *x, const float *w, const floa
 int usot_plan_add_maxpool(void *plan, const float *x, float *y, int N, int H, int W, int C,
                           int OH, int OW);
 int usot_plan_add_conf_reduce(void *plan, const float *cv, float *out, int B, int M, int P, int C);
-int usot_plan_add_conf_reduce_lp(void *plan, const float *cv, void *out, int B, int M, int P, int C, int out_dtype);
+int usot_plan_add_conf_reduce_lp(void *plan, const void *cv, int in_dtype, void *out, int B, int M, int P, int C, int out_dtype);
 int usot_plan_add_prroi(void *plan, const float *feat, const float *rois, float *out,
                         int R, int C, int H, int W, int PH, int PW, float scale,
                         int64_t f_sb, int64_t f_sc, int64_t f_sh, int64_t f_sw,

@@ -1228,6 +1228,13 @@ def test_groupdw_and_conf_reduce_low_precision_outputs(ow, dtype):
     cv = torch.rand(B * M, ow, ow, 512, generator=g).to(DEV) + 0.1
     r32 = hip.conf_fusion_reduce(cv, B, M)
     o = torch.full((B * P * 256 + 8,), 3.0, dtype=dtype, device=DEV)
-    hip.check(hip.lib().usot_conf_fusion_reduce_lp(hip.stream(), hip.ptr(cv), hip.ptr(o), B, M, P, 256, dt), 'conf_reduce_lp')
+    hip.check(hip.lib().usot_conf_fusion_reduce_lp(hip.stream(), hip.ptr(cv), 0, hip.ptr(o), B, M, P, 256, dt), 'conf_reduce_lp')
     torch.cuda.synchronize()
     assert same_up_to_ties(o[:-8].reshape(r32.shape), r32) and torch.all(o[-8:] == 3.0)
+    # ... and with the confidence | value map itself in the storage type: the fp32 reduction of the ROUNDED map
+    cvl = cv.to(dtype)
+    r32l = hip.conf_fusion_reduce(cvl.float(), B, M)
+    o.fill_(3.0)
+    hip.check(hip.lib().usot_conf_fusion_reduce_lp(hip.stream(), hip.ptr(cvl), dt, hip.ptr(o), B, M, P, 256, dt), 'conf_reduce_lp in')
+    torch.cuda.synchronize()
+    assert same_up_to_ties(o[:-8].reshape(r32l.shape), r32l) and torch.all(o[-8:] == 3.0)

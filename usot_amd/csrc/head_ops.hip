@@ -11,9 +11,28 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- Conf_Fusion (connect.py:132-142): out = sum_m conf_m * value_m / sum_m conf_m -------
-template <int OT>        // OT: 0 = fp32 output, 1 = fp16, 2 = bf16 (`out` then points to 16-bit elements)
+// OT: 0 = fp32 output, 1 = fp16, 2 = bf16 (`out` then points to 16-bit elements); IT likewise for the INPUT map cv
+template <int IT> __device__ __forceinline__ f32x4 cf_load4(const void *base, long e)
+{
+    if constexpr (IT == 0) {
+        return *(const f32x4 *)((const float *)base + e);
+    } else {
+        const uint2 v = *(const uint2 *)((const uint16_t *)base + e);
+        f32x4 r;
+        if constexpr (IT == 1) {
+            r[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(v.x & 0xffffu)); r[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(v.x >> 16));
+            r[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(v.y & 0xffffu)); r[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(v.y >> 16));
+        } else {
+            r[0] = __builtin_bit_cast(float, v.x << 16); r[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+            r[2] = __builtin_bit_cast(float, v.y << 16); r[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+        }
+        return r;
+    }
+}
+
+template <int OT, int IT = 0>
 __global__ __launch_bounds__(256) void conf_fusion_reduce_kernel(
-    const float *__restrict__ cv, float *__restrict__ out, int B, int M, int P, int C4)
+    const void *__restrict__ cv, float *__restrict__ out, int B, int M, int P, int C4)
 {
     const long total = (long)B * P * C4;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -22,13 +41,13 @@ __global__ __launch_bounds__(256) void conf_fusion_reduce_kernel(
         const int pix = (int)(bp % P);
         const int b = (int)(bp / P);
         f32x4 den = {0.f, 0.f, 0.f, 0.f}, num = {0.f, 0.f, 0.f, 0.f};
-        const float *base = cv + ((long)b * M * P + pix) * 2 * C4 * 4 + c * 4;
+        const long base = ((long)b * M * P + pix) * 2 * C4 * 4 + c * 4;        // element index of this lane's four conf values
         const long mstride = (long)P * 2 * C4 * 4;
-        for (int m = 0; m < M; ++m) den += *(const f32x4 *)(base + m * mstride);
+        for (int m = 0; m < M; ++m) den += cf_load4<IT>(cv, base + m * mstride);
         // same association as the reference: normalise each conf, then weight and add
         for (int m = 0; m < M; ++m) {
-            const f32x4 c4 = *(const f32x4 *)(base + m * mstride);        // L1/L2 hit
-            const f32x4 v4 = *(const f32x4 *)(base + m * mstride + C4 * 4);
+            const f32x4 c4 = cf_load4<IT>(cv, base + m * mstride);        // L1/L2 hit
+            const f32x4 v4 = cf_load4<IT>(cv, base + m * mstride + C4 * 4);
             num += (c4 / den) * v4;
         }
         if constexpr (OT == 0) {
@@ -654,21 +673,25 @@ extern "C" int usot_conf_fusion_reduce_f32(void *stream, const float *cv, float 
     if (((uintptr_t)cv % 16) || ((uintptr_t)out % 16)) return USOT_EINVAL;
     const long total = (long)B * P * (C / 4);
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(conf_fusion_reduce_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       cv, out, B, M, P, C / 4);
+    hipLaunchKernelGGL((conf_fusion_reduce_kernel<0, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const void *)cv, out, B, M, P, C / 4);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }
 
-/* the same reduction with the result stored as fp16 (out_dtype 1) or bf16 (2): fp32 arithmetic, one rounding */
-extern "C" int usot_conf_fusion_reduce_lp(void *stream, const float *cv, void *out, int B, int M, int P, int C, int out_dtype)
+/* the same reduction with the result stored as fp16 (out_dtype 1) or bf16 (2) and the input map cv in fp32 (in_dtype 0), fp16 (1)
+ * or bf16 (2): fp32 arithmetic, one rounding */
+extern "C" int usot_conf_fusion_reduce_lp(void *stream, const void *cv, int in_dtype, void *out, int B, int M, int P, int C, int out_dtype)
 {
     if (!cv || !out || B <= 0 || M <= 0 || P <= 0 || C <= 0 || (C & 3) || (out_dtype != 1 && out_dtype != 2)) return USOT_EINVAL;
-    if (((uintptr_t)cv % 16) || ((uintptr_t)out % 8)) return USOT_EINVAL;
+    if (in_dtype < 0 || in_dtype > 2 || ((uintptr_t)cv % (in_dtype ? 8 : 16)) || ((uintptr_t)out % 8)) return USOT_EINVAL;
     const long total = (long)B * P * (C / 4);
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    if (out_dtype == 1) hipLaunchKernelGGL(conf_fusion_reduce_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cv, (float *)out, B, M, P, C / 4);
-    else                hipLaunchKernelGGL(conf_fusion_reduce_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cv, (float *)out, B, M, P, C / 4);
+    hipStream_t s = (hipStream_t)stream;
+#define CF_LAUNCH(OT, IT) hipLaunchKernelGGL((conf_fusion_reduce_kernel<OT, IT>), dim3(blocks), dim3(256), 0, s, cv, (float *)out, B, M, P, C / 4)
+    if (out_dtype == 1) { if (in_dtype == 0) CF_LAUNCH(1, 0); else if (in_dtype == 1) CF_LAUNCH(1, 1); else CF_LAUNCH(1, 2); }
+    else                { if (in_dtype == 0) CF_LAUNCH(2, 0); else if (in_dtype == 1) CF_LAUNCH(2, 1); else CF_LAUNCH(2, 2); }
+#undef CF_LAUNCH
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }

@@ -88,7 +88,7 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
                                        op.i[3], op.i[4], op.i[5]);
             break;
         case K_CONF:
-            rc = op.i[6] ? usot_conf_fusion_reduce_lp(s, (const float *)op.p[0], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[6])
+            rc = op.i[6] ? usot_conf_fusion_reduce_lp(s, op.p[0], op.i[5], (void *)op.p[1], op.i[0], op.i[1], op.i[2], op.i[3], op.i[6])
                          : usot_conf_fusion_reduce_f32(s, (const float *)op.p[0], (float *)op.p[1], op.i[0], op.i[1],
                                                        op.i[2], op.i[3]);
             break;
@@ -508,13 +508,13 @@ extern "C" int usot_plan_add_groupdw_multi_lp(void *plan, const usot_groupdw_des
     return USOT_OK;
 }
 
-extern "C" int usot_plan_add_conf_reduce_lp(void *plan, const float *cv, void *out, int B, int M, int P, int C, int out_dtype)
+extern "C" int usot_plan_add_conf_reduce_lp(void *plan, const void *cv, int in_dtype, void *out, int B, int M, int P, int C, int out_dtype)
 {
-    if (out_dtype != 1 && out_dtype != 2) return USOT_EINVAL;
+    if ((out_dtype != 1 && out_dtype != 2) || in_dtype < 0 || in_dtype > 2) return USOT_EINVAL;
     Op *op = push(plan, K_CONF);
     if (!op) return USOT_ESTATE;
     op->p[0] = cv; op->p[1] = out;
-    op->i[0] = B; op->i[1] = M; op->i[2] = P; op->i[3] = C; op->i[6] = out_dtype;
+    op->i[0] = B; op->i[1] = M; op->i[2] = P; op->i[3] = C; op->i[5] = in_dtype; op->i[6] = out_dtype;
     return USOT_OK;
 }
 

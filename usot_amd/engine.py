@@ -691,10 +691,13 @@ class Builder:
             hip.check(L.usot_plan_add_groupdw_multi_lp(self.plan.h, arr, 3, odt), 'plan_add_groupdw_multi_lp')
         else:
             self.groupdw_flush(segs)
+        # the confidence | value map itself in fp16 (not bf16: exp(.) <= 54.6 on 8 bits would put 0.4 % on every weight): half the
+        # bytes of the 287 MB map the reduction reads at 32 streams
+        cv16 = direct and dtype == torch.float16
         cv, _, _ = self.conv_bf16('conf_fusion', W.conf, dwm if direct else self.cvt_lp(dwm, dtype), b * m, S, S, act=ACT_CONF, act2=ACT_RELU,
-                                  act_split=256, dtype=dtype, out_f32=True)
+                                  act_split=256, dtype=dtype, out_f32=not cv16)
         if direct:
-            hip.check(L.usot_plan_add_conf_reduce_lp(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256, odt),
+            hip.check(L.usot_plan_add_conf_reduce_lp(self.plan.h, hip.ptr(cv), 1 if cv16 else 0, hip.ptr(tin[2]), b, m, S * S, 256, odt),
                       'plan_add_conf_reduce_lp')
         else:
             hip.check(L.usot_plan_add_conf_reduce(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256),

@@ -186,8 +186,8 @@ def lib():
         L.usot_plan_add_groupdw_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_plan_add_groupdw_multi_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.usot_groupdw_multi_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-        L.usot_conf_fusion_reduce_lp.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5
-        L.usot_plan_add_conf_reduce_lp.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5
+        L.usot_conf_fusion_reduce_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5
+        L.usot_plan_add_conf_reduce_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5
         L.usot_stem_conv_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5
         L.usot_maxpool3x3s2_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6
         L.usot_xcorr_depthwise_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5
