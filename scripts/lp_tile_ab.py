@@ -10,7 +10,8 @@ from usot_amd.model import USOT
 dev = 'cuda:0'
 base = dict(engine.LP_TUNING)
 cfgs = [''] + sys.argv[1:]
-x = torch.from_numpy(synth.crop(1, 64, 255)).to(dev)
+B = int(os.environ.get('BATCH', '64'))         # BATCH=32: the per-GPU share of configs[4]
+x = torch.from_numpy(synth.crop(1, B, 255)).to(dev)
 plans = []
 for rep in range(2):
     for c in cfgs:
@@ -20,7 +21,7 @@ for rep in range(2):
             engine.LP_TUNING[tuple(int(v) for v in k.split(','))] = int(t)
         m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to(dev)
         for _ in range(3): m.engine.features_bf16(x)
-        plans.append((c or 'table', m, m.engine._feat[('bf16', 64, 255)]['plan']))
+        plans.append((c or 'table', m, m.engine._feat[('bf16', B, 255)]['plan']))
 for rnd in range(2):
     for c, m, plan in plans:
         torch.cuda.synchronize(); t0 = time.perf_counter()
