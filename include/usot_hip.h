@@ -79,7 +79,9 @@ int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int n);
 /* thin 3x3 / stride 1 / pad 1 convolutions with 1-4 output channels and NCHW output (the prediction
  * heads, connect.py:236-241,275): up to four descriptors of the same input geometry per launch, one
  * wavefront per output pixel; honours x, w, bias, y, N, H, W, Cin, Cout, act, groups and the group
- * strides of the descriptor. */
+ * strides of the descriptor.  From 1024 output rows (Cin = 256: batches of >= 14 streams) the launcher
+ * switches to one wavefront per output ROW with the filters in registers and a sliding 3x3 window —
+ * bit-identical results; d[0].tile = 70 forces the per-pixel form (tests). */
 int usot_thin_conv3x3_f32(void *stream, const usot_conv_desc *d, int n);
 int usot_plan_add_thin_conv(void *plan, const usot_conv_desc *d, int n);
 int usot_conv_tile_count(void);
