@@ -66,3 +66,20 @@ def test_product_path_never_imports_the_oracle():
                 if fn.endswith('.py'):
                     with open(os.path.join(dirpath, fn)) as f:
                         assert not pat.search(f.read()), os.path.join(dirpath, fn)
+
+
+def test_low_precision_tuning_table_names_existing_tiles(libpath):
+    """usot_amd/data/tuning_lp_gfx950.json (conv shape -> tile id of csrc/conv_bf16.hip) must only name tiles the library has:
+    a stale id would make every plan of that shape fail with EINVAL on the GPU box."""
+    import ctypes
+    import json
+    import os
+    n = ctypes.CDLL(libpath).usot_conv_bf16_tile_count()
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(here, 'usot_amd', 'data', 'tuning_lp_gfx950.json')) as f:
+        table = json.load(f)
+    assert n >= 37 and table
+    for key, tile in table.items():
+        m, cout, k = (int(v) for v in key.split(','))
+        assert m > 0 and cout > 0 and k % 64 == 0, key
+        assert 1 <= tile <= n, (key, tile, n)
