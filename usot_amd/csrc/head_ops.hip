@@ -311,6 +311,7 @@ struct ThinK {
     const float *x[4], *w[4], *bias[4];
     float *y[4];
     int cout[4], act[4], groups[4], start[5];      // start: first work item of problem i
+    int ycs[4], yco[4];                            // channels of the output tensor, first channel this problem writes (a 4-channel problem may run as two of 2)
     long x_gs[4], w_gs[4], y_gs[4];
     int b_gs[4];
     int n, N, H, W, Cin;                           // shared geometry (3x3, stride 1, pad 1)
@@ -364,7 +365,7 @@ __device__ __forceinline__ void thin_pixel(const ThinK &k, int pi, int g, int pi
         float *yg = k.y[pi] + (long)g * k.y_gs[pi];
 #pragma unroll
         for (int c = 0; c < CO; ++c)
-            yg[((long)n * CO + c) * P + r] = thin_act(acc[c] + (bg ? bg[c] : 0.f), k.act[pi]);   // NCHW
+            yg[((long)n * k.ycs[pi] + k.yco[pi] + c) * P + r] = thin_act(acc[c] + (bg ? bg[c] : 0.f), k.act[pi]);   // NCHW
     }
 }
 
@@ -421,6 +422,9 @@ __device__ __forceinline__ void thin_row(const ThinK &k, int pi, int g, int nrow
     column(1, c2);
     const float *bg = k.bias[pi] ? k.bias[pi] + (long)g * k.b_gs[pi] : nullptr;
     float *yg = k.y[pi] + (long)g * k.y_gs[pi];
+    float keep[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) keep[c] = 0.f;
     for (int ow = 0; ow < k.W; ++ow) {
         column(ow + 2, c3);                          // in flight under this pixel's arithmetic
         float acc[CO];
@@ -440,17 +444,24 @@ __device__ __forceinline__ void thin_row(const ThinK &k, int pi, int g, int nrow
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
         }
-        if (lane == 0) {
+        // the xor butterfly leaves the sum in every lane: lane `ow` keeps pixel ow's, the row is stored once per channel below
+        // (25 x CO four-byte stores from lane 0 were a write transaction each)
 #pragma unroll
-            for (int c = 0; c < CO; ++c)
-                yg[((long)n * CO + c) * P + oh * k.W + ow] = thin_act(acc[c] + (bg ? bg[c] : 0.f), k.act[pi]);   // NCHW
-        }
+        for (int c = 0; c < CO; ++c) keep[c] = lane == ow ? acc[c] : keep[c];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) { c0[dy] = c1[dy]; c1[dy] = c2[dy]; c2[dy] = c3[dy]; }
     }
+    if (lane < k.W) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+            yg[((long)n * k.ycs[pi] + k.yco[pi] + c) * P + oh * k.W + lane] = thin_act(keep[c] + (bg ? bg[c] : 0.f), k.act[pi]);   // NCHW
+    }
 }
 
-// work item = (problem, group, image, output row); k.start counts rows here
+// work item = (problem, group, image, output row); k.start counts rows here.  MAXCO = the widest problem of the launch: the
+// kernel's register allocation is that of its widest case (CO = 4: 243 registers, two waves per SIMD for EVERY problem of the
+// launch), so the launcher splits 4-channel problems in two and runs the <2> instantiation (~half the registers)
+template <int MAXCO>
 __global__ __launch_bounds__(256) void thin_conv3x3_rows_kernel(const ThinK k)
 {
     const int lane = threadIdx.x & 63;
@@ -463,11 +474,16 @@ __global__ __launch_bounds__(256) void thin_conv3x3_rows_kernel(const ThinK k)
     const int local = item - k.start[pi];
     const int per_g = k.N * k.H;
     const int g = local / per_g, nrow = local - g * per_g;
-    switch (k.cout[pi]) {
-    case 1: thin_row<1>(k, pi, g, nrow, lane); break;
-    case 2: thin_row<2>(k, pi, g, nrow, lane); break;
-    case 3: thin_row<3>(k, pi, g, nrow, lane); break;
-    default: thin_row<4>(k, pi, g, nrow, lane); break;
+    if constexpr (MAXCO <= 2) {
+        if (k.cout[pi] == 1) thin_row<1>(k, pi, g, nrow, lane);
+        else                 thin_row<2>(k, pi, g, nrow, lane);
+    } else {
+        switch (k.cout[pi]) {
+        case 1: thin_row<1>(k, pi, g, nrow, lane); break;
+        case 2: thin_row<2>(k, pi, g, nrow, lane); break;
+        case 3: thin_row<3>(k, pi, g, nrow, lane); break;
+        default: thin_row<4>(k, pi, g, nrow, lane); break;
+        }
     }
 }
 
@@ -912,7 +928,7 @@ extern "C" int usot_thin_conv3x3_f32(void *stream, const usot_conv_desc *d, int 
         }
         const int groups = c.groups > 1 ? c.groups : 1;
         k.x[i] = c.x; k.w[i] = c.w; k.bias[i] = c.bias; k.y[i] = c.y;
-        k.cout[i] = c.Cout; k.act[i] = c.act; k.groups[i] = groups;
+        k.cout[i] = c.Cout; k.act[i] = c.act; k.groups[i] = groups; k.ycs[i] = c.Cout; k.yco[i] = 0;
         k.x_gs[i] = c.x_gs; k.w_gs[i] = c.w_gs; k.y_gs[i] = c.y_gs; k.b_gs[i] = (int)c.b_gs;
         k.start[i] = total;
         if (i < n) total += groups * c.N * c.H * c.W;
@@ -922,7 +938,19 @@ extern "C" int usot_thin_conv3x3_f32(void *stream, const usot_conv_desc *d, int 
     // (>= 1024 wavefronts: 8 streams of 25 rows x 6 problem-groups); one frame keeps the wavefront-per-pixel form
     long rows = 0;
     for (int i = 0; i < n; ++i) rows += (long)k.groups[i] * k.N * k.H;
-    if (k.Cin == 256 && rows >= 1024 && d[0].tile != 70) {
+    if (k.Cin == 256 && k.W <= 64 && rows >= 1024 && d[0].tile != 70) {          // (lane ow keeps pixel ow of the row)
+        // 4-channel problems (bbox_pred) as two 2-channel ones: same arithmetic per output, the activations read twice (L2)
+        for (int i = 0; i < n && k.n < 4; ++i)
+            if (k.cout[i] == 4 && k.groups[i] == 1) {
+                const int j = k.n++;
+                k.x[j] = k.x[i]; k.w[j] = k.w[i] + 2L * 9 * k.Cin; k.bias[j] = k.bias[i] ? k.bias[i] + 2 : nullptr; k.y[j] = k.y[i];
+                k.cout[i] = k.cout[j] = 2; k.act[j] = k.act[i]; k.groups[j] = 1;
+                k.x_gs[j] = k.x_gs[i]; k.w_gs[j] = k.w_gs[i]; k.y_gs[j] = k.y_gs[i]; k.b_gs[j] = k.b_gs[i];
+                k.ycs[i] = k.ycs[j] = 4; k.yco[i] = 0; k.yco[j] = 2;
+            }
+        n = k.n;
+        int maxco = 1;
+        for (int i = 0; i < n; ++i) maxco = k.cout[i] > maxco ? k.cout[i] : maxco;
         int tr = 0;
         for (int i = 0; i < 4; ++i) {
             k.start[i] = tr;
@@ -930,7 +958,8 @@ extern "C" int usot_thin_conv3x3_f32(void *stream, const usot_conv_desc *d, int 
         }
         k.start[4] = tr;
         for (int i = n; i < 4; ++i) k.start[i] = tr;
-        hipLaunchKernelGGL(thin_conv3x3_rows_kernel, dim3((unsigned)((tr + 3) / 4)), dim3(256), 0, (hipStream_t)stream, k);
+        if (maxco <= 2) hipLaunchKernelGGL(thin_conv3x3_rows_kernel<2>, dim3((unsigned)((tr + 3) / 4)), dim3(256), 0, (hipStream_t)stream, k);
+        else            hipLaunchKernelGGL(thin_conv3x3_rows_kernel<4>, dim3((unsigned)((tr + 3) / 4)), dim3(256), 0, (hipStream_t)stream, k);
         USOT_CHECK_LAUNCH();
         return USOT_OK;
     }
