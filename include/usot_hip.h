@@ -69,6 +69,10 @@ typedef struct usot_conv_desc {
     int32_t groups;
     int64_t x_gs, w_gs, b_gs, y_gs, r_gs;
     int32_t ksplit, tile;
+    int32_t w_frag;   /* 1: `w` is in MFMA fragment order (usot_conv_pack_wfrag_f32) — required by, and only valid with, the
+                       * weight-streaming tiles (usot_conv_tile_wfrag(tile) == 1); row offsets / group strides of the bank must
+                       * be multiples of 16 rows */
+    int32_t reserved0;
 } usot_conv_desc;
 
 int usot_conv2d_f32(void *stream, const usot_conv_desc *d);
@@ -87,6 +91,13 @@ int usot_plan_add_thin_conv(void *plan, const usot_conv_desc *d, int n);
 int usot_conv_tile_count(void);
 int usot_conv_tile_info(int tile, int *bm, int *bn);           /* tile ids are 1..count */
 int usot_conv_tile_name(int tile, char *buf, int len);         /* kernel symbol of the tile */
+int usot_conv_tile_wfrag(int tile);                            /* 1: the tile streams its filters in fragment order */
+/* weight-stationary tiles (filters held in registers, k split over the 8 waves of a workgroup) serve ONE K each: returns it
+ * (0: the tile takes any K); *kpanel = the multiple Cin must have (128 / 256).  They also need Cout % 32 == 0, ksplit == 1. */
+int usot_conv_tile_kreq(int tile, int *kpanel);
+/* filter bank [Cout][K] (K % 64 == 0) -> ceil(Cout/16)*16*K floats in fragment order
+ * [16-row block][k-tile of 64][round of 16 k][lane][4 k]; rows past Cout zero.  One launch, any stream. */
+int usot_conv_pack_wfrag_f32(void *stream, const float *w, float *wf, int Cout, int K);
 int64_t usot_conv_ws_floats(const usot_conv_desc *d);          /* workspace need for ksplit */
 
 /* ---- bf16 variant for the batched backbone (BASELINE config 3): x / w / res / y are bf16

@@ -11,15 +11,19 @@ os.environ['USOT_HIP_LIB'] = os.path.abspath(sys.argv[1])
 import torch
 from usot_amd import hip
 L = hip.lib(); dev = 'cuda:0'
-N, H, W, Cin, Cout, k, pad, dil = 1, 31, 31, 256, 256, 3, 2, 2
-x = torch.randn(N, H, W, Cin, device=dev); w = torch.randn(Cout, k * k * Cin, device=dev) * 0.02
-b = torch.randn(Cout, device=dev); y = torch.empty(N, H, H, Cout, device=dev)
+# SHAPE=conv2 (default) | tower (3 groups of 625 x 256 x 2304) | conf (7 x 625 pixels, 512 channels)
+N, H, W, Cin, Cout, k, pad, dil, G = {'conv2': (1, 31, 31, 256, 256, 3, 2, 2, 1), 'tower': (1, 25, 25, 256, 256, 3, 1, 1, 3),
+                                      'conf': (7, 25, 25, 256, 512, 3, 1, 1, 1)}[os.environ.get('SHAPE', 'conv2')]
+x = torch.randn(G, N, H, W, Cin, device=dev); w = torch.randn(G * Cout, k * k * Cin, device=dev) * 0.02
+b = torch.randn(G * Cout, device=dev); y = torch.empty(G, N, H, H, Cout, device=dev)
 out = []
-ws = torch.zeros(16 * 961 * 256 + 4096, device=dev)
+ws = torch.zeros(16 * G * N * H * H * Cout + 65536, device=dev)
 for spec in sys.argv[2:] or ['54', '53', '55']:          # tile or tile:ksplit
     tile, ks = (int(v) for v in (spec.split(':') + ['1'])[:2])
     d = hip.conv_desc(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N=N, H=H, W=W, Cin=Cin, OH=H, OW=H, Cout=Cout,
-                      KH=k, KW=k, pad=(pad, pad), dil=(dil, dil), act=1, tile=tile, ksplit=ks, ws=ws.data_ptr())
+                      KH=k, KW=k, pad=(pad, pad), dil=(dil, dil), act=1, tile=tile, ksplit=ks, ws=ws.data_ptr(),
+                      groups=G, x_gs=N * H * W * Cin, w_gs=Cout * k * k * Cin, b_gs=Cout, y_gs=N * H * H * Cout,
+                      w_frag=hip.tile_wfrag(tile))       # timing only: random filters are as good in any order
     for _ in range(5):
         hip.check(L.usot_conv2d_f32(hip.stream(), C.byref(d)))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -47,6 +47,7 @@ struct ConvK {
     int combine;                        // split-K: 1 = last-arriver combine inside the launch, 0 = second launch
     int M, K, KT, cchunks, MT, NT, P;   // P = OH*OW
     int vec_store;
+    int pr;                             // weight-stationary tiles: pixel ranges per (group, 32-channel block)
 };
 
 // Up to four convolutions of DIFFERENT geometry in one launch (same tile shape): the shortcut
@@ -713,8 +714,15 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
 // (Fetching ALL fragments of k-tile t+1 in front of tile t's MFMAs - pinned with sched_barrier, hipcc otherwise
 // sinks the reads to the end of the step - shortens the consumer's MFMA phase 828 -> 712 cycles but the burst of
 // ds_read_b128 doubles the producers' ds_write time; k-step 1064 -> 1196.  Not kept.)
-template <int BM, int BN, int WM, int WN, int BK, int D = 1, int NPW = 4>
+// (USOT_V3_SWZ builds: second launch bound = waves per SIMD the register allocation must leave room for)
+// PF = rounds (16 k each) a consumer's fragment reads run ahead of their MFMAs: 1 = two fragment slots; 2 = one slot per round
+// of the k-tile (BK = 64), reads issued two rounds = 16 MFMAs ahead and pinned there (sched_barrier)
+template <int BM, int BN, int WM, int WN, int BK, int D = 1, int NPW = 4, int PF = 1>
+#ifdef USOT_V3_SWZ
+__global__ __launch_bounds__(256 + 64 * NPW, (BM * BN <= 32 * 64) ? (4 + NPW) / 2 : 1) void conv_igemm_f32_v3(const ConvBatch bt)
+#else
 __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBatch bt)
+#endif
 {
     int pi = 0;
 #pragma unroll
@@ -724,7 +732,18 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
     const int bid0 = (int)blockIdx.x - bt.start[pi];
     static_assert(WM * WN == 4, "4 consumer wavefronts");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int LD = BK + 4;
+    // LDS rows.  BK = 64: a row is 256 B = one bank row, UNPADDED, 16-byte chunk c of tile row `row` stored at chunk
+    // c ^ (row & 15).  ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md
+    // LDS table): with the former 4-float row pad, lane (l15, quad) hit 16-byte slot (l15 + quad) mod 16 and every group had
+    // two lanes on one slot (lanes 12 / 27, 4 / 19, ...): 8 LDS cycles per fragment read instead of 4.  With the XOR the
+    // slots of a group are (4 r) ^ quad ^ l15: {0-3,12-15} ^ 0 and {4-11} ^ 1 - disjoint in every group; the producers' 8-lane
+    // ds_write_b128 groups cover 8 consecutive chunks of one row, still 8 distinct slots.  BK = 32 keeps the padded rows.
+#ifdef USOT_V3_SWZ        // measured, round 5: conflict-free (SQ_LDS_BANK_CONFLICT 0) and SLOWER - frame graph 871 vs 849 us on the same box
+    constexpr bool SWZ = BK == 64;   // (one more v_xor per fragment read, 78 -> 80 VGPRs + a spill on the 32 x 64 tile); kept buildable
+#else
+    constexpr bool SWZ = false;
+#endif
+    constexpr int LD = SWZ ? BK : BK + 4;
     constexpr int CPR = BK / 4;
     constexpr int NPT = 64 * NPW;                 // producer threads
     constexpr int RPP = NPT / CPR;
@@ -806,7 +825,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
             }
 #pragma unroll
             for (int i = 0; i < WI; ++i) {
-#ifdef USOT_ABL_NOLOAD
+#if defined(USOT_ABL_NOLOAD) || defined(USOT_ABL_NOW) || defined(USOT_ABL_NOWLOAD)   // NOW: the W operand never travels; NOWLOAD / NOWSTORE / NOWREAD: one leg of it removed
                 wr[d][i] = f32x4{1.f, 1.f, 1.f, 1.f};
 #else
                 wr[d][i] = *(const f32x4 *)wp[i];
@@ -824,13 +843,23 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
 #ifdef USOT_ABL_NOSTORE
             return;
 #endif
+            // RPP is a multiple of 16 when BK = 64, so (row & 15) == (lr & 15) for every row of this thread
+            const int kcs = (SWZ ? (kc ^ (lr & 15)) : kc) * 4;
 #pragma unroll
             for (int i = 0; i < XI; ++i)
                 if (BM % RPP == 0 || lr + RPP * i < BM)
-                    *(f32x4 *)(sX + (lr + RPP * i) * LD + kc * 4) = xz[d][i] ? xr[d][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    *(f32x4 *)(sX + (lr + RPP * i) * LD + kcs) = xz[d][i] ? xr[d][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+#if !defined(USOT_ABL_NOW) && !defined(USOT_ABL_NOWSTORE)
 #pragma unroll
             for (int i = 0; i < WI; ++i)
-                if (BN % RPP == 0 || lr + RPP * i < BN) *(f32x4 *)(sW + (lr + RPP * i) * LD + kc * 4) = wr[d][i];
+                if (BN % RPP == 0 || lr + RPP * i < BN) *(f32x4 *)(sW + (lr + RPP * i) * LD + kcs) = wr[d][i];
+#elif defined(USOT_ABL_NOWSTORE)
+#pragma unroll
+            for (int i = 0; i < WI; ++i) {
+                const f32x4 keep = wr[d][i];
+                asm volatile("" :: "v"(keep));     // the loads stay, waited for here
+            }
+#endif
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, D >= 2 ? 1 : 0>;
@@ -889,16 +918,25 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int l15 = lane & 15, quad = lane >> 4;
-    const int fx_off = (wm * TM * 16 + l15) * LD + quad * 4;
-    const int fw_off = BM * LD + (wn * TN * 16 + l15) * LD + quad * 4;
-    f32x4 fw[2][TN], fx[2][TM];
+    const int fx_off = (wm * TM * 16 + l15) * LD + (SWZ ? 0 : quad * 4);
+    const int fw_off = BM * LD + (wn * TN * 16 + l15) * LD + (SWZ ? 0 : quad * 4);
+    // swizzled rows: chunk (4 r + quad) of row (16 b + l15) lives at chunk (4 r) ^ (quad ^ l15)
+    const int swz = SWZ ? (quad ^ l15) * 4 : 0;     // one v_xor per round instead of four live offsets (80-VGPR budget: 2 workgroups / CU)
+    constexpr int NSLOT = PF == 2 ? NR : 2;
+    static_assert(PF == 1 || (PF == 2 && NR == 4), "PF = 2 needs BK = 64");
+    f32x4 fw[NSLOT][TN], fx[NSLOT][TM];
     auto read_frags = [&](int st, int r, int slot) {
 #ifdef USOT_ABL_NOREAD
         return;
 #endif
-        const float *base = smem + st * STAGE + r * 16;
+        const float *base = smem + st * STAGE + ((r * 16) ^ swz);
+#if defined(USOT_ABL_NOW) || defined(USOT_ABL_NOWREAD)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fw[slot][i] = f32x4{1.f + st, 2.f, 3.f + r, 4.f};
+#else
 #pragma unroll
         for (int i = 0; i < TN; ++i) fw[slot][i] = *(const f32x4 *)(base + fw_off + i * 16 * LD);
+#endif
 #pragma unroll
         for (int j = 0; j < TM; ++j) fx[slot][j] = *(const f32x4 *)(base + fx_off + j * 16 * LD);
     };
@@ -954,6 +992,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
     unsigned *trc = (p.ksplit == 1 && p.ws && bid0 == 0 && tid == 0) ? (unsigned *)p.ws : nullptr;
 #endif
     if (nt > 0) read_frags(0, 0, 0);
+    if (PF == 2 && nt > 0) read_frags(0, 1, 1);
     int st = 0;
     for (int t = 0; t < nt; ++t) {
         const int st1 = st == 2 ? 0 : st + 1;
@@ -961,9 +1000,17 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
         flush();                                      // the previous k-tile's block (zeros at t = 0)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
-            else if (t + 1 < nt) read_frags(st1, 0, 0);
-            mma(r & 1, r == 0);
+            if constexpr (PF == 2) {
+                // tile t + 1 is complete in its stage since the barrier that ended step t - 1 (the producers run two tiles ahead)
+                if (r + 2 < NR) read_frags(st, r + 2, r + 2);
+                else if (t + 1 < nt) read_frags(st1, r + 2 - NR, r + 2 - NR);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(r, r == 0);
+            } else {
+                if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
+                else if (t + 1 < nt) read_frags(st1, 0, 0);
+                mma(r & 1, r == 0);
+            }
         }
         st = st1;
         USOT_STAMP(1, t);
@@ -1036,14 +1083,666 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
     }
 }
 
-struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int threads; int depth; };
+// ---------------------------------------------------------------------------------------
+// ws ("weight-streaming"): v3's producer / consumer split with the FILTER operand taken out of LDS.
+//
+// Measured on v3 (scripts/ablate_kstep.py, -DUSOT_ABL_NOW: the W operand neither loaded, staged nor read; 32 x 64 tile):
+// Conf_Fusion's conv 112.8 -> 66.8 us (= the MFMA time of its 10.3 GFLOP at 2.4 GHz), one tower level 28.4 -> 18.3,
+// layer3's 3x3 27.7 -> 18.0 — two thirds of a k-step's LDS traffic (16 of 24 KB written, 32 of 48 KB read) and two thirds
+// of the producers' instructions are the filter tile, and that traffic, not the matrix pipe, is what a CU runs out of
+// (two workgroups per CU are only 1.12 x faster than one).  Filters are constants: the host stores them in MFMA FRAGMENT
+// order (usot_conv_pack_wfrag: [channel block of 16][k-tile of 64][round of 16 k][lane][4 floats], a permutation
+// inside every 16-row block, so row offsets that are multiples of 16 and group strides keep their values) and each
+// consumer wave fetches the A fragments of ITS 16 channels straight from global memory into registers, DW k-tiles
+// ahead: one fully coalesced 1-KiB global_load_dwordx4 per round, no LDS, no second reader — the four consumer waves
+// split the CHANNELS of the tile (wave w: channels 16 w TN ... ), every wave multiplies all BM pixels.  The activation
+// tile keeps v3's path (producer waves, global -> registers -> LDS, three stages, one barrier per k-tile); a consumer
+// reads TM = BM / 16 B fragments per round for TM x TN MFMA blocks.  All W loads are unconditional and the k-loop is
+// unrolled over the DW register buffers, so the compiler counts vmcnt exactly (nothing else of a consumer's loop is
+// a vector-memory instruction).
+template <int BM, int BN, int D, int NPW, int DW, int WM = 1>
+__global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_ws(const ConvBatch bt)
+{
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < bt.n && (int)blockIdx.x >= bt.start[q]) pi = q;
+    const ConvK &p = bt.p[pi];
+    const int bid0 = (int)blockIdx.x - bt.start[pi];
+    constexpr int BK = 64;
+    constexpr int WN = 4 / WM;                    // consumer waves: WM along the pixels x WN along the channels
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    static_assert(TM >= 1 && TN >= 1 && BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "four consumer waves split the tile");
+    constexpr int LD = BK;                        // unpadded rows, chunks XOR-swizzled by the row (see v3)
+    constexpr int CPR = BK / 4;
+    constexpr int NPT = 64 * NPW;
+    constexpr int RPP = NPT / CPR;
+    constexpr int XI = (BM + RPP - 1) / RPP;
+    constexpr int NR = BK / 16;
+    constexpr int STAGE = BM * LD;
+    static_assert(RPP % 16 == 0, "a producer thread's rows share row & 15");
 
-#define TILE(bm, bn, wm, wn) { bm, bn, 32, 2, 1, conv_igemm_f32<bm, bn, wm, wn>, 256, 1 }
-#define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v2<bm, bn, wm, wn, bk>, 256, 1 }
-#define TILE3(bm, bn, wm, wn, bk, ksw) { bm, bn, bk, 3, ksw, conv_igemm_f32_v2<bm, bn, wm, wn, bk, ksw>, 256 * ksw, 1 }
-#define TILE4(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk>, 512, 1 }
-#define TILE10(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw>, 256 + 64 * npw, d }
-#define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d }
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const bool producer = threadIdx.x >= 256;
+    const int tid = producer ? (int)threadIdx.x - 256 : (int)threadIdx.x;
+    const int tiles = p.MT * p.NT;
+    const int total = tiles * p.groups * p.ksplit;
+    const int b = xcd_remap(bid0, total);
+    const int z = b / tiles, t0 = b - z * tiles;
+    const int g = z / p.ksplit, ks = z - g * p.ksplit;
+    const int bn0 = (t0 / p.MT) * BN, bm0 = (t0 % p.MT) * BM;
+    const int KT = p.K / BK;
+    const int cch = p.Cin / BK;
+    const int kt0 = (int)((long)KT * ks / p.ksplit);
+    const int kt1 = (int)((long)KT * (ks + 1) / p.ksplit);
+    const int nt = kt1 - kt0;
+
+    auto each_of = [&]<int... Is>(std::integer_sequence<int, Is...>, auto f) { (f(std::integral_constant<int, Is>{}), ...); };
+
+    if (producer) {
+        const float *__restrict__ xg = p.x + (long)g * p.x_gs;
+        const int lr = tid / CPR, kc = tid % CPR;
+        int x_ih0[XI], x_iw0[XI];
+        long x_nb[XI];
+        bool x_ok[XI];
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int row = lr + RPP * i;
+            const int m = bm0 + row;
+            x_ok[i] = (row < BM) && (m < p.M);
+            const int mm = x_ok[i] ? m : 0;
+            const int n = mm / p.P, pix = mm - n * p.P;
+            const int oh = pix / p.OW, ow = pix - oh * p.OW;
+            x_ih0[i] = oh * p.stride - p.pad_h;
+            x_iw0[i] = ow * p.stride - p.pad_w;
+            x_nb[i] = (long)n * p.H * p.W * p.Cin + kc * 4;
+        }
+        f32x4 xr[D][XI];
+        bool xz[D][XI];
+        const float *xp[XI];
+        bool xin[XI];
+        int cur_tap = kt0 / cch, cur_cc = kt0 - cur_tap * cch;
+        auto set_tap = [&](int tap) {
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const int dh = kh * p.dil_h, dw = kw * p.dil_w;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int ih = x_ih0[i] + dh, iw = x_iw0[i] + dw;
+                xin[i] = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                xp[i] = xg + x_nb[i] + ((long)ih * p.W + iw) * p.Cin;
+            }
+        };
+        set_tap(cur_tap);
+        auto load_tile = [&](auto dc, bool advance) {
+            constexpr int d = decltype(dc)::value;
+            const int c0 = cur_cc * BK;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {      // unconditional (see v3): padding taps read pixel 0 and are zeroed at the LDS store
+                xr[d][i] = *(const f32x4 *)(xin[i] ? xp[i] + c0 : xg + kc * 4);
+                xz[d][i] = xin[i];
+            }
+            if (advance && ++cur_cc == cch) {
+                cur_cc = 0;
+                set_tap(++cur_tap);
+            }
+        };
+        auto store_tile = [&](auto dc, int st) {
+            constexpr int d = decltype(dc)::value;
+            float *sX = smem + st * STAGE;
+            const int kcs = (kc ^ (lr & 15)) * 4;
+#pragma unroll
+            for (int i = 0; i < XI; ++i)
+                if (BM % RPP == 0 || lr + RPP * i < BM)
+                    *(f32x4 *)(sX + (lr + RPP * i) * LD + kcs) = xz[d][i] ? xr[d][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, D >= 2 ? 1 : 0>;
+        int lt = 0;
+        auto load_next = [&](auto dc) { load_tile(dc, lt + 1 < nt); ++lt; };
+        if constexpr (D == 1) {
+            load_next(I0{}); store_tile(I0{}, 0);
+            load_next(I0{}); if (nt > 1) store_tile(I0{}, 1);
+        } else {
+            load_next(I0{});
+            load_next(I1{});
+            store_tile(I0{}, 0);
+            if (nt > 1) store_tile(I1{}, 1);
+        }
+        each_of(std::make_integer_sequence<int, D>{}, [&](auto dc) { load_next(dc); });
+        __syncthreads();
+        int st2 = 2;
+        auto step = [&](auto dc, int t) {
+            if (t + 2 < nt) store_tile(dc, st2);
+            load_next(dc);
+            st2 = st2 == 2 ? 0 : st2 + 1;
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + D <= nt; t += D) each_of(std::make_integer_sequence<int, D>{}, [&](auto dc) { step(dc, t + decltype(dc)::value); });
+        each_of(std::make_integer_sequence<int, D>{}, [&](auto dc) {
+            if (t < nt) { step(dc, t); ++t; }
+        });
+        return;
+    }
+
+    // ---------------- consumers: wave w owns channels bn0 + 16 TN w ... of all BM pixels
+    const int lane = tid & 63, wave = (tid >> 6) / WM, wm = (tid >> 6) % WM;
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int fx_off = (wm * TM * 16 + l15) * LD;
+    const int swz = (quad ^ l15) * 4;
+    // fragment-order filter stream of this wave's channel blocks (blocks past the padded bank read block 0: never stored)
+    const int ncb = (p.Cout + 15) >> 4;
+    const float *wq[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int cb = (bn0 >> 4) + wave * TN + i;
+        wq[i] = p.w + (long)g * p.w_gs + ((long)(cb < ncb ? cb : 0) * KT + kt0) * (BK * 16) + lane * 4;
+    }
+    f32x4 wb[DW][TN][NR];
+    f32x4 fx[2][TM];
+    auto read_x = [&](int st, int r, int slot) {
+        const float *base = smem + st * STAGE + ((r * 16) ^ swz) + fx_off;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fx[slot][j] = *(const f32x4 *)(base + j * 16 * LD);
+    };
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+    BlockTotal tot[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) tot[i][j].clear();
+    auto flush = [&]() {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) tot[i][j].add(acc[i][j]);
+        if constexpr (TM * TN == 1) tot[0][0].add(acc2);
+    };
+    // bias and residual first (v3: fetched while the first k-tiles travel), THEN the filter stream: vector loads return in
+    // order, so the wait for the first filter fragments covers them
+    const bool pre = p.vec_store && p.ksplit == 1;
+    f32x4 pb[TN], pr[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int co = bn0 + (wave * TN + i) * 16 + quad * 4;
+        const bool cok = pre && co + 3 < p.Cout;
+        pb[i] = (cok && p.bias) ? *(const f32x4 *)(p.bias + (long)g * p.b_gs + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = bm0 + (wm * TM + j) * 16 + l15;
+            pr[i][j] = (cok && p.res && m < p.M)
+                           ? *(const f32x4 *)(p.res + (long)g * p.r_gs + (long)m * p.res_cstride + p.res_coff + co)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#ifdef USOT_WS_NOWAIT
+    f32x4 sink[DW][TN][NR];
+#endif
+    int lt = 0;
+    auto wnext = [&](auto dc) {                      // fetch the next k-tile of the stream into buffer dc (past the end: the last tile again)
+        constexpr int d = decltype(dc)::value;
+        const bool advance = lt + 1 < nt;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+#if defined(USOT_WS_NOWLOAD)          // timing builds (scripts/ablate_kstep.py): the filter stream never issued ...
+                wb[d][i][r] = f32x4{1.f + r, 2.f, 3.f, 4.f + d};
+#elif defined(USOT_WS_NOWAIT)         // ... or issued but never waited for inside the loop (MFMAs on constants)
+                sink[d][i][r] = *(const f32x4 *)(wq[i] + r * 256);
+                wb[d][i][r] = f32x4{1.f + r, 2.f, 3.f, 4.f + d};
+#else
+                wb[d][i][r] = *(const f32x4 *)(wq[i] + r * 256);
+#endif
+            }
+            wq[i] += advance ? BK * 16 : 0;
+        }
+        ++lt;
+    };
+    each_of(std::make_integer_sequence<int, DW>{}, [&](auto dc) { wnext(dc); });
+    __syncthreads();
+    if (nt > 0) read_x(0, 0, 0);
+    int st = 0;
+    auto step = [&](auto dc, int t) {
+        constexpr int d = decltype(dc)::value;
+        const int st1 = st == 2 ? 0 : st + 1;
+        flush();
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r + 1 < NR) read_x(st, r + 1, (r + 1) & 1);
+            else if (t + 1 < nt) read_x(st1, 0, 0);
+#ifndef USOT_WS_NOPIN
+            // the NEXT round's B fragments leave LDS while this round's MFMAs issue; unpinned, hipcc sinks the reads below the
+            // MFMAs, right in front of their first use, and every round then waits a full LDS latency (k-step 1 620 vs 1 040 cycles)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            f32x4 wfr[TN];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) wfr[i] = wb[d][i][r];
+            blocked_mma<TN, TM>(acc, acc2, wfr, fx[r & 1], r == 0);
+        }
+        wnext(dc);
+        st = st1;
+        __syncthreads();
+    };
+    {
+        int t = 0;
+        for (; t + DW <= nt; t += DW) each_of(std::make_integer_sequence<int, DW>{}, [&](auto dc) { step(dc, t + decltype(dc)::value); });
+        each_of(std::make_integer_sequence<int, DW>{}, [&](auto dc) {
+            if (t < nt) { step(dc, t); ++t; }
+        });
+    }
+    flush();
+#ifdef USOT_WS_NOWAIT
+#pragma unroll
+    for (int d = 0; d < DW; ++d)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) asm volatile("" :: "v"(sink[d][i][r]));
+#endif
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = tot[i][j].get();
+
+    if (p.ksplit > 1) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = bm0 + (wm * TM + j) * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int co = bn0 + (wave * TN + i) * 16 + quad * 4;
+                const long el = ((long)(ks * p.groups + g) * p.M + m) * p.Cout + co;
+                if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
+                    ws_store4(p, el, acc[i][j]);
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Cout) ws_store1(p, el + e, acc[i][j][e]);
+                }
+            }
+        }
+        if (p.combine) splitk_combine<BM, BN>(p, g, t0, tiles, bm0, bn0, tid, (int *)smem);
+        return;
+    }
+    const float *__restrict__ bg = p.bias ? p.bias + (long)g * p.b_gs : nullptr;
+    const float *__restrict__ rg = p.res ? p.res + (long)g * p.r_gs : nullptr;
+    float *__restrict__ yg = p.y + (long)g * p.y_gs;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = bm0 + (wm * TM + j) * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int co = bn0 + (wave * TN + i) * 16 + quad * 4;
+            if (co >= p.Cout) continue;
+            f32x4 v = acc[i][j];
+            if (p.vec_store && co + 3 < p.Cout) {
+                v += pb[i] + pr[i][j];
+                const int a = co < p.act_split ? p.act : p.act2;
+                if (a != USOT_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a);
+                }
+                *(f32x4 *)(yg + (long)m * p.y_cstride + p.y_coff + co) = v;
+            } else {
+                const int n = m / p.P, pix = m - n * p.P;
+                for (int e = 0; e < 4; ++e) {
+                    const int c = co + e;
+                    if (c >= p.Cout) break;
+                    float s2 = v[e];
+                    if (bg) s2 += bg[c];
+                    if (rg) s2 += rg[(long)m * p.res_cstride + p.res_coff + c];
+                    s2 = apply_act(s2, c < p.act_split ? p.act : p.act2);
+                    if (p.y_nchw) yg[((long)n * p.Cout + c) * p.P + pix] = s2;
+                    else          yg[(long)m * p.y_cstride + p.y_coff + c] = s2;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// wstat ("weight-stationary"): the big-K convolutions of the batch-1 frame with the FILTERS IN REGISTERS.
+//
+// What a v3 k-step waits for (round 5; scripts/ablate_kstep.py on Conf_Fusion's conv, 32 x 64 tile, two workgroups per CU):
+// whole kernel 115 us; without the filter tile's global loads 111, without its LDS stores 109, WITHOUT THE CONSUMERS' TWO
+// FILTER-FRAGMENT ds_read_b128 PER ROUND 77, with no filter traffic at all 67 (= the MFMA time of 10.3 GFLOP at 2.4 GHz).
+// Neither deeper fragment prefetch (PF = 2) nor conflict-free rows (USOT_V3_SWZ) nor filters fetched straight from global
+// memory (ws tiles) recover it: a consumer wave runs at the matrix pipe's rate only with ONE operand fragment read per
+// 8 MFMAs.  Filters are constants, so they can stay where the MFMA reads them:
+//   * a workgroup = 8 wavefronts (two per SIMD, all of them loaders AND consumers, 512 threads, one workgroup per CU) owns
+//     32 output channels for a RANGE of 32-pixel tiles; wave j keeps the A fragments of those 32 channels for the k-rounds
+//     j, j + 8, j + 16, ... (a round = 16 k) - K / 128 rounds x 2 channel blocks x 4 registers = 144 VGPRs at K = 2304 -
+//     fetched ONCE per workgroup from the fragment-order bank (usot_conv_pack_wfrag_f32), every wave-load 1 KiB contiguous;
+//   * the activation operand streams through LDS in panels of 32 pixels x 128 k (one round per wave and panel; 16 KB, three
+//     stages, global -> registers -> LDS by all 512 threads two panels ahead, one barrier per panel): per panel a wave reads
+//     TWO B fragments and issues 16 MFMAs (2 pixel blocks x 2 channel blocks x 4) - one read per 8 MFMAs;
+//   * k is split over the eight waves INSIDE the workgroup: at the end of a pixel tile the eight partial 32 x 32 tiles meet
+//     in LDS (32 KB; written before the panel's barrier, summed in wave order 0..7 by waves 0-3 - one 16 x 16 block each -
+//     which add bias / residual / activation and store 16 bytes per lane) while the panel stream of the next tile is
+//     already in flight.  Accumulation: a wave's chain is K / 8 products (288 at K = 2304, flushed into a running total
+//     every four panels = 64 products like every other kernel of this file), then 8 partials in fixed order.
+// Per CU and panel: 16 KB from L2 for 2 x 1 024 MFMA cycles per SIMD (v3: 48 KB), filters never re-read.  Needs
+// Cin % 128 == 0 (a panel lies inside one filter tap), K == NST * 128 * RPS, Cout % 32 == 0.
+template <int NST, int RPS, bool BLOCKED = false>
+__global__ __launch_bounds__(512) void conv_wstat_f32(const ConvBatch bt)
+{
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < bt.n && (int)blockIdx.x >= bt.start[q]) pi = q;
+    const ConvK &p = bt.p[pi];
+    const int bid0 = (int)blockIdx.x - bt.start[pi];
+    constexpr int BM = 32;
+    constexpr int PK = 128 * RPS;                 // k per panel
+    constexpr int LDP = PK + 4;
+    constexpr int CPR = PK / 4;                   // 16-byte chunks per panel row
+    constexpr int RPP = 512 / CPR;                // rows per pass of the 512 loader threads
+    constexpr int XI = BM / RPP;
+    constexpr int STAGE = BM * LDP;
+    constexpr int NSTG = 4;                       // LDS stages: panel q + 1 is complete while panel q is multiplied
+    static_assert(BM % RPP == 0, "loader passes");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *red = smem + NSTG * STAGE;             // [8 waves][4 blocks][64 lanes] f32x4
+
+    // the problem's fields in registers (p is a dynamically indexed reference into the kernel arguments: every use would be an s_load)
+    const int pM = p.M, pP = p.P, pOW = p.OW, pH = p.H, pW = p.W, pCin = p.Cin, pKW = p.KW;
+    const int pstride = p.stride, ppad_h = p.pad_h, ppad_w = p.pad_w, pdil_h = p.dil_h, pdil_w = p.dil_w;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int units = p.groups * p.NT * p.pr;
+    const int u = xcd_remap(bid0, units);
+    const int pr = u % p.pr, gc = u / p.pr;
+    const int cg = gc % p.NT, g = gc / p.NT;
+    const int tile0 = (int)((long)p.MT * pr / p.pr), tile1 = (int)((long)p.MT * (pr + 1) / p.pr);
+    const int ntile = tile1 - tile0;
+    if (ntile <= 0) return;
+    const int npan = ntile * NST;
+    const int KT = p.K / 64;
+
+    // ---- loader state (runs three panels ahead of the MFMAs); 32-bit element offsets (the launcher checks the map's size)
+    const float *__restrict__ xg = p.x + (long)g * p.x_gs;
+    const int lr = tid / CPR, kc = tid % CPR;
+    int x_ih0[XI], x_iw0[XI], x_nb[XI];
+    unsigned xo[XI];                              // BYTE offset of the row's source at the current tap; 0xffffffff: padding / past M
+    // Loads go through a buffer descriptor over this group's input map: an offset past its end returns ZEROS, so padding taps and
+    // the pixels past M need no select on the loaded data and no second pointer; the channel offset of the panel rides in the
+    // instruction's scalar offset - a panel's two loads per thread cost no vector ALU instruction at all
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)xg, 0, (int)((long)p.N * pH * pW * pCin * 4), 0x00020000);
+    int l_tile = tile0, l_s = 0, l_tap = 0, l_cc = 0;
+    auto set_tile = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int m = tile * BM + lr + RPP * i;
+            const bool ok = m < pM;
+            const int mm = ok ? m : 0;
+            const int n = mm / pP, pix = mm - n * pP;
+            const int oh = pix / pOW, ow = pix - oh * pOW;
+            x_ih0[i] = ok ? oh * pstride - ppad_h : -(1 << 20);      // far outside: every tap fails the bounds test
+            x_iw0[i] = ow * pstride - ppad_w;
+            x_nb[i] = n * pH * pW * pCin + kc * 4;
+        }
+    };
+    auto set_tap = [&](int tap) {
+        const int kh = tap / pKW, kw = tap - kh * pKW;
+        const int dh = kh * pdil_h, dw = kw * pdil_w;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int ih = x_ih0[i] + dh, iw = x_iw0[i] + dw;
+            const bool in = (unsigned)ih < (unsigned)pH && (unsigned)iw < (unsigned)pW;
+            xo[i] = in ? (unsigned)(x_nb[i] + (ih * pW + iw) * pCin) * 4u : 0xffffffffu;
+        }
+    };
+    set_tile(l_tile);
+    set_tap(0);
+    f32x4 xr[2][XI];
+    int l_left = npan;                                       // panels not yet fetched
+    auto load_issue = [&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+#if defined(USOT_WSTAT_LOADSAME)     // timing: every panel fetches the SAME lines (L1 hits: the issue side of the loads alone)
+            xr[d][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(kc * 16 + i * 4096 + lr * 512), 0, 0));
+#elif defined(USOT_WSTAT_LOADHALF)   // timing: half the bytes (both loads of a thread fetch its first row)
+            xr[d][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)xo[0], l_cc * 4, 0));
+#else
+            xr[d][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)xo[i], l_cc * 4, 0));
+#endif
+    };
+    auto load_advance = [&]() {
+        // wave-uniform counters: kept in scalar registers (readfirstlane: hipcc otherwise carries them in VGPRs under exec masks)
+        l_left = __builtin_amdgcn_readfirstlane(l_left - 1);
+        if (l_left > 0) {                   // past the last panel the state stops advancing (the panel is fetched again, never stored)
+            l_cc = __builtin_amdgcn_readfirstlane(l_cc + PK);
+            l_s = __builtin_amdgcn_readfirstlane(l_s + 1);
+            if (l_s == NST) {
+                l_s = 0; l_cc = 0; l_tap = 0;
+                l_tile = __builtin_amdgcn_readfirstlane(l_tile + 1);
+                set_tile(l_tile);
+                set_tap(0);
+            } else if (l_cc == pCin) {
+                l_cc = 0;
+                l_tap = __builtin_amdgcn_readfirstlane(l_tap + 1);
+                set_tap(l_tap);
+            }
+        }
+    };
+    auto load_next = [&](auto dc) { load_issue(dc); load_advance(); };
+    auto store_panel = [&](auto dc, int st) {
+        constexpr int d = decltype(dc)::value;
+        float *sX = smem + st * STAGE;
+#ifdef USOT_WSTAT_NOWAIT        // timing: the fetched panel is never waited for (the stores write other registers)
+#pragma unroll
+        for (int i = 0; i < XI; ++i) *(f32x4 *)(sX + (lr + RPP * i) * LDP + kc * 4) = f32x4{1.f * lr, 2.f, 3.f * d, 4.f};
+#else
+#pragma unroll
+        for (int i = 0; i < XI; ++i) *(f32x4 *)(sX + (lr + RPP * i) * LDP + kc * 4) = xr[d][i];
+#endif
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // panels 0 and 1 go to LDS before the first barrier, panel 2 waits in register buffer 0, panel 3 in buffer 1
+    load_next(I0{});
+    load_next(I1{});
+
+    // ---- this wave's filter fragments: rounds (s * 8 + wave) * RPS + rr of the 32 channels [cg * 32, cg * 32 + 32)
+    f32x4 wb[NST][RPS][2];
+    {
+        const float *wbase = p.w + (long)g * p.w_gs + lane * 4;
+#pragma unroll
+        for (int s = 0; s < NST; ++s)
+#pragma unroll
+            for (int rr = 0; rr < RPS; ++rr) {
+                const int R = (s * 8 + wave) * RPS + rr;
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    wb[s][rr][tn] = *(const f32x4 *)(wbase + (((long)(cg * 2 + tn) * KT + (R >> 2)) * 4 + (R & 3)) * 256);
+            }
+    }
+    store_panel(I0{}, 0);
+    load_next(I0{});
+    if (npan > 1) store_panel(I1{}, 1);
+    load_next(I1{});
+    __syncthreads();
+
+    f32x4 acc[2][2];
+    BlockTotal tot[BLOCKED ? 2 : 1][BLOCKED ? 2 : 1];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            acc[tn][tm] = zero;
+            if constexpr (BLOCKED) tot[tn][tm].clear();
+        }
+    constexpr int FLUSH = RPS == 1 ? 4 : 2;       // BLOCKED: panels per 64-product block of a wave's chain
+    const int fx_off = l15 * LDP + wave * RPS * 16 + quad * 4;
+    // gap (0..3 = after MFMA group 0..2, 3 = before group 0) in which this wave stores / fetches: the store of buffer d must
+    // precede the fetch into buffer d within a panel, so st_gap comes first in the order 3, 0, 1, 2
+    const int wsl = __builtin_amdgcn_readfirstlane(wave & 3);
+    const int st_gap = (wsl == 0 || wsl == 3) ? 3 : wsl - 1;  // program order of the gaps: 3, 0, 1, 2
+    const int ld_gap = wsl == 3 ? 2 : wsl;
+    f32x4 fx[2][RPS][2];                          // [slot][round][pixel block]: slot q & 1 holds panel q's B fragments
+    auto read_x = [&](auto sl, int st) {
+        constexpr int slot = decltype(sl)::value;
+        const float *sX = smem + st * STAGE + fx_off;
+#pragma unroll
+        for (int rr = 0; rr < RPS; ++rr)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) fx[slot][rr][tm] = *(const f32x4 *)(sX + tm * 16 * LDP + rr * 16);
+    };
+    read_x(I0{}, 0);
+
+    int q = 0, st = 0;                            // panel index, its LDS stage
+    auto panel = [&](auto sc, auto dc, int tile) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int d = decltype(dc)::value;    // q & 1: fragment slot of panel q, register buffer of panel q + 2 (stored now) and q + 4 (fetched now)
+        const int st1 = (st + 1) & 3, st2 = (st + 2) & 3;
+        // panel q + 1 has been complete in its stage since the previous barrier: its fragments travel while this panel is multiplied
+#ifndef USOT_WSTAT_NOREAD
+        if (q + 1 < npan) read_x(std::integral_constant<int, 1 - d>{}, st1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BLOCKED && s % FLUSH == 0 && s > 0) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) tot[tn][tm].add(acc[tn][tm]);
+        }
+        // A wave issues in order and an MFMA waits for the pipe (32 cycles each, 64 with the SIMD's other wave): everything else
+        // of the panel - the LDS store of panel q + 2, the fetch of panel q + 4, the loader's index arithmetic - is placed BETWEEN
+        // the four k-slot groups of the panel's MFMAs (pinned: hipcc otherwise issues the 16 MFMAs first and the rest behind them,
+        // where both waves of a SIMD sit in the same phase and the matrix pipe idles: 1 920 vs 1 024 cycles per panel)
+        auto mma4 = [&](auto cc, int rr) {
+            constexpr int c = decltype(cc)::value;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[s][rr][tn][c], fx[d][rr][tm][c],
+                                                                       (((BLOCKED && s % FLUSH == 0) || s == 0) && rr == 0 && c == 0) ? zero : acc[tn][tm], 0, 0, 0);
+        };
+        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+        using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+        // ... and STAGGERED over the waves: all eight run the same panel between the same two barriers, and eight fetches (or eight
+        // LDS stores) issued at the same point queue up in one unit while every wave's MFMA stream waits behind its own
+        // instruction; wave w fetches in gap (w & 3) and stores in gap ((w + 2) & 3) of the panel's four MFMA groups
+        auto gap = [&](int g4) {
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef USOT_WSTAT_NOSTORE
+            // panel q + 2 (fetched two panels ago) -> its stage (held panel q - 2, whose last reader passed two barriers ago)
+            if (g4 == st_gap && q + 2 < npan) store_panel(dc, st2);
+#endif
+#ifndef USOT_WSTAT_NOLOAD
+            if (g4 == ld_gap) load_issue(dc);                 // panel q + 4 (after the store of the same buffer: gaps are cyclic)
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        static_assert(RPS == 1, "the gap schedule below is written for one round per panel");
+        gap(3);                                               // cyclic order of a buffer's uses: store (gap st) ... fetch (gap ld) ...
+        mma4(C0{}, 0);
+        gap(0);
+        mma4(C1{}, 0);
+        gap(1);
+        mma4(C2{}, 0);
+        gap(2);
+        load_advance();
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(C3{}, 0);
+        if constexpr (s == NST - 1) {             // the tile's partial sums meet in LDS (read after this panel's barrier)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    f32x4 v = acc[tn][tm];
+                    if constexpr (BLOCKED) { tot[tn][tm].add(v); v = tot[tn][tm].get(); tot[tn][tm].clear(); }
+                    *(f32x4 *)(red + ((wave * 4 + tn * 2 + tm) * 64 + lane) * 4) = v;
+                }
+        }
+        st = st1;
+        ++q;
+#ifndef USOT_WSTAT_NOBAR       // timing builds (results are garbage): no per-panel barrier / no panel stores / no panel loads / no fragment reads
+        __syncthreads();
+#endif
+        if constexpr (s == NST - 1) {
+            if (wave < 4) {                       // wave w: block (tn, tm) = (w >> 1, w & 1), the eight partials in wave order
+                const int tn = wave >> 1, tm = wave & 1;
+                f32x4 v = zero;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v += *(const f32x4 *)(red + ((j * 4 + wave) * 64 + lane) * 4);
+                const int m = tile * BM + tm * 16 + l15;
+                const int co = cg * 32 + tn * 16 + quad * 4;
+                if (m < p.M) {
+                    const float *__restrict__ bg = p.bias ? p.bias + (long)g * p.b_gs : nullptr;
+                    const float *__restrict__ rg = p.res ? p.res + (long)g * p.r_gs : nullptr;
+                    float *__restrict__ yg = p.y + (long)g * p.y_gs;
+                    if (p.vec_store) {
+                        if (bg) v += *(const f32x4 *)(bg + co);
+                        if (rg) v += *(const f32x4 *)(rg + (long)m * p.res_cstride + p.res_coff + co);
+                        const int a = co < p.act_split ? p.act : p.act2;
+                        if (a != USOT_ACT_NONE) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a);
+                        }
+                        *(f32x4 *)(yg + (long)m * p.y_cstride + p.y_coff + co) = v;
+                    } else {
+                        const int n = m / p.P, pix = m - n * p.P;
+                        for (int e = 0; e < 4; ++e) {
+                            const int c = co + e;
+                            float s2 = v[e];
+                            if (bg) s2 += bg[c];
+                            if (rg) s2 += rg[(long)m * p.res_cstride + p.res_coff + c];
+                            s2 = apply_act(s2, c < p.act_split ? p.act : p.act2);
+                            if (p.y_nchw) yg[((long)n * p.Cout + c) * p.P + pix] = s2;
+                            else          yg[(long)m * p.y_cstride + p.y_coff + c] = s2;
+                        }
+                    }
+                }
+            }
+        }
+    };
+#ifdef USOT_WSTAT_NOWAIT
+#define USOT_WSTAT_SINK() do { _Pragma("unroll") for (int i = 0; i < XI; ++i) { asm volatile("" :: "v"(xr[0][i])); asm volatile("" :: "v"(xr[1][i])); } } while (0)
+#else
+#define USOT_WSTAT_SINK()
+#endif
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const bool flip = (NST & 1) && ((tile - tile0) & 1);       // odd panel counts: the buffer parity flips from tile to tile
+        if (!flip) {
+            [&]<int... Is>(std::integer_sequence<int, Is...>) {
+                (panel(std::integral_constant<int, Is>{}, std::integral_constant<int, Is & 1>{}, tile), ...);
+            }(std::make_integer_sequence<int, NST>{});
+        } else {
+            [&]<int... Is>(std::integer_sequence<int, Is...>) {
+                (panel(std::integral_constant<int, Is>{}, std::integral_constant<int, (Is + 1) & 1>{}, tile), ...);
+            }(std::make_integer_sequence<int, NST>{});
+        }
+    }
+    USOT_WSTAT_SINK();
+}
+
+struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int threads; int depth; int wfrag; int dw; int nst = 0; int rps = 0; };
+
+#define TILE(bm, bn, wm, wn) { bm, bn, 32, 2, 1, conv_igemm_f32<bm, bn, wm, wn>, 256, 1, 0, 0 }
+#define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v2<bm, bn, wm, wn, bk>, 256, 1, 0, 0 }
+#define TILE3(bm, bn, wm, wn, bk, ksw) { bm, bn, bk, 3, ksw, conv_igemm_f32_v2<bm, bn, wm, wn, bk, ksw>, 256 * ksw, 1, 0, 0 }
+#define TILE4(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk>, 512, 1, 0, 0 }
+#define TILE10(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw>, 256 + 64 * npw, d, 0, 0 }
+#define TILEW(bm, bn, d, npw, dw) { bm, bn, 64, 3, 1, conv_igemm_f32_ws<bm, bn, d, npw, dw>, 256 + 64 * npw, d, 1, dw }
+#define TILEW2(bm, bn, d, npw, dw) { bm, bn, 64, 3, 1, conv_igemm_f32_ws<bm, bn, d, npw, dw, 2>, 256 + 64 * npw, d, 1, dw }
+#define TILE11(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw, 2>, 256 + 64 * npw, d, 0, 2 }
+#define TILESB(nst, rps) { 32, 32, 64, 3, 1, conv_wstat_f32<nst, rps, true>, 512, 2, 1, 0, nst, rps }
+#define TILES(nst, rps) { 32, 32, 64, 3, 1, conv_wstat_f32<nst, rps>, 512, 2, 1, 0, nst, rps }
+#define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d, 0, 0 }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
     TILE(128, 64, 2, 2),    // 2
@@ -1105,8 +1804,18 @@ const TileCfg kTiles[] = {
     TILE10(64, 64, 2, 2, 32, 2, 8),   // 58
     TILE10(32, 128, 2, 2, 64, 2, 8),  // 59
     TILE10(64, 32, 2, 2, 64, 2, 8),   // 60
-    // (D = 4 and 6 variants of 53-60 were tried inside the frame graph, scripts/tune_frame.py: no layer got faster —
-    //  e.g. layer3's 3x3 908 us/frame at D = 2, 909 at D = 4 and 6 — so a batch-1 k-step is not waiting for loads)
+    TILEW(32, 64, 2, 4, 3),           // 61: weight-streaming consumers (filters in fragment order, usot_conv_pack_wfrag_f32); 1 x 4 waves
+    TILEW(32, 64, 2, 4, 2),           // 62
+    TILEW(64, 64, 2, 4, 3),           // 63
+    TILEW2(32, 64, 2, 4, 2),          // 64: the same, consumer waves 2 x 2 (a wave pair shares its filter fragments through L1)
+    TILEW2(64, 64, 2, 4, 2),          // 65
+    TILE11(32, 64, 2, 2, 64, 2, 4),   // 66: v3 with fragment reads two rounds ahead (PF = 2)
+    TILE11(32, 32, 2, 2, 64, 2, 8),   // 67
+    TILES(18, 1),                     // 68: weight-stationary, K = 2304 (3 x 3 x 256)
+    TILES(9, 1),                      // 69: K = 1152 (3 x 3 x 128)
+    TILESB(18, 1),                    // 70: K = 2304, blocked accumulation (64-product blocks + running total)
+    TILES(8, 1),                      // 71: K = 1024
+    // (61-67: parity-green, none faster than v3 - DESIGN.md section 3.1 "what a k-step waits for")
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1144,12 +1853,62 @@ extern "C" int usot_conv_tile_name(int tile, char *buf, int len)
 {
     if (tile < 1 || tile > kNumTiles || !buf || len < 8) return USOT_EINVAL;
     const TileCfg &t = kTiles[tile - 1];
+    if (t.nst) { snprintf(buf, len, "conv_wstat_f32<NST=%d,RPS=%d>", t.nst, t.rps); return USOT_OK; }
+    if (t.wfrag) { snprintf(buf, len, "conv_igemm_f32_ws<%d,%d,D=%d,NPW=%d,DW=%d>", t.bm, t.bn, t.depth, (t.threads - 256) / 64, t.dw); return USOT_OK; }
+    if (t.dw == 2 && !t.wfrag) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=2>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.threads == 768 && t.ksw == 1) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=8>", t.bm, t.bn, t.bk, t.depth); return USOT_OK; }
     const char *fam = t.threads == 512 && t.ksw == 1 ? "conv_igemm_f32_v3" : (t.stages == 3 ? "conv_igemm_f32_v2" : "conv_igemm_f32");
     if (t.stages == 3 && t.ksw > 1) snprintf(buf, len, "%s<%d,%d,%d,%d> ksw=%d", fam, t.bm, t.bn, t.bk, t.ksw, t.ksw);
     else if (t.depth > 1)           snprintf(buf, len, "%s<%d,%d,BK=%d,D=%d>", fam, t.bm, t.bn, t.bk, t.depth);
     else if (t.stages == 3)         snprintf(buf, len, "%s<%d,%d,BK=%d>", fam, t.bm, t.bn, t.bk);
     else                            snprintf(buf, len, "%s<%d,%d>", fam, t.bm, t.bn);
+    return USOT_OK;
+}
+
+/* 1 when the tile takes its filters in MFMA fragment order (usot_conv_pack_wfrag_f32, descriptor field w_frag = 1) */
+extern "C" int usot_conv_tile_wfrag(int tile)
+{
+    if (tile < 1 || tile > kNumTiles) return 0;
+    return kTiles[tile - 1].wfrag;
+}
+
+/* weight-stationary tiles serve ONE reduction length: K the tile requires (0: any K the other rules allow); their other
+ * requirements: Cin % kpanel == 0 (128 or 256, returned through *kpanel), Cout % 32 == 0, ksplit == 1, w_frag == 1 */
+extern "C" int usot_conv_tile_kreq(int tile, int *kpanel)
+{
+    if (tile < 1 || tile > kNumTiles || !kTiles[tile - 1].nst) return 0;
+    if (kpanel) *kpanel = 128 * kTiles[tile - 1].rps;
+    return kTiles[tile - 1].nst * 128 * kTiles[tile - 1].rps;
+}
+
+namespace {
+__global__ void pack_wfrag_kernel(const float *__restrict__ w, float *__restrict__ wf, int Cout, int K, long n4)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // one float4 of the packed bank
+    if (i >= n4) return;
+    const int lane = (int)(i & 63);
+    const long rest = i >> 6;
+    const int r = (int)(rest & 3);
+    const long tb = rest >> 2;                                          // cb * KT + kt
+    const int KT = K / 64;
+    const int kt = (int)(tb % KT), cb = (int)(tb / KT);
+    const int row = cb * 16 + (lane & 15), col = kt * 64 + r * 16 + (lane >> 4) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < Cout) v = *(const f32x4 *)(w + (long)row * K + col);
+    *(f32x4 *)(wf + i * 4) = v;
+}
+}  // namespace
+
+/* w [Cout][K] row-major (k = (kh*KW + kw)*Cin + ci, Cin % 64 == 0) -> wf: ceil(Cout/16) blocks of 16 x K floats in the order
+ * [block][k-tile of 64][round of 16 k][lane = (k-slot quad)*16 + row][4 consecutive k]: what lane `lane` of a consumer
+ * wave feeds v_mfma_f32_16x16x4_f32 as the A operand, one contiguous KiB per wave and round.  Rows past Cout are zero. */
+extern "C" int usot_conv_pack_wfrag_f32(void *stream, const float *w, float *wf, int Cout, int K)
+{
+    if (!w || !wf || Cout < 1 || K < 64 || (K & 63)) return USOT_EINVAL;
+    if (((uintptr_t)w | (uintptr_t)wf) & 15) return USOT_EINVAL;
+    const long n4 = (long)((Cout + 15) / 16) * 16 * K / 4;
+    hipLaunchKernelGGL(pack_wfrag_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, wf, Cout, K, n4);
+    if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
     return USOT_OK;
 }
 
@@ -1234,10 +1993,52 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
     if (tile < 1 || tile > kNumTiles) return USOT_EINVAL;
     const TileCfg &tc = kTiles[tile - 1];
     long blocks = 0;
+    if (tc.nst) {                          // weight-stationary tiles: one workgroup per (group, 32 channels, pixel range)
+        double work = 0;
+        for (int i = 0; i < n; ++i) work += (double)bt.p[i].M * bt.p[i].Cout * bt.p[i].groups;
+        int cus = 256;
+        {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+        }
+        for (int i = 0; i < n; ++i) {
+            ConvK &p = bt.p[i];
+            const int pk = 128 * tc.rps;
+            if (p.K != tc.nst * pk || (d[i].Cin % pk) || (d[i].Cout & 31) || p.ksplit != 1 || !d[i].w_frag) return USOT_EINVAL;
+            if (p.groups > 1 && (p.w_gs % ((long)16 * p.K))) return USOT_EINVAL;
+            if ((long)p.N * p.H * p.W * p.Cin >= (1L << 31)) return USOT_EINVAL;        // 32-bit element offsets in the loader
+            p.MT = (p.M + 31) / 32;
+            p.NT = d[i].Cout / 32;
+            // pixel ranges: this problem's share of the CUs (one workgroup per CU: 8 waves x ~220 VGPRs), by its share of the work
+            const double share = (double)p.M * p.Cout * p.groups / work;
+            int pr = (int)(cus * share / ((double)p.groups * p.NT));
+            if (d[i].ksplit < 0) pr = -d[i].ksplit;            // experiments: ksplit = -PR forces the number of pixel ranges
+            p.pr = pr < 1 ? 1 : (pr > p.MT ? p.MT : pr);
+            bt.start[i] = (int)blocks;
+            blocks += (long)p.groups * p.NT * p.pr;
+        }
+        for (int i = n; i < 5; ++i) bt.start[i] = (int)blocks;
+        const size_t lds = (size_t)4 * 32 * (128 * tc.rps + 4) * sizeof(float) + 8 * 4 * 64 * 16;
+        static bool raised[128] = {false};
+        if (!raised[tile]) {
+            if (hipFuncSetAttribute((const void *)tc.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return USOT_ELAUNCH;
+            raised[tile] = true;
+        }
+        hipLaunchKernelGGL(tc.fn, dim3((unsigned)blocks), dim3(tc.threads), lds, (hipStream_t)stream, bt);
+        if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
+        return USOT_OK;
+    }
     for (int i = 0; i < n; ++i) {
         ConvK &p = bt.p[i];
         if (d[i].Cin % tc.bk) return USOT_EINVAL;
         if (p.ksplit > p.K / tc.bk) return USOT_EINVAL;
+        // filters in fragment order iff the tile streams them (a row-major bank under a streaming tile, or the reverse,
+        // would compute garbage silently); group strides must keep whole 16-row blocks
+        if ((d[i].w_frag != 0) != (tc.wfrag != 0)) return USOT_EINVAL;
+        if (tc.wfrag && p.groups > 1 && (p.w_gs % ((long)16 * p.K))) return USOT_EINVAL;
         p.MT = (p.M + tc.bm - 1) / tc.bm;
         p.NT = (d[i].Cout + tc.bn - 1) / tc.bn;
         bt.start[i] = (int)blocks;
@@ -1245,7 +2046,16 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
     }
     for (int i = n; i < 5; ++i) bt.start[i] = (int)blocks;
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
-    const size_t lds = (size_t)tc.ksw * tc.stages * (tc.bm + tc.bn) * (tc.bk + 4) * sizeof(float);
+    // the weight-streaming tiles stage the activation operand only
+    // v3 / ws with BK = 64: unpadded swizzled rows; every other form pads a row by 4 floats
+    const bool v3fam = tc.stages == 3 && tc.ksw == 1 && tc.threads >= 512;
+#ifdef USOT_V3_SWZ
+    const int ld = (tc.bk == 64 && (v3fam || tc.wfrag)) ? 64 : tc.bk + 4;
+#else
+    const int ld = (tc.bk == 64 && tc.wfrag) ? 64 : tc.bk + 4;
+    (void)v3fam;
+#endif
+    const size_t lds = (size_t)tc.ksw * tc.stages * (tc.bm + (tc.wfrag ? 0 : tc.bn)) * ld * sizeof(float);
     if (lds > 64 * 1024) {
         static bool raised[128] = {false};
         if (!raised[tile]) {

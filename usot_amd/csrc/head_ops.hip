@@ -968,7 +968,7 @@ extern "C" int usot_thin_conv3x3_f32(void *stream, const usot_conv_desc *d, int 
     return USOT_OK;
 }
 
-extern "C" int usot_abi_version(void) { return 1; }
+extern "C" int usot_abi_version(void) { return 2; }   // 2: usot_conv_desc.w_frag
 
 extern "C" const char *usot_strerror(int code)
 {

@@ -75,6 +75,13 @@ class PackedConv:
             self._wpp32 = hip.pw_pair_f32_pack(self.w)
         return self._wpp32
 
+    def w_frag(self):
+        """fp32 filter bank in MFMA fragment order for the weight-streaming / weight-stationary conv tiles
+        (hip.pack_wfrag: a permutation inside every 16-row block, so row offsets that are multiples of 16 keep their meaning)."""
+        if '_wfrag' not in self.__dict__:
+            self._wfrag = hip.pack_wfrag(self.w)
+        return self._wfrag
+
     def w_lp(self, dtype=torch.bfloat16):
         """bf16 / fp16 copy of the folded filter bank (made on first use; fp32 stays the master)."""
         cache = self.__dict__.setdefault('_wlp', {})
@@ -280,18 +287,24 @@ class Builder:
         if force_ks is not None:
             ksplit = force_ks
         ws = None
+        frag = hip.tile_wfrag(ttile)                # tiles that take their filters in MFMA fragment order
+        if frag and (row0 % 16 or ((w_rows or cout) % 16 and groups > 1) or not hip.tile_supports(ttile, pc.cin, cout, k)):
+            ttile, ksplit, frag = (self.default_batch_tile if tile is not None else 0), 1, 0     # geometry the tile cannot take
+        if frag and hip.tile_kreq(ttile)[0]:
+            ksplit = 1                              # weight-stationary tiles split k inside the workgroup
         if ksplit > 1:            # partial slabs + one ticket per tile (usot_conv_ws_floats), tickets zero before first use
             ws = self.buf(ksplit * groups * m * cout + groups * ((m + 15) // 16) * ((cout + 31) // 32))
             ws.zero_()
-        d = hip.conv_desc(x.data_ptr(), pc.w.data_ptr() + row0 * k * 4, pc.b.data_ptr() + row0 * 4, y.data_ptr(),
+        wbank = pc.w_frag() if frag else pc.w
+        d = hip.conv_desc(x.data_ptr(), wbank.data_ptr() + row0 * k * 4, pc.b.data_ptr() + row0 * 4, y.data_ptr(),
                           N=n, H=h, W=w, Cin=pc.cin, OH=oh, OW=ow, Cout=cout, KH=pc.kh, KW=pc.kw,
                           stride=pc.stride, pad=pc.pad, dil=pc.dil,
                           res=res.data_ptr() if res is not None else None, act=act, act2=act2,
                           act_split=act_split, y_cstride=y_cstride, y_coff=y_coff, y_nchw=int(y_nchw),
                           groups=groups, x_gs=x_gs, w_gs=(w_rows or cout) * k, b_gs=(w_rows or cout),
                           y_gs=y_gs if y_gs else n * oh * ow * cout, r_gs=0,
-                          ksplit=ksplit, tile=ttile, ws=ws.data_ptr() if ws is not None else None)
-        self.plan.keep += [x, pc.w, pc.b]
+                          ksplit=ksplit, tile=ttile, ws=ws.data_ptr() if ws is not None else None, w_frag=frag)
+        self.plan.keep += [x, wbank, pc.b]
         log = (name, m, cout, k, groups, m * cout * k * groups)
         geom = dict(name=name, N=n, H=h, W=w, Cin=pc.cin, Cout=cout, KH=pc.kh, KW=pc.kw, stride=pc.stride,
                     pad=list(pc.pad), dil=list(pc.dil), groups=groups, has_res=res is not None)

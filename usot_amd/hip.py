@@ -15,7 +15,7 @@ ACT_NONE, ACT_RELU, ACT_EXP, ACT_CONF = 0, 1, 2, 3
 
 EXPORTS = (
     'usot_abi_version', 'usot_strerror', 'usot_conv2d_f32', 'usot_conv_tile_count',
-    'usot_conv_tile_info', 'usot_conv_tile_name', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
+    'usot_conv_tile_info', 'usot_conv_tile_name', 'usot_conv_tile_wfrag', 'usot_conv_tile_kreq', 'usot_conv_pack_wfrag_f32', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
     'usot_xcorr_depthwise_f32', 'usot_groupdw_f32', 'usot_conf_fusion_reduce_f32',
     'usot_prroi_pool_forward_f32', 'usot_prroi_pool_backward_f32', 'usot_prroi_pool_coor_backward_f32', 'usot_permute4_f32', 'usot_decode_f32',
     'usot_plan_create', 'usot_plan_destroy', 'usot_plan_add_conv', 'usot_plan_add_stem',
@@ -50,7 +50,7 @@ class ConvDesc(C.Structure):
                 ('groups', C.c_int32),
                 ('x_gs', C.c_int64), ('w_gs', C.c_int64), ('b_gs', C.c_int64), ('y_gs', C.c_int64),
                 ('r_gs', C.c_int64),
-                ('ksplit', C.c_int32), ('tile', C.c_int32)]
+                ('ksplit', C.c_int32), ('tile', C.c_int32), ('w_frag', C.c_int32), ('reserved0', C.c_int32)]
 
 
 class GroupDWDesc(C.Structure):
@@ -207,6 +207,8 @@ def lib():
         L.usot_decode_dev_f32.argtypes = ([C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_float] + [C.c_double] * 2
                                           + [C.c_void_p] * 2)
         L.usot_conv_tile_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.usot_conv_pack_wfrag_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 2
+        L.usot_conv_tile_kreq.argtypes = [C.c_int, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -238,6 +240,38 @@ def tile_name(tile):
     return buf.value.decode()
 
 
+def tile_wfrag(tile):
+    """1 when conv tile id `tile` streams its filters in fragment order (descriptor field w_frag, pack_wfrag)."""
+    return int(lib().usot_conv_tile_wfrag(int(tile))) if tile else 0
+
+
+def tile_kreq(tile):
+    """(K, Cin multiple) a weight-stationary conv tile requires, or (0, 0) for the tiles that take any geometry."""
+    if not tile:
+        return 0, 0
+    kp = C.c_int(0)
+    k = int(lib().usot_conv_tile_kreq(int(tile), C.byref(kp)))
+    return k, int(kp.value) if k else 0
+
+
+def tile_supports(tile, cin, cout, k):
+    """Whether conv tile id `tile` can run a convolution with these channel counts and reduction length."""
+    kreq, kp = tile_kreq(tile)
+    if not kreq:
+        return True
+    return k == kreq and cin % kp == 0 and cout % 32 == 0
+
+
+def pack_wfrag(w):
+    """[Cout, K] row-major fp32 filter bank (K % 64 == 0) -> the same bank in MFMA fragment order, rows padded to a multiple
+    of 16 (usot_conv_pack_wfrag_f32).  Returns a new device tensor [ceil(Cout/16)*16, K]."""
+    _dev(w)
+    cout, k = w.shape
+    wf = torch.empty(((cout + 15) // 16) * 16, k, device=w.device, dtype=torch.float32)
+    check(lib().usot_conv_pack_wfrag_f32(stream(), ptr(w.contiguous()), ptr(wf), cout, k), 'usot_conv_pack_wfrag_f32')
+    return wf
+
+
 def tile_table():
     L = lib()
     out = {}
@@ -253,7 +287,7 @@ def tile_table():
 def conv_desc(x, w, bias, y, *, N, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, pad=(0, 0), dil=(1, 1),
               res=None, act=ACT_NONE, act2=ACT_NONE, act_split=0, y_cstride=0, y_coff=0,
               res_cstride=0, res_coff=0, y_nchw=0, groups=1, x_gs=0, w_gs=0, b_gs=0, y_gs=0, r_gs=0,
-              ksplit=1, tile=0, ws=None):
+              ksplit=1, tile=0, ws=None, w_frag=0):
     d = ConvDesc()
     d.x, d.w, d.bias, d.res, d.y, d.ws = (x, w, bias or None, res or None, y, ws or None)
     d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout = N, H, W, Cin, OH, OW, Cout
@@ -263,7 +297,7 @@ def conv_desc(x, w, bias, y, *, N, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, pa
     d.act, d.act2, d.act_split = act, act2, act_split
     d.groups = groups
     d.x_gs, d.w_gs, d.b_gs, d.y_gs, d.r_gs = x_gs, w_gs, b_gs, y_gs, r_gs
-    d.ksplit, d.tile = ksplit, tile
+    d.ksplit, d.tile, d.w_frag = ksplit, tile, w_frag
     return d
 
 
@@ -281,10 +315,13 @@ def conv2d(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, ac
     if ksplit > 1:        # slabs + tile tickets (usot_conv_ws_floats); the tickets must start at zero
         ws = torch.zeros(ksplit * N * OH * OW * Cout + ((N * OH * OW + 15) // 16) * ((Cout + 31) // 32), device=x.device,
                          dtype=torch.float32)
+    frag = tile_wfrag(tile)
+    if frag:                # weight-streaming tile: the filter bank in MFMA fragment order
+        w = pack_wfrag(w)
     d = conv_desc(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                   N=N, H=H, W=W_, Cin=Cin, OH=OH, OW=OW, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad,
                   dil=dil, res=res.data_ptr() if res is not None else None, act=act, tile=tile,
-                  ksplit=ksplit, ws=ws.data_ptr() if ws is not None else None, y_nchw=int(y_nchw))
+                  ksplit=ksplit, ws=ws.data_ptr() if ws is not None else None, y_nchw=int(y_nchw), w_frag=frag)
     check(lib().usot_conv2d_f32(stream(), C.byref(d)), 'usot_conv2d_f32')
     return y
 
