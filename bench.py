@@ -107,6 +107,34 @@ def run_frames_multi(group, n):
 K_PWPAIR, K_PW1, K_SC3, K_PW3 = 18, 19, 20, 21          # plan op kinds of the fused pointwise pair / the streaming 1x1 and 3x3 convs (csrc/plan.hip)
 
 
+def build_info_line():
+    """What the in-tree library is and whether the last build() compiled anything (usot_amd/build.py: build_info.json)."""
+    from usot_amd import build
+    bi = build.build_info()
+    return {'lib': os.path.relpath(build.LIB, ROOT), 'lib_mtime': bi.get('lib_mtime'), 'lib_stale': bi.get('lib_stale'),
+            'csrc_tree': bi.get('csrc_tree_now'), 'built_from_csrc_tree': bi.get('csrc_tree'),
+            'compiled_units_last_build': bi.get('compiled_units'), 'build_seconds': bi.get('seconds'), 'build_host': bi.get('host'),
+            'build_when': bi.get('when')}
+
+
+def _tree_now():
+    from usot_amd import build
+    if not hasattr(_tree_now, 'v'):
+        _tree_now.v = build.csrc_tree()
+    return _tree_now.v
+
+
+def counters_current(meta, path):
+    """(ok, source string).  A committed counter file (profiles/pmc_*.json) describes the kernels of ONE source tree: its
+    `_meta.csrc_tree` (usot_amd/build.py: csrc_tree, a content hash of csrc/ + include/) must equal the running tree's, otherwise
+    every field derived from it is reported as null with the reason — a kernel edit without a new scripts/round_snapshot.sh
+    pass can no longer leave stale traffic / mfma_busy / clock figures in the line."""
+    have, now = (meta or {}).get('csrc_tree'), _tree_now()
+    if have == now:
+        return True, '%s@%s (csrc_tree %s)' % (path, (meta or {}).get('commit', ''), now)
+    return False, '%s is STALE: measured on csrc_tree %s, running %s - rerun scripts/round_snapshot.sh' % (path, have, now)
+
+
 def roofline(sess, frames):
     """Dominant kernel = the conv_igemm_f32 tile instance with the largest total time."""
     prof = sess.plan.profile(frames=frames, reps=1)      # every op once per pass, in frame order (cold operands, as in a replay)
@@ -137,10 +165,10 @@ def roofline(sess, frames):
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
             pmc = json.load(f)
-        traffic = pmc.get(hip.tile_name(tile), {}).get('hbm_bytes_per_launch')
-        if traffic is not None:
-            traffic_src = 'profiles/pmc_traffic.json@%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)' \
-                          % pmc.get('_meta', {}).get('commit', 'round1')
+        ok, traffic_src = counters_current(pmc.get('_meta'), 'profiles/pmc_traffic.json')
+        if ok:
+            traffic = pmc.get(hip.tile_name(tile), {}).get('hbm_bytes_per_launch')
+            traffic_src += ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)'
     except Exception:
         pass
     busy = pmc_busy(hip.tile_name(tile), MFMA_F32_PEAK_TFLOPS)
@@ -170,9 +198,12 @@ def pmc_busy(kernel, peak):
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_busy.json')) as f:
             pj = json.load(f)
+        ok, src = counters_current(pj.get('_meta'), 'profiles/pmc_busy.json')
+        if not ok:
+            return {'stale': src}
         e = pj['kernels'][kernel]
         return {'clock_ghz': e['clock_ghz'], 'mfma_busy': e['mfma_busy_frac'], 'peak_sustained': round(peak * e['clock_ghz'] / 2.4, 1),
-                'source': 'profiles/pmc_busy.json@%s' % pj.get('_meta', {}).get('commit', '')}
+                'source': src}
     except Exception:
         return None
 
@@ -180,6 +211,8 @@ def pmc_busy(kernel, peak):
 def busy_fields(busy, ach):
     if not busy:
         return {'peak_sustained': None}
+    if 'stale' in busy:
+        return {'peak_sustained': None, 'clock_ghz': None, 'mfma_busy': None, 'busy_source': busy['stale']}
     return {'peak_sustained': busy['peak_sustained'], 'frac_of_sustained': round(ach / busy['peak_sustained'], 4),
             'clock_ghz': busy['clock_ghz'], 'mfma_busy': busy['mfma_busy'], 'busy_source': busy['source']}
 
@@ -251,9 +284,11 @@ def xcorr_traffic(kernel, samples):
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_xcorr.json')) as f:
             pmc = json.load(f)
+        ok, src = counters_current(pmc.get('_meta'), 'profiles/pmc_xcorr.json')
+        if not ok:
+            return {'traffic': None, 'traffic_source': src}
         per = pmc[kernel]['hbm_bytes_per_sample']
-        return {'traffic': int(per) * samples, 'traffic_to_algorithmic': pmc[kernel]['ratio_to_algorithmic'],
-                'traffic_source': 'profiles/pmc_xcorr.json@%s' % pmc.get('_meta', {}).get('commit', '')}
+        return {'traffic': int(per) * samples, 'traffic_to_algorithmic': pmc[kernel]['ratio_to_algorithmic'], 'traffic_source': src}
     except Exception:
         return {'traffic': None}
 
@@ -377,7 +412,7 @@ def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, 
     x = torch.from_numpy(synth.crop(3000, batch, size)).to(device)
     for _ in range(max(2, warmup)):
         e.features_bf16(x)
-    p = e._feat[('bf16', batch, size)]
+    p = next(v for k, v in e._feat.items() if k[:3] == ('bf16', batch, size))
     n, dt = _timed(p['plan'].run, min_seconds, steps)
     prof = p['plan'].profile(frames=3, reps=1)
     convs = iter(p['log'])
@@ -400,9 +435,11 @@ def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, 
     if batch == 64 and size == 255 and os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        traffic = tj.get('hbm_bytes_per_step')
-        tsrc = 'profiles/pmc_traffic_bf16.json@%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, summed over the step)' % tj['_meta'].get('commit', '?')
-        by_kernel = {k: v['hbm_bytes_per_launch'] for k, v in sorted(tj.get('by_kernel', {}).items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches_per_step'])[:6]}
+        ok, tsrc = counters_current(tj.get('_meta'), 'profiles/pmc_traffic_bf16.json')
+        if ok:
+            traffic = tj.get('hbm_bytes_per_step')
+            tsrc += ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, summed over the step)'
+            by_kernel = {k: v['hbm_bytes_per_launch'] for k, v in sorted(tj.get('by_kernel', {}).items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches_per_step'])[:6]}
     return {
         'workload': 'configs[2]: batch=%d search crops %dx%d bf16, backbone + neck convs on v_mfma_f32_16x16x32_bf16, '
                     'fp32 accumulate, one hipGraph' % (batch, size, size),
@@ -435,7 +472,7 @@ def backbone_bf16(a, device):
         'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': r['workload'], 'search': a.size, 'hipgraph': True},
-        'roofline': r['roofline'],
+        'roofline': r['roofline'], 'build_info': build_info_line(),
     }
     print(json.dumps(line))
 
@@ -457,7 +494,60 @@ def measure_track_mixed(model, device, batch=32, size=255, lp='fp16', heads_f32=
     dt_ = torch.float16 if lp == 'fp16' else torch.bfloat16
     for _ in range(max(2, warmup)):
         e.track_mixed(x, model.zf, mem, sm, dtype=dt_, heads_lp=not heads_f32)
-    return e._track[('mixed', batch, size, 7, dt_, not heads_f32)]
+    return next(v for k, v in e._track.items() if k[:6] == ('mixed', batch, size, 7, dt_, not heads_f32))
+
+
+FRAME_GFLOP = 54.304194           # one tracked 255^2 frame, N_q = 7 (duplicate search encodes removed)
+MIXED_DOMINANT_KERNEL = 'conv_igemm_bf16<256, 256, 4, 4, true, 0, 2, 16, 1>'    # the fp16 256 x 256 tile (scripts/pmc_busy.py key)
+
+
+def mixed_roofline(pm, batch, size, n, dt, top=5):
+    """Roofline object of configs[4]'s per-GPU step (`batch` streams in one mixed-precision plan): algorithmic FLOPs of
+    SURVEY 8(d) per tracked frame x batch over the replay time against the dense fp16 MFMA peak; the clock / matrix-pipe
+    utilisation of its dominant tile and the step's HBM traffic from the committed counter passes of THIS workload
+    (scripts/round_snapshot.sh: `--workload track_mixed`; null when they were measured on another source tree); per-op
+    HIP-event spans (plan.profile) for the slowest launches."""
+    prof = pm['plan'].profile(frames=5, reps=1)
+    convs = iter(pm['log'])
+    rows, ms_all, ms_conv, fl_conv = [], 0.0, 0.0, 0.0
+    for kind, tile, ks, groups, ms in prof:
+        ms_all += ms
+        if kind in (0, 11, 18, 22, 23, 24, 25, 26, 27, 28):
+            try:
+                name, M, N, K, g, macs = next(convs)
+            except StopIteration:
+                continue
+            ms_conv += ms
+            fl_conv += 2.0 * macs
+            rows.append((ms, name, M, N, K, 2.0 * macs / ms / 1e9))
+        else:
+            rows.append((ms, 'op kind %d' % kind, 0, 0, 0, 0.0))
+    gflop = batch * FRAME_GFLOP * (size / 255.0) ** 2 if size != 255 else batch * FRAME_GFLOP
+    ach = gflop * n / dt / 1e3
+    alg_bytes = sum(pm.get('lp_bytes', [])) + sum(pm.get('f32_bytes', [])) + batch * 3 * size * size * 4
+    traffic, tsrc, by_kernel = None, None, None
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic_mixed.json')
+    if batch == 32 and size == 255 and os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        ok, tsrc = counters_current(tj.get('_meta'), 'profiles/pmc_traffic_mixed.json')
+        if ok:
+            traffic = tj.get('hbm_bytes_per_step')
+            tsrc += ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, summed over the step)'
+            by_kernel = {k: v['hbm_bytes_per_launch'] for k, v in sorted(tj.get('by_kernel', {}).items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches_per_step'])[:6]}
+    return {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / BF16_PEAK_TFLOPS, 4),
+            **busy_fields(pmc_busy(MIXED_DOMINANT_KERNEL, BF16_PEAK_TFLOPS), ach),
+            'algorithmic_gflop_per_step': round(gflop, 1),
+            'traffic': traffic, 'traffic_source': tsrc,
+            'algorithmic_bytes_per_step': int(alg_bytes),
+            'algorithmic_bytes_note': 'every conv launch: operands + result once (storage type of each), + the fp32 crops; GroupDW / reduce / prediction maps not counted',
+            'traffic_to_algorithmic': round(traffic / alg_bytes, 3) if traffic else None,
+            'traffic_per_launch_top_kernels': by_kernel,
+            'kernel': 'conv_igemm_bf16<f16> family + heads (%d launches per step)' % len(prof),
+            'conv_ms_per_step': round(ms_conv, 3), 'all_ops_ms_per_step': round(ms_all, 3),
+            'conv_tflops': round(fl_conv / (ms_conv * 1e-3) / 1e12, 1) if ms_conv else None,
+            'slowest': [{'op': nm, 'M': M, 'N': N, 'K': K, 'ms': round(ms, 3), 'tflops': round(tf, 1)}
+                        for ms, nm, M, N, K, tf in sorted(rows, reverse=True)[:top]]}
 
 
 def measure_lockstep_f32(model, device, batch=4, size=255, steps=0, min_seconds=1.0):
@@ -520,8 +610,9 @@ def track_mixed(a, rank, world, device):
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.lp + '+f32', 'data': 'synthetic',
             'config': {'workload': 'configs[4]: %s backbone + fp32 xcorr mixed precision, batch=%d per GPU x %d GPUs, N_q=7'
                                    % (a.lp, b, world), 'search': a.size, 'hipgraph': True,
-                       'weights': 'synthetic seed 0 (calibrated BN), %s broadcast %d B' % (streams.backend_name(), wbytes),
-                       'head_convs': 'f32' if a.heads_f32 else a.lp + ' (encoders, conf/value, towers); preds, memory-kernel encoders, GroupDW, reduce f32'}}))
+                       'weights': 'synthetic seed 0 (calibrated BN), %s' % streams.broadcast_summary(),
+                       'head_convs': 'f32' if a.heads_f32 else a.lp + ' (encoders, conf/value, towers); preds, memory-kernel encoders, GroupDW, reduce f32'},
+            'roofline': mixed_roofline(p, b, a.size, steps, dt), 'build_info': build_info_line()}))
     streams.barrier()
 
 
@@ -589,7 +680,8 @@ def main():
     device = torch.device('cuda', local % ndev)
     torch.cuda.set_device(device)
     streams.init(backend='gloo' if oversub else None, device_index=device.index)
-    torch.set_num_threads(host_threads())        # the box shows 256 hardware threads under a 16-CPU quota
+    # the box shows 256 hardware threads under a 16-CPU quota; N ranks share that quota: cap every rank at quota // N
+    torch.set_num_threads(min(host_threads(), streams.host_thread_cap(world)))
     if a.workload == 'backbone_bf16':
         if rank == 0:
             backbone_bf16(a, device)
@@ -627,8 +719,11 @@ def main():
             'config': {'workload': 'configs[1]: batch=1 ResNet-50(layer3)+neck, fused depthwise xcorr, cls/reg/'
                                    'memory heads (N_q=7), decode + PrRoIPool, fp32, 1 stream per GPU',
                        'search': a.size, 'template': 127, 'streams': world * S, 'streams_per_gpu': S, 'weights': 'synthetic seed 0 '
-                       '(calibrated BN), %s broadcast %d B' % (streams.backend_name(), wbytes), 'hipgraph': True,
-                       'devices_visible': ndev},
+                       '(calibrated BN), %s' % streams.broadcast_summary(), 'hipgraph': True,
+                       'devices_visible': ndev, 'host_threads_per_rank': torch.get_num_threads(),
+                       'sessions': len({id(g[0]) for g in group}),
+                       # distinct pinned result blocks and distinct HIP streams: every video has its own
+                       'result_streams': len({g[0].out8.data_ptr() for g in group}), 'hip_streams': len({g[4].cuda_stream for g in group})},
         }
         line['roofline'] = roofline(sess, frames=10)
         if not a.no_xcorr:
@@ -644,12 +739,14 @@ def main():
             line['track_mixed_b32'] = {
                 'workload': 'configs[4], one GPU: fp16 backbone + head convs, fp32 xcorr / reduce / predictions, 32 streams in '
                             'lock step, N_q=7, one hipGraph', 'value': round(32 * n / t, 1), 'unit': 'frames/s',
-                'steps': n, 'ms_per_step': round(t / n * 1e3, 3), 'dtype': 'fp16+f32'}
+                'steps': n, 'ms_per_step': round(t / n * 1e3, 3), 'dtype': 'fp16+f32',
+                'roofline': mixed_roofline(pm, 32, a.size, n, t)}
             line['lockstep_f32_b4'] = measure_lockstep_f32(model, device, 4, a.size)
             if a.size != 271:
                 line['track_271'] = measure_track_271(model, device)
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
+        line['build_info'] = build_info_line()
         print(json.dumps(line))
     streams.barrier()
 

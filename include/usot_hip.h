@@ -34,6 +34,9 @@ extern "C" {
 #define USOT_ACT_CONF      3   /* exp(min(max(x,0),4))    connect.py:128-131 (ReLU then clamp) */
 
 int usot_abi_version(void);
+/* One GPU per process: the library binds to the first device a launcher runs on (its launchers cache per-device state);
+ * USOT_OK on that device, USOT_ESTATE on any other.  Every launcher with such state calls it first. */
+int usot_device_guard(void);
 /* HBM ceiling probe of the box (csrc/bw_probe.hip): mode 0 read `bytes`, 1 copy `bytes`, 2 read `bytes` + write bytes / 4
  * (GroupDW's byte mix, one interleaved read stream, non-temporal stores).  bytes % 4096 == 0. */
 int usot_bw_probe(void *stream, const void *src, void *dst, int64_t bytes, int mode);

@@ -20,7 +20,7 @@ for B in (1, 4):
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
     print('B=%d fp32 features %.1f us' % (B, bench(lambda: e.features(x))))
     print('B=%d fp16 features %.1f us' % (B, bench(lambda: e.features_bf16(x, dtype=torch.float16))))
-    p = e._feat[('f16', B, 255)]
+    p = next(v for k, v in e._feat.items() if k[:3] == ('f16', B, 255))
     prof = p['plan'].profile(20)
     print('  lp ops:', ' '.join('%d:%.1f' % (k, ms * 1e3) for k, _, _, _, ms in prof))
     key = [k for k in e._feat if k[0] not in ('f16', 'bf16') and k[-1] == 255 or (len(k) == 2 and k[1] == 255)]

@@ -18,7 +18,7 @@ B = a.batch
 dt = torch.bfloat16 if a.lp == 'bf16' else torch.float16
 x = torch.from_numpy(synth.crop(1, B, 255)).cuda()
 for _ in range(3): e.features_bf16(x, dtype=dt)
-p = e._feat[('bf16' if a.lp == 'bf16' else 'f16', B, 255)]
+p = next(v for k, v in e._feat.items() if k[:3] == ('bf16' if a.lp == 'bf16' else 'f16', B, 255))
 prof = p['plan'].profile(10)
 convs = iter(p['log'])
 tot = 0.0; fl = 0.0

@@ -21,7 +21,7 @@ for rep in range(2):
             engine.LP_TUNING[tuple(int(v) for v in k.split(','))] = int(t)
         m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to(dev)
         for _ in range(3): m.engine.features_bf16(x)
-        plans.append((c or 'table', m, m.engine._feat[('bf16', B, 255)]['plan']))
+        plans.append((c or 'table', m, next(v for k, v in m.engine._feat.items() if k[:3] == ('bf16', B, 255))['plan']))
 for rnd in range(2):
     for c, m, plan in plans:
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -76,7 +76,9 @@ def main(argv):
         path = argv[2]
         cur = json.load(open(path)) if os.path.exists(path) else {'_meta': {}, 'kernels': {}}
         cur['kernels'].update(out)
-        cur['_meta'].update({'commit': argv[3] if len(argv) > 3 else '',
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from usot_amd import build as _b
+        cur['_meta'].update({'commit': argv[3] if len(argv) > 3 else '', 'csrc_tree': _b.csrc_tree(),
                              'what': 'rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES; clock = SQ_BUSY_CYCLES (mean over '
                                      'the 32 SEs) / duration; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (32 SIMDs per SE x SQ_BUSY_CYCLES)'})
         json.dump(cur, open(path, 'w'), indent=1, sort_keys=True)

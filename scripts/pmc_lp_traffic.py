@@ -11,8 +11,15 @@ pw_kstream_kernel, conv3x3_halo_kernel -> a traffic figure BELOW the algorithmic
 
 Writes profiles/pmc_traffic_bf16.json: bytes per STEP, per launch of every kernel symbol, and the step's launch list;
 bench.py reads it for `backbone_bf16_b64.roofline.traffic`.
-    python scripts/pmc_lp_traffic.py FETCH.db WRITE.db out.json [commit] [head-kernel-prefix]"""
+    python scripts/pmc_lp_traffic.py FETCH.db WRITE.db out.json [commit] [head-kernel-prefix] [command]"""
 import collections, json, re, sqlite3, sys
+
+def _csrc_tree():
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from usot_amd import build
+    return build.csrc_tree()
+
 
 
 def short(name):
@@ -74,10 +81,10 @@ def main(argv):
         by[k] = {'launches_per_step': n // len(st_f), 'fetch_kb_raw': round(kb / n, 1), 'write_kb_raw': round(wkb / wn, 1),
                  'hbm_bytes_per_launch': int(per_launch * 1024)}
         total += per_launch * 1024 * n / len(st_f)
-    out = {'_meta': {'commit': argv[4] if len(argv) > 4 else '', 'steps_profiled': [len(st_f), len(st_w)],
+    out = {'_meta': {'commit': argv[4] if len(argv) > 4 else '', 'csrc_tree': _csrc_tree(), 'steps_profiled': [len(st_f), len(st_w)],
                      'segments_seen': [nseg_f, nseg_w],
                      'selection': 'dispatch order: segments between launches of %s* with the modal kernel sequence' % head,
-                     'command': 'bench.py --workload backbone_bf16 --steps 20 --min-seconds 0',
+                     'command': argv[6] if len(argv) > 6 else 'bench.py --workload backbone_bf16 --steps 20 --min-seconds 0',
                      'correction': 'hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (gfx950: FETCH_SIZE counts 128-byte requests at 64 B)'},
            'hbm_bytes_per_step': int(total), 'launches_per_step': len(sig_f), 'launch_list': list(sig_f), 'by_kernel': by}
     json.dump(out, open(argv[3], 'w'), indent=1, sort_keys=True)

@@ -6,6 +6,13 @@ wide (16 B/lane) coalesced reads -> doubled.  Writes profiles/pmc_traffic.json, 
 reads for `roofline.traffic`."""
 import json, re, sqlite3, sys
 
+def _csrc_tree():
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from usot_amd import build
+    return build.csrc_tree()
+
+
 
 def per_kernel(path):
     db = sqlite3.connect(path)
@@ -50,7 +57,7 @@ for sym, (n, kb) in fetch.items():
     wkb = write.get(sym, (0, 0.0))[1]
     out[k] = {'launches_profiled': n, 'fetch_kb_raw': round(kb, 1), 'write_kb_raw': round(wkb, 1),
               'hbm_bytes_per_launch': int((2.0 * kb + wkb) * 1024)}
-out['_meta'] = {'commit': sys.argv[4] if len(sys.argv) > 4 else '', 'command': 'bench.py --steps 30 --min-seconds 0 --no-extras --no-xcorr --no-cpu-baseline',
+out['_meta'] = {'commit': sys.argv[4] if len(sys.argv) > 4 else '', 'csrc_tree': _csrc_tree(), 'command': 'bench.py --steps 30 --min-seconds 0 --no-extras --no-xcorr --no-cpu-baseline',
                 'correction': 'hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (gfx950: FETCH_SIZE counts 128-byte requests at 64 B)'}
 json.dump(out, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

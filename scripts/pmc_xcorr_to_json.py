@@ -5,6 +5,13 @@ MI355X_MICROARCH.md §HBM (gfx950 counts the 128-byte requests of wide coalesced
 beside the algorithmic 3 161 088 B.  usage: pmc_xcorr_to_json.py fetch.db write.db samples out.json [commit]"""
 import json, re, sqlite3, sys
 
+def _csrc_tree():
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from usot_amd import build
+    return build.csrc_tree()
+
+
 
 def per_kernel(path):
     db = sqlite3.connect(path)
@@ -22,7 +29,7 @@ def per_kernel(path):
 
 
 fetch, write, samples, out = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-res = {'_meta': {'commit': sys.argv[5] if len(sys.argv) > 5 else '', 'samples_per_launch': samples,
+res = {'_meta': {'commit': sys.argv[5] if len(sys.argv) > 5 else '', 'csrc_tree': _csrc_tree(), 'samples_per_launch': samples,
                  'algorithmic_bytes_per_sample': 3161088, 'correction': 'FETCH_SIZE x 2 (gfx950), WRITE_SIZE x 1, KB -> B'}}
 for sym, (n, kb) in fetch.items():
     m = re.search(r'(groupdw_\w+)', sym)

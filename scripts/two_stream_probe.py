@@ -21,7 +21,7 @@ def plan_for(batch, options=None):
     x = torch.from_numpy(synth.crop(1, batch, 255)).to(dev)
     for _ in range(3):
         e.features_bf16(x)
-    return e, e._feat[('bf16', batch, 255)]['plan']
+    return e, next(v for k, v in e._feat.items() if k[:3] == ('bf16', batch, 255))['plan']
 
 
 def timed(fn, n=200):

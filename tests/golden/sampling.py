@@ -11,6 +11,22 @@ def sample_index(name, numel, n=N_SAMPLES):
     return g.integers(0, numel, min(n, numel))
 
 
+def sample_index2(name, numel, n=N_SAMPLES):
+    """A second sample from another seed, DISJOINT from sample_index(name, numel): an error confined to elements the first
+    2 048 points miss has a second, independent chance of being seen."""
+    first = set(sample_index(name, numel, n).tolist())
+    g = np.random.default_rng(zlib.crc32((name + '#second').encode()) ^ 0x5bd1e995)
+    out = []
+    while len(out) < min(n, max(0, numel - len(first))):
+        for v in g.integers(0, numel, n).tolist():
+            if v not in first:
+                first.add(v)
+                out.append(v)
+                if len(out) == n:
+                    break
+    return np.array(out[:n], np.int64)
+
+
 def summarize(name, arr, full_below=8192):
     """{name+'/full'} for small tensors, else {'/samp', '/stats'} (mean, |mean|, std, max|.|)."""
     a = np.asarray(arr, dtype=np.float32)
@@ -20,6 +36,7 @@ def summarize(name, arr, full_below=8192):
     else:
         f = a.reshape(-1)
         out[name + '/samp'] = f[sample_index(name, f.size)]
+        out[name + '/samp2'] = f[sample_index2(name, f.size)]
         out[name + '/stats'] = np.array([f.mean(dtype=np.float64), np.abs(f).mean(dtype=np.float64),
                                          f.std(dtype=np.float64), np.abs(f).max()], np.float64)
     return out
@@ -45,4 +62,10 @@ def check(name, gold, arr, rtol, atol_scale=1.0):
     scale = np.maximum(np.abs(ref), atol_scale * np.abs(ref).mean() + 1e-30)
     err = float(np.max(np.abs(got - ref) / scale))
     assert err <= rtol, '%s: scaled error %.3e > %.1e' % (name, err, rtol)
+    if name + '/samp2' in gold:                         # the second, disjoint sample (fixtures written from round 5 on)
+        ref2, got2 = gold[name + '/samp2'], a.reshape(-1)[sample_index2(name, a.size)]
+        scale2 = np.maximum(np.abs(ref2), atol_scale * np.abs(ref).mean() + 1e-30)
+        err2 = float(np.max(np.abs(got2 - ref2) / scale2))
+        assert err2 <= rtol, '%s (second sample): scaled error %.3e > %.1e' % (name, err2, rtol)
+        err = max(err, err2)
     return err

@@ -61,3 +61,33 @@ def test_single_process_is_a_noop():
     assert streams.broadcast_weights(USOT(), src=0) == 0
     assert streams.shard('abcdef', 1, 3) == ['b', 'e']
     assert streams.max_over_ranks(3.5) == 3.5
+
+
+def test_host_thread_cap_divides_the_quota_between_ranks():
+    """SURVEY 8e: host cores are the one resource streams on different GPUs share; a rank gets quota // world threads."""
+    from usot_amd import streams
+    assert streams.host_thread_cap(8, quota=16) == 2
+    assert streams.host_thread_cap(1, quota=16) == 16
+    assert streams.host_thread_cap(8, quota=4) == 1
+    assert streams.host_thread_cap(2) >= 1
+
+
+def test_init_refuses_gloo_when_every_rank_has_its_own_gpu(monkeypatch):
+    """The RCCL branch is the product path on a GPU box: a gloo group with world <= visible GPUs raises instead of silently
+    moving the weights through host memory (the 2-ranks-on-1-GPU functional run, world > devices, stays allowed)."""
+    import torch
+    from usot_amd import streams
+    monkeypatch.setenv('RANK', '0'); monkeypatch.setenv('LOCAL_RANK', '0'); monkeypatch.setenv('WORLD_SIZE', '2')
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(torch.distributed, 'is_initialized', lambda: False)
+    called = []
+    monkeypatch.setattr(torch.distributed, 'init_process_group', lambda **kw: called.append(kw))
+    import pytest
+    with pytest.raises(RuntimeError, match='must broadcast over RCCL'):
+        streams.init(backend='gloo')
+    assert not called
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)       # oversubscribed functional run: allowed
+    monkeypatch.setattr(torch.distributed, 'get_backend', lambda: 'gloo')
+    streams.init(backend='gloo')
+    assert called and called[0]['backend'] == 'gloo'

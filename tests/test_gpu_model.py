@@ -146,6 +146,34 @@ def test_bf16_stem_on_the_fp16_mfma_is_not_less_accurate(oracle_sd, capsys):
     assert errs[True] < 6e-2 and errs[True] <= 1.15 * errs[False], errs
 
 
+def test_low_precision_plans_are_keyed_by_the_input_convention(oracle_sd):
+    """the raw-pixel decision of a low-precision plan was taken from the FIRST batch of a shape and applied to every
+    later one.  It is now part of the plan key: a caller that states the convention (raw_pixels=True / False) gets its own plan,
+    and that plan (the hi + lo stem, adequate for any range) is checked against the fp32 oracle."""
+    m = USOT()
+    m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True), strict=True)
+    m = m.eval().to(DEV)
+    e = m.engine
+    x = t(synth.crop(41, 2, 255))
+    e.features_bf16(x.to(DEV))                                       # 'auto': raw pixels seen first -> the fp16-arithmetic stem
+    got = e.features_bf16(x.to(DEV), raw_pixels=False).float().cpu().numpy()      # stated: any range -> the hi + lo stem, its own plan
+    keys = [k for k in e._feat if k[:3] == ('bf16', 2, 255)]
+    assert sorted(k[3] for k in keys) == [False, True], keys
+    with torch.no_grad():
+        ref = orc.neck(oracle_sd, orc.backbone(oracle_sd, x)).numpy()
+    assert float(np.abs(got - ref).mean() / np.abs(ref).mean()) < 6e-2
+    # a later [0, 1]-normalised batch of the same shape is NOT re-examined in 'auto' mode (documented: Engine._raw_pixels) ...
+    e.features_bf16((x / 255.0).to(DEV))
+    assert len([k for k in e._feat if k[:3] == ('bf16', 2, 255)]) == 2
+    # the engine option pins the convention for every shape (no min / max reduction at all)
+    m2 = USOT()
+    m2.load_state_dict(synth.torch_state_dict(m2, seed=0, calibrated=True), strict=True)
+    m2 = m2.eval().to(DEV)
+    m2.engine_options['options'] = {'lp_raw_pixels': False}
+    m2.engine.features_bf16(x.to(DEV))
+    assert [k[3] for k in m2.engine._feat] == [False] and not m2.engine._raw_seen
+
+
 @pytest.mark.parametrize('heads_lp', [False, True], ids=['heads_f32', 'heads_lp'])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['fp16', 'bf16'])
 def test_track_mixed_precision(net, oracle_sd, dtype, heads_lp):

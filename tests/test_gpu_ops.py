@@ -168,7 +168,12 @@ def test_xcorr_golden(gold_model):
 
 @pytest.mark.parametrize('S,x_rep,OW,cols', [(1, 1, 25, 1), (7, 7, 25, 1), (14, 7, 25, 5), (3, 1, 27, 1),
                                              (2, 1, 25, 5), (4, 2, 27, 5), (9, 1, 25, 2), (7, 7, 27, 2), (3, 1, 25, 50), (9, 1, 25, 3), (14, 7, 27, 3), (5, 1, 25, 3), (9, 1, 25, 4), (14, 7, 27, 4), (5, 1, 25, 4),
-                                             (9, 1, 25, 6), (14, 7, 27, 6), (5, 1, 25, 6), (70, 7, 25, 0), (66, 1, 27, 0)])
+                                             (9, 1, 25, 6), (14, 7, 27, 6), (5, 1, 25, 6), (70, 7, 25, 0), (66, 1, 27, 0),
+                                             # 7: non-temporal LDS-DMA; 8 / 9: the persistent LDS-DMA kernel: odd sample counts
+                                             # (a unit whose second sample does not exist), shared search maps, more units than
+                                             # resident workgroups (131 samples -> 528 units over 512 slots: the cross-unit tap prefetch)
+                                             (5, 1, 25, 7), (14, 7, 27, 7), (9, 1, 25, 8), (14, 7, 27, 8), (5, 1, 27, 8), (9, 1, 25, 9),
+                                             (21, 7, 27, 9), (131, 1, 25, 8), (133, 7, 27, 9), (131, 1, 27, 9)])
 def test_groupdw_fused(S, x_rep, OW, cols):
     g = torch.Generator().manual_seed(S * 31 + OW)
     XS = S // x_rep
@@ -183,6 +188,36 @@ def test_groupdw_fused(S, x_rep, OW, cols):
     nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
     out = hip.groupdw([nh(t) for t in xs], [nh(t) for t in zs], wsm.numpy(), x_rep=x_rep, cols=cols)
     assert rel_err(out.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('cols', [0, 6, 8, 9])
+def test_groupdw_three_segments_one_launch(cols):
+    """A frame batch's three segments (reg, cls with their own search-map channel offsets, memory with x_rep = 7 and its own
+    kernel maps) in ONE usot_groupdw_multi_f32 launch, as the engine issues them (engine.Builder.heads) - also on the persistent
+    LDS-DMA kernel (modes 8 / 9), whose unit walk crosses segment borders; odd sample counts per segment."""
+    g = torch.Generator().manual_seed(400 + cols)
+    b, m, OW = 3, 7, 25
+    geo = ((5, 5), (3, 5), (5, 3))
+    es = [torch.randn(b, OW + hk - 1, OW + wk - 1, 512, generator=g).to(DEV) for hk, wk in geo]       # merged cls | reg search maps
+    zk = [torch.randn(b, hk, wk, 512, generator=g).to(DEV) for hk, wk in geo]
+    mk = [torch.randn(b * m, hk, wk, 256, generator=g).to(DEV) for hk, wk in geo]
+    w_reg, w_cls = torch.softmax(torch.randn(3, generator=g), 0).numpy(), torch.softmax(torch.randn(3, generator=g), 0).numpy()
+    outs = [torch.full((b, OW, OW, 256), float('nan'), device=DEV), torch.full((b, OW, OW, 256), float('nan'), device=DEV),
+            torch.full((b * m, OW, OW, 256), float('nan'), device=DEV)]
+    mk_desc = lambda xs, zs, out, wsm, S, rep, x_co, z_cs: hip.groupdw_desc(
+        [t.data_ptr() for t in xs], [t.data_ptr() for t in zs], out.data_ptr(), wsm, S=S, x_rep=rep, OH=OW, OW=OW, Cc=256,
+        x_cs=[512] * 3, x_co=[x_co] * 3, z_cs=[z_cs] * 3, z_co=[x_co if z_cs == 512 else 0] * 3, cols=cols)
+    descs = [mk_desc(es, zk, outs[0], w_reg, b, 1, 256, 512), mk_desc(es, zk, outs[1], w_cls, b, 1, 0, 512),
+             mk_desc(es, mk, outs[2], w_cls, b * m, m, 0, 256)]
+    arr = (hip.GroupDWDesc * 3)(*descs)
+    hip.check(hip.lib().usot_groupdw_multi_f32(hip.stream(), arr, 3), 'groupdw_multi')
+    nchw = lambda t: t.permute(0, 3, 1, 2).cpu()
+    for out, wsm, co, zs, rep in ((outs[0], w_reg, 256, [z[..., 256:] for z in zk], 1), (outs[1], w_cls, 0, [z[..., :256] for z in zk], 1),
+                                  (outs[2], w_cls, 0, mk, m)):
+        ref = 0
+        for i in range(3):
+            ref = ref + float(wsm[i]) * orc.xcorr_depthwise(nchw(es[i][..., co:co + 256]).repeat_interleave(rep, 0), nchw(zs[i]))
+        assert rel_err(nchw(out).numpy(), ref.numpy()) < 1e-5
 
 
 @pytest.mark.parametrize('B,M', [(1, 7), (2, 7), (1, 1), (3, 4)])
@@ -1196,6 +1231,29 @@ def test_bneck_tail_lp(N, H, W, cn, dtype):
     assert ey <= 3 * ulp, ey
     assert et <= 4 * ulp, et
     assert hip.lib().usot_bneck_tail_lp(hip.stream(), C.byref(d), 96, dt) != 0
+
+
+def test_bneck_counted_waits_equal_full_waits():
+    """bneck_first_kernel decides that the next halo tile has landed with `s_waitcnt vmcnt(<stores issued since>)`,
+    bneck_tail_kernel relies on its residual loads for the same - correct only while the compiler emits exactly the counted
+    vector-memory operations.  The -DUSOT_BNECK_VMCNT0 build waits for everything: both builds, same seeded ragged images
+    (more tiles than workgroups, repeated launches), must produce the same BITS (scripts/bneck_bits.py)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'build_variant.py'), 'bneck_vmcnt0', 'bneck_lp.hip', '-DUSOT_BNECK_VMCNT0'],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors='replace')[-2000:]
+    safe = r.stdout.decode().strip().splitlines()[-1]
+    digests = []
+    for lib in (None, safe):
+        env = dict(os.environ)
+        env.pop('USOT_HIP_LIB', None)
+        if lib:
+            env['USOT_HIP_LIB'] = lib
+        q = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'bneck_bits.py')], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert q.returncode == 0, q.stderr.decode(errors='replace')[-2000:]
+        digests.append([ln for ln in q.stdout.decode().splitlines() if ln.startswith('bneck_bits')][0])
+    assert digests[0] == digests[1], digests
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['fp16', 'bf16'])

@@ -16,6 +16,46 @@ FILE_FLAGS = {'xcorr.hip': ['-fno-slp-vectorize'],
               'conv_igemm.hip': ['-std=c++20']}      # templated lambda over the producer's register buffers
 
 
+INFO = os.path.join(CSRC, 'build_info.json')      # written by build(): what the last call compiled (git-ignored, travels to the GPU box)
+
+
+def csrc_tree():
+    """Content hash of everything libusot_hip.so is built from (csrc/*.hip, csrc/*.h, include/*.h, this file's flags): the
+    key that ties a committed counter file (profiles/pmc_*.json: `_meta.csrc_tree`) to the kernels it was measured on.  The
+    GPU box has no .git, so this is a hash of file contents, not `git rev-parse HEAD:usot_amd/csrc`."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sources() + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + sorted(glob.glob(os.path.join(INCLUDE, '*.h')))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b'\0')
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    h.update(repr((FLAGS[:4], sorted(FILE_FLAGS.items()))).encode())     # include paths differ between boxes: the first four flags only
+    return h.hexdigest()[:16]
+
+
+def build_info():
+    """The record the last build() left (or a stub when the library was never built here)."""
+    import json
+    try:
+        with open(INFO) as f:
+            info = json.load(f)
+    except Exception:
+        info = {'compiled_units': None, 'note': 'no build record beside the library'}
+    info['lib_exists'] = os.path.exists(LIB)
+    info['lib_mtime'] = int(os.path.getmtime(LIB)) if os.path.exists(LIB) else None
+    info['lib_stale'] = is_stale()
+    info['csrc_tree_now'] = csrc_tree()
+    return info
+
+
+def _write_info(compiled, linked, seconds):
+    import json, socket, time
+    with open(INFO, 'w') as f:
+        json.dump({'csrc_tree': csrc_tree(), 'compiled_units': compiled, 'linked': linked, 'seconds': round(seconds, 1),
+                   'when': int(time.time()), 'host': socket.gethostname(), 'hipcc': _hipcc()}, f, indent=1, sort_keys=True)
+
+
 def _hipcc():
     for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
         if c and (os.path.sep not in c or os.path.exists(c)):
@@ -37,8 +77,13 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every .hip translation unit and link the shared library."""
+    """Compile every .hip translation unit and link the shared library.  Leaves csrc/build_info.json: which units THIS call
+    compiled (an empty list = the library was up to date and nothing ran), so a driver's record can show a real build."""
+    import time
+    t0 = time.time()
     if not force and not is_stale():
+        if not os.path.exists(INFO):
+            _write_info([], False, 0.0)
         return LIB
     cc = _hipcc()
     objs = []
@@ -68,6 +113,7 @@ def build(force=False, verbose=False):
     tmp = LIB + '.tmp%d' % os.getpid()
     subprocess.check_call([cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs)
     os.replace(tmp, LIB)
+    _write_info([os.path.basename(src) for src, _, _, _ in procs], True, time.time() - t0)
     return LIB
 
 

@@ -205,12 +205,21 @@ __global__ __launch_bounds__(512) void bneck_first_kernel(const BneckK p)
         // (stores_prev = this wave's y and t stores of the previous tile, the only younger operations — the next conv1's fragments
         //  are loaded once, before the loop: wave-uniform counts of rows inside the image.  Waiting for the stores too — their
         //  acknowledgements, not their issue — would put a memory round trip into every tile)
+        // The counted wait is correct only while this wave issues EXACTLY stores_prev vector-memory operations between the DMA and
+        // here (one store per in-image row; a compiler-inserted extra op would be safe, a merged or sunk store a silent LDS race).
+        // -DUSOT_BNECK_VMCNT0 builds wait for everything instead; tests/test_gpu_ops.py::test_bneck_counted_waits_equal_full_waits
+        // compares the two builds bit for bit on ragged images.
+#ifdef USOT_BNECK_VMCNT0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        (void)stores_prev;
+#else
         switch (stores_prev) {
 #define BK_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
         BK_W(12) BK_W(11) BK_W(10) BK_W(9) BK_W(8) BK_W(7) BK_W(6) BK_W(5) BK_W(4) BK_W(3) BK_W(2) BK_W(1)
 #undef BK_W
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
+#endif
         __syncthreads();                             // #1: x(tile) visible; the other slot and the t region are free
 #ifndef USOT_BKABL_NODMA
         if (next < p.ntiles) issue_x(next, slot ^ 1);
@@ -508,7 +517,11 @@ __global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckTK p)
         const int next = tile_of(kit + 1);
         // this tile's halo was issued one tile ago; the residual loads issued behind it were waited for in phase C, so — vmcnt
         // retires in order — the DMA has landed for this wave.  The first tile waits explicitly.
+#ifdef USOT_BNECK_VMCNT0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (kit == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __syncthreads();                             // #1: t1(tile) visible; the other slot, t2 and the y half are free
         if (next < p.ntiles) issue_t1(next, slot ^ 1);
         // residual: lane (l15, q) of wave w = channels w*32 + q*8 .. +7 of pixel (row pb, column l15): one 16-byte load per row
@@ -637,6 +650,7 @@ extern "C" int usot_bneck_first_supported(int Cin, int Cmid, int Cout, int Cnext
  * k, wn [64][256]; biases fp32 (b3c = conv3's + the downsample's); y [N][H][W][256], t [N][H][W][64]. */
 extern "C" int usot_bneck_first_lp(void *stream, const usot_bneck_desc *d, int dtype)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     if (!d || !d->x || !d->w1 || !d->w2 || !d->w3c || !d->wn || !d->b1 || !d->b2 || !d->b3c || !d->bn || !d->y || !d->t) return USOT_EINVAL;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
     if (((uintptr_t)d->x | (uintptr_t)d->w1 | (uintptr_t)d->w2 | (uintptr_t)d->w3c | (uintptr_t)d->wn | (uintptr_t)d->b1 |
@@ -691,6 +705,7 @@ extern "C" int usot_bneck_tail_supported(int Cmid, int Cout, int Cnext)
  * d->bn (d->b1 unused); y [N][H][W][256] = relu(conv3(relu(conv2 t1)) + residual), t [N][H][W][Cnext] = relu(conv1'(y)). */
 extern "C" int usot_bneck_tail_lp(void *stream, const usot_bneck_desc *d, int Cnext, int dtype)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     if (!d || !d->x || !d->w1 || !d->w2 || !d->w3c || !d->wn || !d->b2 || !d->b3c || !d->bn || !d->y || !d->t) return USOT_EINVAL;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || (dtype != 0 && dtype != 1) || !usot_bneck_tail_supported(64, 256, Cnext)) return USOT_EINVAL;
     if (((uintptr_t)d->x | (uintptr_t)d->w1 | (uintptr_t)d->w2 | (uintptr_t)d->w3c | (uintptr_t)d->wn |

@@ -11,6 +11,13 @@
 
 static inline int usot_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// The launchers keep per-DEVICE facts in function-local statics: raised dynamic-LDS limits (hipFuncSetAttribute), the address
+// of a __device__ zero page (hipGetSymbolAddress), the CU count.  All of these belong to ONE device; the execution model is
+// one process per GPU (streams.py), so the library binds itself to the first device a launcher runs on and every
+// launcher refuses (USOT_ESTATE) to run on another one - instead of handing device 0's zero page to a kernel on device 1 or
+// skipping the LDS-limit raise there.  Defined in head_ops.hip.
+extern "C" int usot_device_guard(void);
+
 // Running total of the finished k-blocks of an MFMA accumulator (4 floats per lane); see conv_igemm.hip: blocked_mma.
 // USOT_TOT selects its arithmetic (a build-time experiment switch; scripts/tot_variants.py builds and times all of them).
 // Measured on one MI355X box, frame graph replay / mean rms ratio of HIP-vs-float64 to reference-float32-vs-float64 over the

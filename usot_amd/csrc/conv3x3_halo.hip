@@ -208,6 +208,7 @@ extern "C" int usot_conv3x3_halo_supported(int Cin, int Cout) { return Cin == 64
 extern "C" int usot_conv3x3_halo_lp(void *stream, const void *x, const void *w, const float *bias, void *y,
                                     int N, int H, int W, int Cin, int Cout, int act, int dtype)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || (dtype != 0 && dtype != 1) || !usot_conv3x3_halo_supported(Cin, Cout)) return USOT_EINVAL;
     if (act != USOT_ACT_NONE && act != USOT_ACT_RELU) return USOT_EINVAL;
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)y) & 15) return USOT_EINVAL;

@@ -1044,6 +1044,7 @@ extern "C" int usot_conv_bf16_tile_count(void) { return kNumTilesB; }
  * ksplit / nchw / channel-offset outputs are fp32-path features. */
 extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, int out_f32)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     if (dtype != 0 && dtype != 1) return USOT_EINVAL;
     if (!d || !d->x || !d->w || !d->y) return USOT_EINVAL;
     if (d->Cin <= 0 || (d->Cin % BKB) || d->Cout <= 0 || (d->Cout & 3) || d->N <= 0) return USOT_EINVAL;

@@ -1977,6 +1977,7 @@ int fill_params(const usot_conv_desc *d, ConvK &p)
 
 extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int n)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     if (!d || n < 1 || n > 4) return USOT_EINVAL;
     ConvBatch bt;
     bt.n = n;

@@ -220,6 +220,7 @@ __global__ __launch_bounds__(512) void conv_kstream_kernel(const CKStreamK p)
 template <int CIN>
 int ck_launch(void *stream, const CKStreamK &p, int dtype)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     constexpr int CC = CIN / 64;
     constexpr int lds = (CK_S * CK_BN * 8 + (CK_BN / 4 > CC * 8 ? CK_BN / 4 : CC * 8)) * 16;
     static bool raised[2] = {false, false};

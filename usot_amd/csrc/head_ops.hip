@@ -1,6 +1,7 @@
 // Small head-side kernels: Conf_Fusion reduction, Precise RoI Pooling forward, layout
 // permutes at the API edge, and the on-device decode of a frame's response maps.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include "usot_hip.h"
@@ -966,6 +967,16 @@ extern "C" int usot_thin_conv3x3_f32(void *stream, const usot_conv_desc *d, int 
     hipLaunchKernelGGL(thin_conv3x3_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, k);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
+}
+
+extern "C" int usot_device_guard(void)
+{
+    static std::atomic<int> bound{-1};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return USOT_ELAUNCH;
+    int expect = -1;
+    if (bound.compare_exchange_strong(expect, dev)) return USOT_OK;
+    return expect == dev ? USOT_OK : USOT_ESTATE;
 }
 
 extern "C" int usot_abi_version(void) { return 2; }   // 2: usot_conv_desc.w_frag

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(512) void pw_kstream_kernel(const KStreamK p)
 template <int K, int N>
 int ks_launch(void *stream, const KStreamK &p, int dtype)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     constexpr int lds = KS_S * N * 8 * 16 + ((N / 4 > (K / 64) * 8 ? N / 4 : (K / 64) * 8)) * 16;
     static bool raised[2] = {false, false};
     const void *fn = dtype ? (const void *)pw_kstream_kernel<K, N, true> : (const void *)pw_kstream_kernel<K, N, false>;

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(512) void pw_pair_kernel(const PwK p)
 template <int CM, int CO, int CN>
 int pw_launch(hipStream_t s, const PwK &p, int dtype)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     using G16 = PwCfg<CM, CO, CN, true>;
     constexpr int lds = G16::LDS_BYTES;
     static bool raised[2] = {false, false};

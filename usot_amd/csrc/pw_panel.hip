@@ -380,6 +380,7 @@ __global__ __launch_bounds__(512) void pw_panel_kernel(const PanelK p)
 template <int K, int N, int CN, int PB>
 int panel_launch(hipStream_t s, PanelK p, int dtype)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     using C = PanelCfg<K, N, CN, PB>;
     static bool raised[2] = {false, false};
     const void *fn = dtype ? (const void *)pw_panel_kernel<K, N, CN, PB, true> : (const void *)pw_panel_kernel<K, N, CN, PB, false>;

@@ -319,6 +319,7 @@ template <int CM, int CO, int CN, int S = 1> int launch(hipStream_t s, const PwF
 
 template <int CIN, int CM, int CO, int CN> int launch_triple(hipStream_t s, const PwT &q)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     constexpr int NB2 = CN / 16, KS2 = NB2 >= 8 ? 1 : 8 / NB2, KS0 = 8 / (CM / 16);
     constexpr int PSF = ps_floats<CM, KS0>() > ps_floats<CN, KS2>() ? ps_floats<CM, KS0>() : ps_floats<CN, KS2>();
     const size_t lds = (size_t)(16 * (9 * CIN + 4) + 16 * (CM + 4) + 16 * (CO + 4) + PSF) * sizeof(float);
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(512) void pw_single_f32_kernel(const Pw1 p)
 
 template <int K, int N, int S> int launch1(hipStream_t s, const Pw1 &p)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     constexpr int NB = N / 16 / S, KS = NB >= 8 ? 1 : 8 / NB;
     const size_t lds = (size_t)(16 * (K + 4) + (KS > 1 ? (KS - 1) * 16 * (NB * 16 + 4) : 0)) * sizeof(float);
     if (lds > 64 * 1024) {
@@ -507,6 +509,7 @@ __global__ __launch_bounds__(512) void stream_conv3x3_f32_kernel(const PwC p)
 
 template <int CIN, int N, int S> int launch3(hipStream_t s, const PwC &p)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     constexpr int K = 9 * CIN, NB = N / 16 / S, KS = NB >= 8 ? 1 : 8 / NB;
     const size_t lds = (size_t)(16 * (K + 4) + (KS > 1 ? (KS - 1) * 16 * (NB * 16 + 4) : 0)) * sizeof(float);
     static bool raised = false;

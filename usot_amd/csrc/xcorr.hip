@@ -1087,6 +1087,7 @@ extern "C" int usot_groupdw_auto_variant(int total_samples, int OW)
 
 static int groupdw_multi_impl(void *stream, const usot_groupdw_desc *d, int nseg, int out_dtype)
 {
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
     if (!d || nseg < 1 || nseg > 3) return USOT_EINVAL;
     static const int hk[3] = {5, 3, 5}, wk[3] = {5, 5, 3};
     GdwK p;

@@ -1032,6 +1032,9 @@ DEFAULT_OPTIONS = {
     'enc_s_ksplit': None,
     # Session.collect(): wall-clock budget of the result-tag spin before it falls back to 50 us sleeps
     'spin_seconds': 0.004,
+    # low-precision plans: are the crops raw 0..255 pixel values (the range the fp16-arithmetic stem is adequate for)?
+    # 'auto' = decided ONCE per input shape from the first batch (Engine._raw_pixels); True / False = stated by the caller
+    'lp_raw_pixels': 'auto',
 }
 ENV_SWITCHES = {      # environment variable -> (option, parser)
     'USOT_FUSED_TRIPLE_F32': ('fused_triple_f32', lambda v: v == '1'),
@@ -1084,6 +1087,7 @@ class Engine:
         self.lanes = int(lanes) if graphs else 0   # lanes only exist as parallel branches of a captured graph
         self.tuning = load_tuning() if tuning is None else tuning
         self._feat = {}       # (n, size) -> dict(x, xf, h, plan)
+        self._raw_seen = {}   # low-precision plans, 'auto' mode: shape -> were the first batch's crops raw pixels
         self._zenc = {}       # n -> dict(zf, zk, plan)
         self._track = {}      # (b, size, m) -> dict
         self._zk_key = None
@@ -1116,16 +1120,33 @@ class Engine:
         p['plan'].run()
         return p['xf'].permute(0, 3, 1, 2)
 
-    def features_bf16(self, x, dtype=torch.bfloat16):
+    def _raw_pixels(self, x, shape_key, raw_pixels):
+        """Whether a low-precision plan may stage its crops for the fp16-arithmetic stem (inputs in the reference's convention,
+        raw 0..255 pixel values).  Explicit argument > engine option `lp_raw_pixels` (True / False) > 'auto': ONE min / max
+        reduction of the first batch of a shape (two host syncs), remembered for that shape - later batches of the shape are NOT
+        re-checked (that would put two blocking reductions into every call); the resolved value is part of the plan key, so a
+        caller that passes raw_pixels explicitly gets its own plan per input convention."""
+        if raw_pixels is not None:
+            return bool(raw_pixels)
+        opt = self.opt.get('lp_raw_pixels', 'auto')
+        if opt != 'auto':
+            return bool(opt)
+        if shape_key not in self._raw_seen:
+            self._raw_seen[shape_key] = looks_like_raw_pixels(x)
+        return self._raw_seen[shape_key]
+
+    def features_bf16(self, x, dtype=torch.bfloat16, raw_pixels=None):
         """Batched low-precision backbone + neck (config 3): x NCHW fp32 [n,3,s,s] -> NCHW-shaped
-        bf16|fp16 view [n,256,hf,hf] of the NHWC result.  Workspace view: valid until the next call."""
+        bf16|fp16 view [n,256,hf,hf] of the NHWC result.  Workspace view: valid until the next call.
+        raw_pixels: see _raw_pixels (None = the engine option, 'auto' by default = decided by the first batch of this shape)."""
         x = _as_dev_f32(x, self.device)
         n, _, s, _ = x.shape
-        key = ('bf16' if dtype == torch.bfloat16 else 'f16', n, s)
+        raw = self._raw_pixels(x, ('feat', n, s), raw_pixels)
+        key = ('bf16' if dtype == torch.bfloat16 else 'f16', n, s, raw)
         if key not in self._feat:
             bld = Builder(self.W, self.tuning, 0, self.opt)
             xin = bld.buf(n, 3, s, s)
-            xf, h = bld.backbone_bf16(xin, n, s, dtype=dtype, raw_pixels=looks_like_raw_pixels(x))
+            xf, h = bld.backbone_bf16(xin, n, s, dtype=dtype, raw_pixels=raw)
             self._finish(bld.plan)
             self._feat[key] = dict(x=xin, xf=xf, h=h, plan=bld.plan, log=bld.log, p3=bld.p3, lp_bytes=bld.lp_bytes)
         p = self._feat[key]
@@ -1224,7 +1245,7 @@ class Engine:
         cls_mem = p['cls2'][1].clone() if clone else p['cls2'][1]
         return cls, bbox, cls_mem, p['xf'].permute(0, 3, 1, 2)
 
-    def track_mixed(self, x, zf, template_mem, score_mem, dtype=torch.float16, heads_lp=True):
+    def track_mixed(self, x, zf, template_mem, score_mem, dtype=torch.float16, heads_lp=True, raw_pixels=None):
         """BASELINE config 5: low-precision (fp16 | bf16) backbone + neck on MFMA; heads_lp: the big head
         convolutions too (Builder.heads_lp), else every head op in fp32.  The depthwise correlations
         are fp32 either way.  Same returns as track(); batch = independent streams."""
@@ -1233,12 +1254,12 @@ class Engine:
         if self._zk_key != (zf.data_ptr(), zf._version, tuple(zf.shape)) or b not in self._zenc:
             self.set_template(zf)
         m = int(score_mem.shape[1])
-        key = ('mixed', b, size, m, dtype, bool(heads_lp))
+        raw = self._raw_pixels(x, ('mixed', b, size), raw_pixels)
+        key = ('mixed', b, size, m, dtype, bool(heads_lp), raw)
         if key not in self._track:
             bld = Builder(self.W, self.tuning, 0, self.opt)
             xin = bld.buf(b, 3, size, size)
             mem = bld.buf(b * m, 7, 7, 256)
-            raw = looks_like_raw_pixels(x)
             if heads_lp:
                 xl, hf = bld.backbone_bf16(xin, b, size, dtype=dtype, neck_f32=False, raw_pixels=raw)
                 bbox, cls2, S = bld.heads_lp(xl, b, hf, self._zenc[b]['zk'], mem, m, dtype)
@@ -1247,7 +1268,8 @@ class Engine:
                 xf, hf = bld.backbone_bf16(xin, b, size, dtype=dtype, neck_f32=True, raw_pixels=raw)
                 bbox, cls2, S = bld.heads(xf, b, hf, self._zenc[b]['zk'], mem, m)
             self._finish(bld.plan)
-            self._track[key] = dict(x=xin, xf=xf, hf=hf, mem=mem, bbox=bbox, cls2=cls2, S=S, plan=bld.plan, log=bld.log)
+            self._track[key] = dict(x=xin, xf=xf, hf=hf, mem=mem, bbox=bbox, cls2=cls2, S=S, plan=bld.plan, log=bld.log,
+                                    lp_bytes=bld.lp_bytes, f32_bytes=bld.f32_bytes)
         p = self._track[key]
         p['x'].copy_(x)
         p['mem'].copy_(hip.to_nhwc(_as_dev_f32(template_mem, self.device)))
@@ -1450,9 +1472,17 @@ class Session:
         rather than sleeping in hipStreamSynchronize (the PrRoIPool + bank append behind it are
         ordered before the next frame by the stream)."""
         try:
-            return self._collect()
-        finally:
-            self._x_ref = None                      # an in-place crop may be reused from here on (also after a timed-out frame)
+            out = self._collect()
+        except BaseException:
+            # a frame that never published its tag may still be running and reads the in-place crop by ADDRESS: drain the
+            # stream before the reference (the only thing keeping that memory away from the caching allocator) is dropped
+            try:
+                self._stream.synchronize()
+            finally:
+                self._x_ref = None
+            raise
+        self._x_ref = None                          # the tag was observed: the crop may be reused from here on
+        return out
 
     def _collect(self):
         out, tag = self._out_np, self._tag
