@@ -75,7 +75,10 @@ typedef struct usot_conv_desc {
     int32_t w_frag;   /* 1: `w` is in MFMA fragment order (usot_conv_pack_wfrag_f32) — required by, and only valid with, the
                        * weight-streaming tiles (usot_conv_tile_wfrag(tile) == 1); row offsets / group strides of the bank must
                        * be multiples of 16 rows */
-    int32_t reserved0;
+    int32_t defer;    /* with ksplit > 1: 1 = DEFERRED reduction - the launch writes its ksplit partial tiles [ksplit][groups][M][Cout]
+                       * to `ws` (plain stores, no tickets) and applies NEITHER bias NOR activation; `y` is not written.  The consumer
+                       * sums the slabs, adds the bias and activates while it stages its input (usot_pw_pair_desc.t2_parts).  A kernel
+                       * boundary is the synchronisation: no in-launch combine (4-6 us on the tail of a 20 us launch), no second launch */
 } usot_conv_desc;
 
 int usot_conv2d_f32(void *stream, const usot_conv_desc *d);
@@ -143,6 +146,10 @@ typedef struct usot_pw_pair_desc {
     void *y, *t;
     int32_t M, CM, CO, CN, act2;
     void *ws;             /* fp32 form only: usot_pw_pair_f32_ws_floats() zero-initialised floats, or NULL */
+    /* fp32 form only: t2 given as t2_parts > 1 partial sums [t2_parts][M][CM] of the producing convolution (usot_conv_desc.defer);
+     * the kernel stages relu(sum of the parts in order + t2_bias) as its pixel tile.  0 / 1: t2 is the finished map. */
+    int32_t t2_parts, reserved0;
+    const float *t2_bias;
 } usot_pw_pair_desc;
 int usot_pw_pair_lp(void *stream, const usot_pw_pair_desc *d, int dtype);
 int usot_pw_pair_layout(int CM, int CO, int CN, int which, int32_t *row, int32_t *k0);   /* which: 0 = w3, 1 = w1 */

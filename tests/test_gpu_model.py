@@ -311,10 +311,13 @@ def test_every_fixture_within_1p5x_of_the_references_own_float32_error(family, c
 # every switch of usot_amd.engine.DEFAULT_OPTIONS that changes which kernels a frame uses, flipped away from its default
 OPTION_VARIANTS = [{'fused_f32_sliced': False}, {'conf_tail_split': None}, {'conf_tail_split': (2, 3)}, {'fused_triple_f32': False}, {'stream_1x1': False}, {'stream_3x3': False},
                    {'fused_pointwise_f32': set()},
-                   {'stream_3x3_shapes': {(128, 128), (256, 256)}}, {'stream_1x1_shapes': {(256, 1024), (128, 512), (1024, 256), (512, 128)}}]
+                   {'stream_3x3_shapes': {(128, 128), (256, 256)}}, {'stream_1x1_shapes': {(256, 1024), (128, 512), (1024, 256), (512, 128)}},
+                   # deferred split-K reduction of layer3's conv2 (summed by the following fused pair): on / off / another split
+                   {'defer_split_f32': {}}, {'defer_split_f32': {(961, 256, 2304): (57, 4), (1089, 256, 2304): (57, 4)}},
+                   {'defer_split_f32': {(961, 256, 2304): (55, 2), (1089, 256, 2304): (55, 3)}}]
 
 
-@pytest.mark.parametrize('variant', OPTION_VARIANTS, ids=lambda v: ','.join(sorted(v)))
+@pytest.mark.parametrize('variant', OPTION_VARIANTS, ids=lambda v: ','.join('%s=%s' % (k, str(v[k])[:40].replace(' ', '')) for k in sorted(v)))
 def test_engine_option_variants_keep_parity(variant, capsys):
     """Every lowering switch (engine.DEFAULT_OPTIONS; env names in engine.ENV_SWITCHES) is a configuration of the product
     path: each one, flipped, must pass the same acceptance rule as the default (f64_gate: HIP-vs-float64 within 1.5 x the

@@ -97,6 +97,55 @@ def test_conv_splitk(ksplit):
     assert rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize('tile,ks', [(57, 4), (55, 2), (53, 3), (38, 4)])
+def test_conv_deferred_reduction_feeds_the_fused_pair(tile, ks):
+    """usot_conv_desc.defer: a split-K convolution that writes its partial tiles and stops (no bias, no activation, no
+    combine), and the fused fp32 pointwise pair that sums them - in part order, + bias, ReLU - while it stages its pixel tile
+    (usot_pw_pair_desc.t2_parts).  (1) the slabs sum to the convolution; (2) the pair on the slabs is BIT-identical to the pair on
+    the tile torch builds from the same slabs in the same order; layer3's geometry (31 x 31, 256 -> 256, dilation 2)."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(500 + tile)
+    N, H, Cin, Cout, CO, CN = 1, 31, 256, 256, 1024, 256
+    x = torch.randn(N, Cin, H, H, generator=g).relu()
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 48
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, None, 1, 2, 2)
+    xd, wd, bd = x.permute(0, 2, 3, 1).contiguous().to(DEV), pack_w(w).to(DEV), b.to(DEV)
+    M = N * H * H
+    ws = torch.zeros(ks * M * Cout + 4096, device=DEV)
+    d = hip.conv_desc(xd.data_ptr(), wd.data_ptr(), None, xd.data_ptr(), N=N, H=H, W=H, Cin=Cin, OH=H, OW=H, Cout=Cout, KH=3, KW=3,
+                      pad=(2, 2), dil=(2, 2), tile=tile, ksplit=ks, ws=ws.data_ptr(), defer=1)
+    hip.check(hip.lib().usot_conv2d_f32(hip.stream(), C.byref(d)), 'conv (deferred)')
+    slabs = ws[:ks * M * Cout].view(ks, M, Cout)
+    got = slabs.sum(0).view(N, H, H, Cout).permute(0, 3, 1, 2).cpu()
+    assert rel_err(got.numpy(), ref.numpy()) < 2e-5
+    assert torch.equal(xd.cpu(), x.permute(0, 2, 3, 1).contiguous())          # y (aliased to x here) is not written
+    d.ksplit = 1                                                               # defer without a split is refused
+    assert hip.lib().usot_conv2d_f32(hip.stream(), C.byref(d)) != 0
+    # the pair: conv3 256 -> 1024 + residual + ReLU, conv1 1024 -> 256 + ReLU
+    w3 = torch.randn(CO, Cout, generator=g) / 16; b3 = torch.randn(CO, generator=g) * 0.1
+    w1 = torch.randn(CN, CO, generator=g) / 32; b1 = torch.randn(CN, generator=g) * 0.1
+    res = torch.randn(M, CO, generator=g).relu().to(DEV)
+    w3p, w1p = hip.pw_pair_f32_pack(w3.to(DEV)), hip.pw_pair_f32_pack(w1.to(DEV))
+    b3d, b1d = b3.to(DEV), b1.to(DEV)
+    outs = []
+    t2_sum = slabs[0].clone()
+    for q in range(1, ks):
+        t2_sum += slabs[q]                                                     # the kernel's order: part 0, 1, ... then the bias
+    t2_sum = (t2_sum + bd).relu().contiguous()
+    for t2, parts in ((slabs, ks), (t2_sum, 0)):
+        y = torch.empty(M, CO, device=DEV); t = torch.empty(M, CN, device=DEV)
+        wsp = hip.pw_pair_f32_ws(M, Cout, CO, CN, DEV)
+        pd = hip.pw_pair_desc(t2.data_ptr(), w3p.data_ptr(), b3d.data_ptr(), res.data_ptr(), y.data_ptr(), w1p.data_ptr(), b1d.data_ptr(),
+                              t.data_ptr(), M, Cout, CO, CN, hip.ACT_RELU, wsp.data_ptr() if wsp is not None else None,
+                              t2_parts=parts, t2_bias=bd.data_ptr() if parts else None)
+        hip.check(hip.lib().usot_pw_pair_f32(hip.stream(), C.byref(pd)), 'pw_pair_f32')
+        outs.append((y.cpu(), t.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    y_ref = (t2_sum.cpu().double() @ w3.double().t() + b3.double() + res.cpu().double()).relu()
+    assert rel_err(outs[0][0].numpy(), y_ref.numpy()) < 2e-5
+
+
 def test_conv_activations():
     g = torch.Generator().manual_seed(6)
     x = torch.randn(1, 64, 9, 9, generator=g)

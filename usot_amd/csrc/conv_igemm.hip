@@ -1957,7 +1957,8 @@ int fill_params(const usot_conv_desc *d, ConvK &p)
     p.groups = d->groups;
     p.x_gs = d->x_gs; p.w_gs = d->w_gs; p.b_gs = d->b_gs; p.y_gs = d->y_gs; p.r_gs = d->r_gs;
     p.ksplit = ksplit;
-    p.combine = 1;
+    if (d->defer && ksplit < 2) return USOT_EINVAL;
+    p.combine = d->defer ? 0 : 1;            // deferred reduction: the slabs ARE the result (plain stores, no tickets)
     p.P = d->OH * d->OW;
     p.M = d->N * p.P;
     p.K = d->KH * d->KW * d->Cin;

@@ -53,6 +53,8 @@ struct PwF {
     const float *t2, *w3p, *b3, *res, *w1p, *b1;
     float *y, *t, *ws;
     int M, act2;
+    int parts = 0;                 // > 1: t2 = `parts` partial sums [parts][M][CM] of the producing conv (usot_conv_desc.defer)
+    const float *tbias = nullptr;  //      ... staged as relu(sum in part order + tbias)
 };
 
 // acc[u] (u < CBW) = sum over rounds [r0, r0 + RS) of W fragment (cb0 + u, r) x the B operand rows in LDS.
@@ -225,11 +227,31 @@ __global__ __launch_bounds__(512) void pw_pair_f32_kernel(const PwF p)
     const int pt = S > 1 ? (int)blockIdx.x / S : (int)blockIdx.x, sl = S > 1 ? (int)blockIdx.x % S : 0;
     const int bm0 = pt * BM;
     // pixel tile -> LDS (rows past M are zero)
-    for (int i = tid; i < BM * (CM / 4); i += NW * 64) {
-        const int row = i / (CM / 4), c4 = i - row * (CM / 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (bm0 + row < p.M) v = *(const f32x4 *)(p.t2 + (long)(bm0 + row) * CM + c4 * 4);
-        *(f32x4 *)(Xs + row * XP + c4 * 4) = v;
+    if (p.parts > 1) {
+        // deferred split-K reduction of the producing convolution: the partial tiles are summed HERE, in part order, bias and
+        // ReLU applied, while the pixel tile is staged - the producer's launch ends on its k-loop (no ticket, no combine, no
+        // reduction launch) and every slice of this tile does the same sum on the same values (bit-identical tiles)
+        const long slab = (long)p.M * CM;
+        for (int i = tid; i < BM * (CM / 4); i += NW * 64) {
+            const int row = i / (CM / 4), c4 = i - row * (CM / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (bm0 + row < p.M) {
+                const float *src = p.t2 + (long)(bm0 + row) * CM + c4 * 4;
+                v = *(const f32x4 *)src;
+                for (int q = 1; q < p.parts; ++q) v += *(const f32x4 *)(src + q * slab);
+                v += *(const f32x4 *)(p.tbias + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *(f32x4 *)(Xs + row * XP + c4 * 4) = v;
+        }
+    } else {
+        for (int i = tid; i < BM * (CM / 4); i += NW * 64) {
+            const int row = i / (CM / 4), c4 = i - row * (CM / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (bm0 + row < p.M) v = *(const f32x4 *)(p.t2 + (long)(bm0 + row) * CM + c4 * 4);
+            *(f32x4 *)(Xs + row * XP + c4 * 4) = v;
+        }
     }
     __syncthreads();
     pair_tail<CM, COT, CN, S>(p, Xs, Ys, Ps, pt, sl);
@@ -546,8 +568,11 @@ extern "C" int usot_pw_pair_f32(void *stream, const usot_pw_pair_desc *d)
     const uintptr_t al = (uintptr_t)d->t2 | (uintptr_t)d->w3p | (uintptr_t)d->b3 | (uintptr_t)d->res | (uintptr_t)d->w1 |
                          (uintptr_t)d->b1 | (uintptr_t)d->y | (uintptr_t)d->t | (uintptr_t)d->ws;
     if (al & 15) return USOT_EINVAL;
-    const PwF p{(const float *)d->t2, (const float *)d->w3p, d->b3, (const float *)d->res, (const float *)d->w1, d->b1,
-                (float *)d->y, (float *)d->t, (float *)d->ws, d->M, d->act2};
+    if (d->t2_parts > 1 && (!d->t2_bias || ((uintptr_t)d->t2_bias & 15) || d->t2_parts > 16)) return USOT_EINVAL;
+    PwF p{(const float *)d->t2, (const float *)d->w3p, d->b3, (const float *)d->res, (const float *)d->w1, d->b1,
+          (float *)d->y, (float *)d->t, (float *)d->ws, d->M, d->act2};
+    p.parts = d->t2_parts > 1 ? d->t2_parts : 0;
+    p.tbias = d->t2_bias;
     hipStream_t s = (hipStream_t)stream;
     const bool sliced = slices(d->M, d->CM, d->CN) > 1 && d->ws;          /* no workspace: the unsliced form */
     if (d->CM == 64 && d->CO == 256 && d->CN == 64) return launch<64, 256, 64>(s, p);

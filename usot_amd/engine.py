@@ -319,6 +319,23 @@ class Builder:
         self.geoms.append(geom)
         return y, oh, ow
 
+    def conv_deferred(self, name, pc, x, n, h, w, tile, ks):
+        """A convolution whose split-K reduction is DEFERRED to its consumer (usot_conv_desc.defer): one launch writes the `ks`
+        partial tiles, no bias, no activation, no combine.  Returns (slabs [ks, m, cout], oh, ow); the consumer sums them, adds
+        pc.b and activates while it stages its input (pw_pair_f32(t2_parts=ks, t2_bias=pc.b))."""
+        d, _, oh, ow, log, geom = self.conv_desc(name, pc, x, n, h, w, tile=tile, force_ks=ks, y=x)    # y is not written
+        if d.ksplit != ks or d.w_frag:
+            raise hip.HipError('conv_deferred %s: tile %d cannot split k %d ways' % (name, tile, ks))
+        m = n * oh * ow
+        d.defer, d.act, d.bias, d.res = 1, ACT_NONE, None, None
+        # the workspace conv_desc allocated is the last buffer it kept before x / w / b: find it by pointer
+        slabs = next(t for t in reversed(self.plan.keep) if isinstance(t, torch.Tensor) and t.data_ptr() == d.ws)
+        hip.check(hip.lib().usot_plan_add_conv(self.plan.h, C.byref(d)), 'plan_add_conv(deferred) ' + name)
+        self.log.append(log)
+        self.f32_bytes.append(4 * (n * h * w * pc.cin + pc.cout * pc.kh * pc.kw * pc.cin + ks * m * pc.cout))
+        self.geoms.append(geom)
+        return slabs[:ks * m * pc.cout].view(ks, m, pc.cout), oh, ow
+
     @staticmethod
     def _conv_bytes(d):
         """Algorithmic HBM bytes of one fp32 convolution: input map, filter bank, bias, result (+ residual), once each."""
@@ -427,6 +444,16 @@ class Builder:
                     and hip.lib().usot_pw_triple_f32_supported(c2.cin, c3.cin, c3.cout, nxt.cout)):
                 cur, t1_fused = self.pw_triple_f32('b%d.conv2+' % bi + nm, c2, c3, nxt, t1, sc, n, h, act2=act2)
             else:
+                dk = (m2, c2.cout, c2.kh * c2.kw * c2.cin)
+                dfr = O['defer_split_f32'].get(dk) if (fuse and c2.kh == 3) else None
+                if dfr:
+                    # conv2's split-K reduction rides in the pair's tile staging (DEFAULT_OPTIONS: defer_split_f32)
+                    t2, _, _ = self.conv_deferred('b%d.conv2' % bi, c2, t1, n, h, h, tile=dfr[0], ks=dfr[1])
+                    cur, t1_fused = self.pw_pair_f32(nm, c3, nxt, t2, sc, n, h2, act2=act2, t2_parts=dfr[1], t2_bias=c2.b)
+                    h = h2
+                    if bi in (2, 6, 12):
+                        stages.append(cur)
+                    continue
                 t2, _, _ = self.conv3x3('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU)
                 if ds is not None and self.lanes >= 3:
                     self.join(1)
@@ -585,9 +612,10 @@ class Builder:
         self.lp_bytes.append(2 * (m * (c2.cin + 2 * c3.cout + nxt.cout) + w2.numel() + w3.numel() + wn.numel()))
         return y, t
 
-    def pw_pair_f32(self, name, c3, nxt, t2, res, n, h, act2=ACT_RELU):
+    def pw_pair_f32(self, name, c3, nxt, t2, res, n, h, act2=ACT_RELU, t2_parts=0, t2_bias=None):
         """fp32: conv3 + residual + ReLU and the next block's conv1 in ONE launch (csrc/smallm_f32.hip).
-        Returns (y [n,h,h,c3.cout], t [n,h,h,nxt.cout])."""
+        Returns (y [n,h,h,c3.cout], t [n,h,h,nxt.cout]).  t2_parts > 1: t2 holds that many partial sums of the producing
+        convolution (conv_deferred); the kernel stages relu(sum + t2_bias)."""
         m = n * h * h
         y = self.buf(n, h, h, c3.cout)
         t = self.buf(n, h, h, nxt.cout)
@@ -598,9 +626,10 @@ class Builder:
         ws = hip.pw_pair_f32_ws(m, c3.cin, c3.cout, nxt.cout, self.dev) if self.opt['fused_f32_sliced'] else None
         d = hip.pw_pair_desc(t2.data_ptr(), w3p.data_ptr(), c3.b.data_ptr(), res.data_ptr(), y.data_ptr(), w1p.data_ptr(),
                              nxt.b.data_ptr(), t.data_ptr(), m, c3.cin, c3.cout, nxt.cout, act2,
-                             ws.data_ptr() if ws is not None else None)
+                             ws.data_ptr() if ws is not None else None,
+                             t2_parts=t2_parts, t2_bias=t2_bias.data_ptr() if t2_bias is not None else None)
         hip.check(hip.lib().usot_plan_add_pw_pair(self.plan.h, C.byref(d), 2), 'plan_add_pw_pair(f32) ' + name)
-        self.plan.keep += [t2, res, w3p, w1p, c3.b, nxt.b, ws]
+        self.plan.keep += [t2, res, w3p, w1p, c3.b, nxt.b, ws, t2_bias]
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
         self.f32_bytes.append(4 * (m * (c3.cin + 2 * c3.cout + nxt.cout) + c3.cout * c3.cin + nxt.cout * c3.cout))
         return y, t
@@ -1035,6 +1064,14 @@ DEFAULT_OPTIONS = {
     # low-precision plans: are the crops raw 0..255 pixel values (the range the fp16-arithmetic stem is adequate for)?
     # 'auto' = decided ONCE per input shape from the first batch (Engine._raw_pixels); True / False = stated by the caller
     'lp_raw_pixels': 'auto',
+    # {(M, Cout, K): (tile, ksplit)} of the 3x3 convolutions in front of a fused fp32 pointwise pair whose split-K reduction is
+    # DEFERRED to that pair (csrc/smallm_f32.hip sums the partial tiles, adds the bias and applies the ReLU while it stages its
+    # pixel tile): the convolution's launch ends on its k-loop - no ticket combine (4-6 us on the tail of a 20 us launch), no
+    # reduction launch - so layer3's conv2 (M = 961: too few 32 x 64 / 64 x 64 tiles to fill 256 CUs unsplit) can run on tiles
+    # that move fewer L2 bytes than the 32 x 32 ones.  Same-process A/B of the frame graph (scripts/ks_ab.py, two boxes): layer3's six
+    # conv2 (32 x 64, ks 2) 858-871 -> 843-845 us, + layer2.0's conv2 (32 x 32, ks 2, was ks 2 with the in-launch combine) -> 838;
+    # 64 x 64 tiles with ks 4 are SLOWER (862-868).  {} = every reduction inside its own launch
+    'defer_split_f32': {(961, 256, 2304): (55, 2), (1089, 256, 2304): (55, 2), (961, 128, 1152): (53, 2), (1089, 128, 1152): (53, 2)},
 }
 ENV_SWITCHES = {      # environment variable -> (option, parser)
     'USOT_FUSED_TRIPLE_F32': ('fused_triple_f32', lambda v: v == '1'),

@@ -50,7 +50,7 @@ class ConvDesc(C.Structure):
                 ('groups', C.c_int32),
                 ('x_gs', C.c_int64), ('w_gs', C.c_int64), ('b_gs', C.c_int64), ('y_gs', C.c_int64),
                 ('r_gs', C.c_int64),
-                ('ksplit', C.c_int32), ('tile', C.c_int32), ('w_frag', C.c_int32), ('reserved0', C.c_int32)]
+                ('ksplit', C.c_int32), ('tile', C.c_int32), ('w_frag', C.c_int32), ('defer', C.c_int32)]
 
 
 class GroupDWDesc(C.Structure):
@@ -67,7 +67,7 @@ class PwPairDesc(C.Structure):
     _fields_ = [('t2', C.c_void_p), ('w3p', C.c_void_p), ('res', C.c_void_p), ('w1', C.c_void_p),
                 ('b3', C.c_void_p), ('b1', C.c_void_p), ('y', C.c_void_p), ('t', C.c_void_p),
                 ('M', C.c_int32), ('CM', C.c_int32), ('CO', C.c_int32), ('CN', C.c_int32), ('act2', C.c_int32),
-                ('ws', C.c_void_p)]
+                ('ws', C.c_void_p), ('t2_parts', C.c_int32), ('reserved0', C.c_int32), ('t2_bias', C.c_void_p)]
 
 
 class BneckDesc(C.Structure):
@@ -287,7 +287,7 @@ def tile_table():
 def conv_desc(x, w, bias, y, *, N, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, pad=(0, 0), dil=(1, 1),
               res=None, act=ACT_NONE, act2=ACT_NONE, act_split=0, y_cstride=0, y_coff=0,
               res_cstride=0, res_coff=0, y_nchw=0, groups=1, x_gs=0, w_gs=0, b_gs=0, y_gs=0, r_gs=0,
-              ksplit=1, tile=0, ws=None, w_frag=0):
+              ksplit=1, tile=0, ws=None, w_frag=0, defer=0):
     d = ConvDesc()
     d.x, d.w, d.bias, d.res, d.y, d.ws = (x, w, bias or None, res or None, y, ws or None)
     d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout = N, H, W, Cin, OH, OW, Cout
@@ -297,7 +297,7 @@ def conv_desc(x, w, bias, y, *, N, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, pa
     d.act, d.act2, d.act_split = act, act2, act_split
     d.groups = groups
     d.x_gs, d.w_gs, d.b_gs, d.y_gs, d.r_gs = x_gs, w_gs, b_gs, y_gs, r_gs
-    d.ksplit, d.tile, d.w_frag = ksplit, tile, w_frag
+    d.ksplit, d.tile, d.w_frag, d.defer = ksplit, tile, w_frag, defer
     return d
 
 
@@ -630,11 +630,12 @@ def pw_pair_supported(cm, co, cn):
     return bool(lib().usot_pw_pair_supported(int(cm), int(co), int(cn)))
 
 
-def pw_pair_desc(t2, w3p, b3, res, y, w1, b1, t, M, CM, CO, CN, act2, ws=None):
+def pw_pair_desc(t2, w3p, b3, res, y, w1, b1, t, M, CM, CO, CN, act2, ws=None, t2_parts=0, t2_bias=None):
     d = PwPairDesc()
     d.t2, d.w3p, d.res, d.w1, d.b3, d.b1, d.y, d.t = t2, w3p, res, w1, b3, b1, y, t
     d.M, d.CM, d.CO, d.CN, d.act2 = M, CM, CO, CN, act2
     d.ws = ws
+    d.t2_parts, d.t2_bias = t2_parts, t2_bias
     return d
 
 
