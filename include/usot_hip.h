@@ -101,6 +101,11 @@ int usot_conv_tile_wfrag(int tile);                            /* 1: the tile st
 /* weight-stationary tiles (filters held in registers, k split over the 8 waves of a workgroup) serve ONE K each: returns it
  * (0: the tile takes any K); *kpanel = the multiple Cin must have (128 / 256).  They also need Cout % 32 == 0, ksplit == 1. */
 int usot_conv_tile_kreq(int tile, int *kpanel);
+/* persistent stream-K tiles (conv_igemm_f32_v3p): the launch is ONE resident set of workgroups that share the (tile, k-tile)
+ * units of all its problems evenly; shares that end inside a tile meet through write-through slabs and per-wave tickets in
+ * d[0].ws (usot_conv_streamk_ws_floats floats, zero before first use).  ksplit must be 1. */
+int usot_conv_tile_streamk(int tile);
+int64_t usot_conv_streamk_ws_floats(const usot_conv_desc *d, int n, int tile);
 /* filter bank [Cout][K] (K % 64 == 0) -> ceil(Cout/16)*16*K floats in fragment order
  * [16-row block][k-tile of 64][round of 16 k][lane][4 k]; rows past Cout zero.  One launch, any stream. */
 int usot_conv_pack_wfrag_f32(void *stream, const float *w, float *wf, int Cout, int K);

@@ -146,6 +146,45 @@ def test_conv_deferred_reduction_feeds_the_fused_pair(tile, ks):
     assert rel_err(outs[0][0].numpy(), y_ref.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize('tile', [72, 73, 76])
+def test_conv_streamk_batch_of_problems(tile):
+    """Persistent stream-K tiles (conv_igemm_f32_v3p): several problems of different geometry in ONE launch whose workgroups share
+    the (tile, k-tile) units evenly - shares end inside tiles, so the slab / per-wave ticket combine runs - against torch, twice
+    (the tickets must be back at zero), with residual + ReLU on one problem and groups on another."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(700 + tile)
+    probs = [(2, 256, 25, 25, 512, (1, 1), (1, 1), 1), (1, 256, 31, 31, 256, (0, 0), (2, 1), 1), (1, 256, 27, 29, 128, (2, 2), (2, 2), 3)]
+    descs, refs, outs, keep = [], [], [], []
+    for N, Cin, H, W, Cout, pad, dil, G in probs:
+        x = torch.randn(G, N, Cin, H, W, generator=g)
+        w = torch.randn(G * Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+        b = torch.randn(G * Cout, generator=g)
+        ref = torch.stack([F.conv2d(x[q], w[q * Cout:(q + 1) * Cout], b[q * Cout:(q + 1) * Cout], 1, pad, dil) for q in range(G)])
+        OH, OW = ref.shape[-2:]
+        res = torch.randn(G, N, OH, OW, Cout, generator=g) if G == 1 and Cout == 512 else None
+        if res is not None:
+            ref = F.relu(ref + res.permute(0, 1, 4, 2, 3))
+        xd, wd, bd = x.permute(0, 1, 3, 4, 2).contiguous().to(DEV), pack_w(w).to(DEV), b.to(DEV)
+        y = torch.full((G, N, OH, OW, Cout), float('nan'), device=DEV)
+        rd = res.to(DEV) if res is not None else None
+        descs.append(hip.conv_desc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), N=N, H=H, W=W, Cin=Cin, OH=OH, OW=OW, Cout=Cout,
+                                   KH=3, KW=3, pad=pad, dil=dil, res=rd.data_ptr() if rd is not None else None,
+                                   act=hip.ACT_RELU if rd is not None else hip.ACT_NONE, tile=tile, groups=G,
+                                   x_gs=N * H * W * Cin, w_gs=Cout * 9 * Cin, b_gs=Cout, y_gs=N * OH * OW * Cout))
+        refs.append(ref); outs.append(y); keep += [xd, wd, bd, rd]
+    ws = hip.streamk_ws(descs, tile, DEV)
+    arr = (hip.ConvDesc * len(descs))(*descs)
+    for rep in range(2):
+        for y in outs:
+            y.fill_(float('nan'))
+        hip.check(hip.lib().usot_conv2d_batch_f32(hip.stream(), arr, len(descs)), 'conv batch (stream-K)')
+        for y, ref in zip(outs, refs):
+            assert rel_err(y.permute(0, 1, 4, 2, 3).cpu().numpy(), ref.numpy()) < 2e-5, rep
+    assert int(ws.numel()) > 0
+    tickets = ws[-4 * 64:]                      # (the tail of the workspace is ticket words: all back at zero)
+    assert float(tickets.abs().max()) == 0.0
+
+
 def test_conv_activations():
     g = torch.Generator().manual_seed(6)
     x = torch.randn(1, 64, 9, 9, generator=g)

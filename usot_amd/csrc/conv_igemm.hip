@@ -1084,6 +1084,314 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
 }
 
 // ---------------------------------------------------------------------------------------
+// v3p: v3 as a PERSISTENT stream-K launch (whole-chip rounds).
+//
+// The launch's work is the list of (tile, k-tile) UNITS of all its problems - N-strip-major, so that a contiguous range of units
+// is one filter strip x consecutive pixel tiles.  G resident workgroups (one or two per CU, never more than fit) each take
+// a contiguous share of U / G units (XCD x takes the x-th eighth of the list: one filter strip per L2) and walk it SEGMENT by
+// segment (a segment = the part of one tile inside the share).  A segment that covers its tile's whole k range ends in v3's
+// epilogue.  A partial segment stores the wave's accumulators - in register order, 1 KiB per store, write-through (sc1) - to the
+// tile's slab [part][wave][block][lane], drains, and takes a ticket PER CONSUMER WAVE; the wave that finds the other parts
+// already there (the last to arrive) reads them back, adds them IN PART ORDER (= k order: the same bits whoever is last) and
+// runs the epilogue.  No workgroup barrier, no spin, nothing that depends on placement or dispatch order (Guideline 16, recipe
+// R1); tickets return to zero.  Producer waves never see any of this: they run ahead into the next segment's first k-tiles
+// while the consumers finish the previous one - the launch pays ONE start-up and one drain instead of one per tile, and ends
+// within one k-tile of U / G for every workgroup, which is what lets the 64 x 64 tile (2/64 of M N K instead of 3/64 or 4/64
+// L2 bytes) be used where 552 tiles over 256 slots would otherwise quantise to three rounds.
+struct SkInfo {                   // per problem: where its units start and how its tiles are numbered
+    int ubase[5];                 // first unit of problem i (ubase[n] = U)
+    int tbase[5];                 // first slab / ticket index of problem i
+    int G;                        // workgroups of the launch
+    int pmax;                     // parts a slab has room for
+};
+
+template <int BM, int BN, int WM, int WN, int D, int NPW, int BK = 64>
+__global__ __launch_bounds__(256 + 64 * NPW, (BM * BN <= 32 * 64) ? (4 + NPW) / 2 : 1) void conv_igemm_f32_v3p(const ConvBatch bt, const SkInfo sk)
+{
+    static_assert(WM * WN == 4, "4 consumer wavefronts");
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int LD = BK + 4;
+    constexpr int CPR = BK / 4;
+    constexpr int NPT = 64 * NPW;
+    constexpr int RPP = NPT / CPR;
+    constexpr int XI = (BM + RPP - 1) / RPP, WI = (BN + RPP - 1) / RPP;
+    constexpr int NR = BK / 16;
+    constexpr int STAGE = (BM + BN) * LD;
+    constexpr int NBLK = TM * TN;                 // 16 x 16 blocks of a consumer wave
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const bool producer = threadIdx.x >= 256;
+    const int tid = producer ? (int)threadIdx.x - 256 : (int)threadIdx.x;
+    const int U = sk.ubase[bt.n];
+    // XCD x (blocks b with b % 8 == x) walks the x-th contiguous eighth of the unit list
+    const int wi = xcd_remap((int)blockIdx.x, sk.G);
+    const int u_begin = (int)((long)U * wi / sk.G), u_end = (int)((long)U * (wi + 1) / sk.G);
+    auto owner = [&](long u) { return (int)(((u + 1) * sk.G - 1) / U); };      // index (wi) of the workgroup whose share holds unit u
+
+    auto each_buffer = [&](auto f) {
+        [&]<int... Is>(std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }(std::make_integer_sequence<int, D>{});
+    };
+
+    int u = u_begin;
+    while (u < u_end) {
+        // ---- decode the segment [u, u1): problem, tile, k range (wave-uniform; both wave kinds compute the same)
+        int pi = 0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (q < bt.n && u >= sk.ubase[q]) pi = q;
+        const ConvK &p = bt.p[pi];
+        const int KT = p.K / BK;
+        const int cch = p.Cin / BK;
+        const int local = u - sk.ubase[pi];
+        const int tl = local / KT, kt0 = local - tl * KT;            // tile of the problem (groups x N-strips x M-tiles), first k-tile
+        const int ut0 = sk.ubase[pi] + tl * KT;                       // the tile's first unit
+        const int u1 = min(u_end, ut0 + KT);
+        const int nt = u1 - u;
+        const int tiles = p.MT * p.NT;
+        const int g = tl / tiles, t0 = tl - g * tiles;
+        const int bn0 = (t0 / p.MT) * BN, bm0 = (t0 % p.MT) * BM;
+        u = u1;
+
+        if (producer) {
+            const float *__restrict__ xg = p.x + (long)g * p.x_gs;
+            const float *__restrict__ wg = p.w + (long)g * p.w_gs;
+            const int lr = tid / CPR, kc = tid % CPR;
+            int x_ih0[XI], x_iw0[XI];
+            long x_nb[XI];
+            bool x_ok[XI];
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int row = lr + RPP * i;
+                const int m = bm0 + row;
+                x_ok[i] = (row < BM) && (m < p.M);
+                const int mm = x_ok[i] ? m : 0;
+                const int n = mm / p.P, pix = mm - n * p.P;
+                const int oh = pix / p.OW, ow = pix - oh * p.OW;
+                x_ih0[i] = oh * p.stride - p.pad_h;
+                x_iw0[i] = ow * p.stride - p.pad_w;
+                x_nb[i] = (long)n * p.H * p.W * p.Cin + kc * 4;
+            }
+            const float *wp[WI];
+#pragma unroll
+            for (int i = 0; i < WI; ++i) {
+                const int row = lr + RPP * i;
+                const int co = bn0 + row;
+                wp[i] = wg + (long)((row < BN && co < p.Cout) ? co : 0) * p.K + kc * 4 + (long)kt0 * BK;
+            }
+            f32x4 xr[D][XI], wr[D][WI];
+            bool xz[D][XI];
+            const float *xp[XI];
+            bool xin[XI];
+            int cur_tap = kt0 / cch, cur_cc = kt0 - cur_tap * cch;
+            auto set_tap = [&](int tap) {
+                const int kh = tap / p.KW, kw = tap - kh * p.KW;
+                const int dh = kh * p.dil_h, dw = kw * p.dil_w;
+#pragma unroll
+                for (int i = 0; i < XI; ++i) {
+                    const int ih = x_ih0[i] + dh, iw = x_iw0[i] + dw;
+                    xin[i] = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                    xp[i] = xg + x_nb[i] + ((long)ih * p.W + iw) * p.Cin;
+                }
+            };
+            set_tap(cur_tap);
+            auto load_tile = [&](auto dc, bool advance) {
+                constexpr int d = decltype(dc)::value;
+                const int c0 = cur_cc * BK;
+#pragma unroll
+                for (int i = 0; i < XI; ++i) {
+                    xr[d][i] = *(const f32x4 *)(xin[i] ? xp[i] + c0 : xg + kc * 4);
+                    xz[d][i] = xin[i];
+                }
+#pragma unroll
+                for (int i = 0; i < WI; ++i) {
+                    wr[d][i] = *(const f32x4 *)wp[i];
+                    wp[i] += advance ? BK : 0;
+                }
+                if (advance && ++cur_cc == cch) {
+                    cur_cc = 0;
+                    set_tap(++cur_tap);
+                }
+            };
+            auto store_tile = [&](auto dc, int st) {
+                constexpr int d = decltype(dc)::value;
+                float *sX = smem + st * STAGE, *sW = sX + BM * LD;
+#pragma unroll
+                for (int i = 0; i < XI; ++i)
+                    if (BM % RPP == 0 || lr + RPP * i < BM)
+                        *(f32x4 *)(sX + (lr + RPP * i) * LD + kc * 4) = xz[d][i] ? xr[d][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < WI; ++i)
+                    if (BN % RPP == 0 || lr + RPP * i < BN) *(f32x4 *)(sW + (lr + RPP * i) * LD + kc * 4) = wr[d][i];
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, D >= 2 ? 1 : 0>;
+            int lt = 0;
+            auto load_next = [&](auto dc) { load_tile(dc, lt + 1 < nt); ++lt; };
+            // the previous segment's last barrier has passed: every consumer has finished reading every stage
+            load_next(I0{});
+            load_next(I1{});
+            store_tile(I0{}, 0);
+            if (nt > 1) store_tile(I1{}, 1);
+            each_buffer([&](auto dc) { load_next(dc); });
+            __syncthreads();
+            int st2 = 2;
+            auto step = [&](auto dc, int t) {
+                if (t + 2 < nt) store_tile(dc, st2);
+                load_next(dc);
+                st2 = st2 == 2 ? 0 : st2 + 1;
+                __syncthreads();
+            };
+            int t = 0;
+            for (; t + D <= nt; t += D) each_buffer([&](auto dc) { step(dc, t + decltype(dc)::value); });
+            each_buffer([&](auto dc) {
+                if (t < nt) { step(dc, t); ++t; }
+            });
+            continue;                                   // next segment: its loads are issued while the consumers finish this one
+        }
+
+        // ---------------- consumers
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wm = wave % WM, wn = wave / WM;
+        const int l15 = lane & 15, quad = lane >> 4;
+        const int fx_off = (wm * TM * 16 + l15) * LD + quad * 4;
+        const int fw_off = BM * LD + (wn * TN * 16 + l15) * LD + quad * 4;
+        f32x4 fw[2][TN], fx[2][TM];
+        auto read_frags = [&](int st, int r, int slot) {
+            const float *base = smem + st * STAGE + r * 16;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fw[slot][i] = *(const f32x4 *)(base + fw_off + i * 16 * LD);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) fx[slot][j] = *(const f32x4 *)(base + fx_off + j * 16 * LD);
+        };
+        f32x4 acc[TN][TM];
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+        BlockTotal tot[TN][TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[i][j].clear(); }
+        auto flush = [&]() {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) tot[i][j].add(acc[i][j]);
+            if constexpr (TM * TN == 1) tot[0][0].add(acc2);
+        };
+        const bool whole = nt == KT;                     // the segment IS the tile: v3's epilogue
+        // bias and residual travel while the producers bring the first k-tiles (whole tiles, vectorised stores)
+        const bool pre = p.vec_store && whole;
+        f32x4 pb[TN], pr[TN][TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+            const bool cok = pre && co + 3 < p.Cout;
+            pb[i] = (cok && p.bias) ? *(const f32x4 *)(p.bias + (long)g * p.b_gs + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int m = bm0 + (wm * TM + j) * 16 + l15;
+                pr[i][j] = (cok && p.res && m < p.M)
+                               ? *(const f32x4 *)(p.res + (long)g * p.r_gs + (long)m * p.res_cstride + p.res_coff + co)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();
+        read_frags(0, 0, 0);
+        int st = 0;
+        for (int t = 0; t < nt; ++t) {
+            const int st1 = st == 2 ? 0 : st + 1;
+            flush();
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
+                else if (t + 1 < nt) read_frags(st1, 0, 0);
+                blocked_mma<TN, TM>(acc, acc2, fw[r & 1], fx[r & 1], r == 0);
+            }
+            st = st1;
+            __syncthreads();
+        }
+        flush();
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = tot[i][j].get();
+
+        if (!whole) {
+            // ---- partial tile: this wave's blocks -> slab [tile][part][wave][block][lane]; one ticket per (tile, wave)
+            const int w_first = owner(ut0), w_last = owner((long)ut0 + KT - 1);
+            const int nparts = w_last - w_first + 1, part = wi - w_first;
+            const long tslot = sk.tbase[pi] + tl;
+            float *slab = p.ws + (tslot * sk.pmax) * (long)(BM * BN);
+            int *tick = (int *)(p.ws + (long)sk.tbase[bt.n] * sk.pmax * (BM * BN)) + tslot * 4 + wave;
+            const long ntot = (long)sk.tbase[bt.n] * sk.pmax * (BM * BN) * 4;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)p.ws, 0, (int)(ntot > 0x7fffffffL ? 0x7fffffffL : ntot), 0x00020000);
+            auto off = [&](int prt, int blk) { return (int)((((tslot * sk.pmax + prt) * 4 + wave) * NBLK + blk) * 64 + lane) * 16; };
+            (void)slab;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, off(part, i * TM + j), 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            if (ticket != nparts - 1) continue;           // another part's wave finishes this wave-tile
+            if (lane == 0) __hip_atomic_store(tick, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // sum the parts in order (this wave's own part from the slab too: the same bits whichever wave is last)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    for (int q = 0; q < nparts; ++q)
+                        v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off(q, i * TM + j), 0, 16));
+                    acc[i][j] = v;
+                }
+        }
+        const float *__restrict__ bg = p.bias ? p.bias + (long)g * p.b_gs : nullptr;
+        const float *__restrict__ rg = p.res ? p.res + (long)g * p.r_gs : nullptr;
+        float *__restrict__ yg = p.y + (long)g * p.y_gs;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = bm0 + (wm * TM + j) * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
+                if (co >= p.Cout) continue;
+                f32x4 v = acc[i][j];
+                if (p.vec_store && co + 3 < p.Cout) {
+                    if (whole) {
+                        v += pb[i] + pr[i][j];
+                    } else {
+                        if (bg) v += *(const f32x4 *)(bg + co);
+                        if (rg) v += *(const f32x4 *)(rg + (long)m * p.res_cstride + p.res_coff + co);
+                    }
+                    const int a = co < p.act_split ? p.act : p.act2;
+                    if (a != USOT_ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a);
+                    }
+                    *(f32x4 *)(yg + (long)m * p.y_cstride + p.y_coff + co) = v;
+                } else {
+                    const int n = m / p.P, pix = m - n * p.P;
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = co + e;
+                        if (c >= p.Cout) break;
+                        float s2 = v[e];
+                        if (bg) s2 += bg[c];
+                        if (rg) s2 += rg[(long)m * p.res_cstride + p.res_coff + c];
+                        s2 = apply_act(s2, c < p.act_split ? p.act : p.act2);
+                        if (p.y_nchw) yg[((long)n * p.Cout + c) * p.P + pix] = s2;
+                        else          yg[(long)m * p.y_cstride + p.y_coff + c] = s2;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // ws ("weight-streaming"): v3's producer / consumer split with the FILTER operand taken out of LDS.
 //
 // Measured on v3 (scripts/ablate_kstep.py, -DUSOT_ABL_NOW: the W operand neither loaded, staged nor read; 32 x 64 tile):
@@ -1730,7 +2038,8 @@ __global__ __launch_bounds__(512) void conv_wstat_f32(const ConvBatch bt)
     USOT_WSTAT_SINK();
 }
 
-struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int threads; int depth; int wfrag; int dw; int nst = 0; int rps = 0; };
+struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int threads; int depth; int wfrag; int dw; int nst = 0; int rps = 0;
+                 void (*skfn)(const ConvBatch, const SkInfo) = nullptr; };
 
 #define TILE(bm, bn, wm, wn) { bm, bn, 32, 2, 1, conv_igemm_f32<bm, bn, wm, wn>, 256, 1, 0, 0 }
 #define TILE2(bm, bn, wm, wn, bk) { bm, bn, bk, 3, 1, conv_igemm_f32_v2<bm, bn, wm, wn, bk>, 256, 1, 0, 0 }
@@ -1741,6 +2050,8 @@ struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int t
 #define TILEW2(bm, bn, d, npw, dw) { bm, bn, 64, 3, 1, conv_igemm_f32_ws<bm, bn, d, npw, dw, 2>, 256 + 64 * npw, d, 1, dw }
 #define TILE11(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw, 2>, 256 + 64 * npw, d, 0, 2 }
 #define TILESB(nst, rps) { 32, 32, 64, 3, 1, conv_wstat_f32<nst, rps, true>, 512, 2, 1, 0, nst, rps }
+#define TILEP(bm, bn, wm, wn, d, npw) { bm, bn, 64, 3, 1, nullptr, 256 + 64 * npw, d, 0, 0, 0, 0, conv_igemm_f32_v3p<bm, bn, wm, wn, d, npw> }
+#define TILEP32(bm, bn, wm, wn, d, npw) { bm, bn, 32, 3, 1, nullptr, 256 + 64 * npw, d, 0, 0, 0, 0, conv_igemm_f32_v3p<bm, bn, wm, wn, d, npw, 32> }
 #define TILES(nst, rps) { 32, 32, 64, 3, 1, conv_wstat_f32<nst, rps>, 512, 2, 1, 0, nst, rps }
 #define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d, 0, 0 }
 const TileCfg kTiles[] = {
@@ -1815,6 +2126,17 @@ const TileCfg kTiles[] = {
     TILES(9, 1),                      // 69: K = 1152 (3 x 3 x 128)
     TILESB(18, 1),                    // 70: K = 2304, blocked accumulation (64-product blocks + running total)
     TILES(8, 1),                      // 71: K = 1024
+    TILEP(64, 64, 2, 2, 2, 8),        // 72: v3 as a persistent stream-K launch (whole-chip rounds)
+    TILEP(32, 64, 2, 2, 2, 8),        // 73
+    TILEP(64, 64, 2, 2, 3, 8),        // 74
+    TILEP(64, 64, 2, 2, 2, 4),        // 75
+    TILEP(32, 32, 2, 2, 3, 8),        // 76
+    TILEP32(64, 64, 2, 2, 2, 8),      // 77: k-tiles of 32
+    TILEP32(128, 64, 2, 2, 2, 4),     // 78
+    // (72-78, round 5: parity-green; Conf_Fusion's conv isolated 120 (v3 32 x 64) -> 111 us on tile 74 - 64 x 64 tiles without the
+    //  three-round quantisation - but INSIDE the frame 111.6 -> 119.5 us and the graph +13 us; the three search encoders 74.6 -> 71.1
+    //  per op, graph +10; shortcut conv + conv1 97 -> 132.  128 x 64 / 64 x 128 / 128 x 128 shapes spill at 768 threads.  Not in
+    //  the tuning table)
     // (61-67: parity-green, none faster than v3 - DESIGN.md section 3.1 "what a k-step waits for")
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
@@ -1854,6 +2176,7 @@ extern "C" int usot_conv_tile_name(int tile, char *buf, int len)
     if (tile < 1 || tile > kNumTiles || !buf || len < 8) return USOT_EINVAL;
     const TileCfg &t = kTiles[tile - 1];
     if (t.nst) { snprintf(buf, len, "conv_wstat_f32<NST=%d,RPS=%d>", t.nst, t.rps); return USOT_OK; }
+    if (t.skfn) { snprintf(buf, len, "conv_igemm_f32_v3p<%d,%d,BK=%d,D=%d,NPW=%d>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.wfrag) { snprintf(buf, len, "conv_igemm_f32_ws<%d,%d,D=%d,NPW=%d,DW=%d>", t.bm, t.bn, t.depth, (t.threads - 256) / 64, t.dw); return USOT_OK; }
     if (t.dw == 2 && !t.wfrag) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=2>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.threads == 768 && t.ksw == 1) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=8>", t.bm, t.bn, t.bk, t.depth); return USOT_OK; }
@@ -1976,6 +2299,71 @@ int fill_params(const usot_conv_desc *d, ConvK &p)
 
 }  // namespace
 
+namespace {
+// geometry of a persistent stream-K launch of `n` problems on tile tc: fills bt.p[i].MT/NT, sk; returns the workspace floats
+// (slabs [tile][part][BM x BN] + four ticket words per tile) or a negative status
+int64_t sk_plan(const TileCfg &tc, const usot_conv_desc *d, int n, ConvBatch &bt, SkInfo &sk)
+{
+    long U = 0, T = 0;
+    int ktmax = 1;
+    for (int i = 0; i < n; ++i) {
+        ConvK &p = bt.p[i];
+        if (d[i].Cin % tc.bk || p.ksplit != 1 || d[i].w_frag || d[i].defer) return USOT_EINVAL;
+        p.MT = (p.M + tc.bm - 1) / tc.bm;
+        p.NT = (d[i].Cout + tc.bn - 1) / tc.bn;
+        const int kt = p.K / tc.bk;
+        sk.ubase[i] = (int)U;
+        sk.tbase[i] = (int)T;
+        U += (long)p.groups * p.MT * p.NT * kt;
+        T += (long)p.groups * p.MT * p.NT;
+        ktmax = kt > ktmax ? kt : ktmax;
+    }
+    if (U <= 0 || U > 0x3fffffffL) return USOT_EINVAL;
+    for (int i = n; i < 5; ++i) { sk.ubase[i] = (int)U; sk.tbase[i] = (int)T; }
+    static int slots[128] = {0};                       // resident workgroups of this tile on this device (usot_device_guard: one device)
+    const int tile = (int)(&tc - kTiles);
+    if (!slots[tile]) {
+        const size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * (tc.bk + 4) * sizeof(float);
+        if (hipFuncSetAttribute((const void *)tc.skfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return USOT_ELAUNCH;
+        int dev = 0, cus = 256, occ = 1;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)tc.skfn, tc.threads, lds) != hipSuccess || occ < 1) occ = 1;
+        slots[tile] = cus * (occ > 2 ? 2 : occ);
+    }
+    long G = slots[tile];
+    if (G > U / 4) G = U / 4 > 0 ? U / 4 : 1;          // at least four k-tiles per workgroup
+    sk.G = (int)G;
+    const long share = U / G;                          // the smallest share
+    sk.pmax = (int)((ktmax + share - 1) / share) + 1;  // a tile of KT units meets at most ceil(KT / share) + 1 shares
+    const int64_t fl = (int64_t)T * sk.pmax * tc.bm * tc.bn + (int64_t)T * 4;
+    if ((int64_t)T * sk.pmax * tc.bm * tc.bn * 4 >= 0x7fffffffLL) return USOT_EINVAL;
+    return fl;
+}
+}  // namespace
+
+/* workspace floats a persistent stream-K tile (usot_conv_tile_streamk(tile) == 1) needs for this batch of problems: the partial
+ * tiles of the workgroup shares that end inside a tile + four ticket words per tile.  d[0].ws must hold that many floats, ZERO
+ * before the first launch (the kernel leaves the tickets zero); 0 for the other tiles, negative = invalid arguments. */
+extern "C" int64_t usot_conv_streamk_ws_floats(const usot_conv_desc *d, int n, int tile)
+{
+    if (!d || n < 1 || n > 4 || tile < 1 || tile > kNumTiles) return USOT_EINVAL;
+    const TileCfg &tc = kTiles[tile - 1];
+    if (!tc.skfn) return 0;
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;
+    ConvBatch bt;
+    SkInfo sk;
+    bt.n = n;
+    for (int i = 0; i < n; ++i) {
+        usot_conv_desc c = d[i];
+        if (!c.y) c.y = (float *)c.x;                  // sizing only
+        int rc = fill_params(&c, bt.p[i]);
+        if (rc != USOT_OK) return rc;
+    }
+    return sk_plan(tc, d, n, bt, sk);
+}
+
+extern "C" int usot_conv_tile_streamk(int tile) { return (tile >= 1 && tile <= kNumTiles && kTiles[tile - 1].skfn) ? 1 : 0; }
+
 extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int n)
 {
     if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
@@ -1995,6 +2383,18 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
     if (tile < 1 || tile > kNumTiles) return USOT_EINVAL;
     const TileCfg &tc = kTiles[tile - 1];
     long blocks = 0;
+    if (tc.skfn) {                         // persistent stream-K: a resident set of workgroups shares the (tile, k-tile) units
+        SkInfo sk;
+        const int64_t need = sk_plan(tc, d, n, bt, sk);
+        if (need < 0) return (int)need;
+        if (!d[0].ws) return USOT_EINVAL;
+        for (int i = 0; i < n; ++i) bt.p[i].ws = d[0].ws;         // one workspace for the batch
+        for (int i = 0; i < 5; ++i) bt.start[i] = 0;
+        const size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * (tc.bk + 4) * sizeof(float);
+        hipLaunchKernelGGL(tc.skfn, dim3((unsigned)sk.G), dim3(tc.threads), lds, (hipStream_t)stream, bt, sk);
+        if (hipGetLastError() != hipSuccess) return USOT_ELAUNCH;
+        return USOT_OK;
+    }
     if (tc.nst) {                          // weight-stationary tiles: one workgroup per (group, 32 channels, pixel range)
         double work = 0;
         for (int i = 0; i < n; ++i) work += (double)bt.p[i].M * bt.p[i].Cout * bt.p[i].groups;

@@ -290,8 +290,8 @@ class Builder:
         frag = hip.tile_wfrag(ttile)                # tiles that take their filters in MFMA fragment order
         if frag and (row0 % 16 or ((w_rows or cout) % 16 and groups > 1) or not hip.tile_supports(ttile, pc.cin, cout, k)):
             ttile, ksplit, frag = (self.default_batch_tile if tile is not None else 0), 1, 0     # geometry the tile cannot take
-        if frag and hip.tile_kreq(ttile)[0]:
-            ksplit = 1                              # weight-stationary tiles split k inside the workgroup
+        if (frag and hip.tile_kreq(ttile)[0]) or hip.tile_streamk(ttile):
+            ksplit = 1                              # weight-stationary tiles split k inside the workgroup, stream-K tiles over the resident set
         if ksplit > 1:            # partial slabs + one ticket per tile (usot_conv_ws_floats), tickets zero before first use
             ws = self.buf(ksplit * groups * m * cout + groups * ((m + 15) // 16) * ((cout + 31) // 32))
             ws.zero_()
@@ -313,6 +313,8 @@ class Builder:
     def conv(self, name, pc, x, n, h, w, **kw):
         """One convolution = one launch.  Returns (y, oh, ow)."""
         d, y, oh, ow, log, geom = self.conv_desc(name, pc, x, n, h, w, **kw)
+        if hip.tile_streamk(d.tile):                # persistent stream-K tile: slabs + tickets for the shares that end inside a tile
+            self.plan.keep.append(hip.streamk_ws([d], d.tile, self.dev))
         hip.check(hip.lib().usot_plan_add_conv(self.plan.h, C.byref(d)), 'plan_add_conv ' + name)
         self.log.append(log)
         self.f32_bytes.append(self._conv_bytes(d))
@@ -361,6 +363,8 @@ class Builder:
             outs.append((y, oh, ow))
             macs += log[5]
             self.geoms.append(geom)
+        if hip.tile_streamk(lead_tile):
+            self.plan.keep.append(hip.streamk_ws(descs, lead_tile, self.dev))
         arr = (hip.ConvDesc * len(descs))(*descs)
         hip.check(hip.lib().usot_plan_add_conv_batch(self.plan.h, arr, len(descs)), 'plan_add_conv_batch')
         first = items[0]

@@ -15,7 +15,7 @@ ACT_NONE, ACT_RELU, ACT_EXP, ACT_CONF = 0, 1, 2, 3
 
 EXPORTS = (
     'usot_abi_version', 'usot_device_guard', 'usot_strerror', 'usot_conv2d_f32', 'usot_conv_tile_count',
-    'usot_conv_tile_info', 'usot_conv_tile_name', 'usot_conv_tile_wfrag', 'usot_conv_tile_kreq', 'usot_conv_pack_wfrag_f32', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
+    'usot_conv_tile_info', 'usot_conv_tile_name', 'usot_conv_tile_wfrag', 'usot_conv_tile_kreq', 'usot_conv_tile_streamk', 'usot_conv_streamk_ws_floats', 'usot_conv_pack_wfrag_f32', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
     'usot_xcorr_depthwise_f32', 'usot_groupdw_f32', 'usot_conf_fusion_reduce_f32',
     'usot_prroi_pool_forward_f32', 'usot_prroi_pool_backward_f32', 'usot_prroi_pool_coor_backward_f32', 'usot_permute4_f32', 'usot_decode_f32',
     'usot_plan_create', 'usot_plan_destroy', 'usot_plan_add_conv', 'usot_plan_add_stem',
@@ -209,6 +209,8 @@ def lib():
         L.usot_conv_tile_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.usot_conv_pack_wfrag_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 2
         L.usot_conv_tile_kreq.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.usot_conv_streamk_ws_floats.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.usot_conv_streamk_ws_floats.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -260,6 +262,22 @@ def tile_supports(tile, cin, cout, k):
     if not kreq:
         return True
     return k == kreq and cin % kp == 0 and cout % 32 == 0
+
+
+def tile_streamk(tile):
+    return int(lib().usot_conv_tile_streamk(int(tile))) if tile else 0
+
+
+def streamk_ws(descs, tile, device):
+    """Zeroed workspace of a persistent stream-K launch of `descs` (list of ConvDesc) on `tile`; sets every desc's ws."""
+    arr = (ConvDesc * len(descs))(*descs)
+    n = int(lib().usot_conv_streamk_ws_floats(arr, len(descs), int(tile)))
+    if n < 0:
+        raise HipError('usot_conv_streamk_ws_floats: %d' % n)
+    ws = torch.zeros(max(n, 4), device=device, dtype=torch.float32)
+    for d in descs:
+        d.ws = ws.data_ptr()
+    return ws
 
 
 def pack_wfrag(w):
@@ -322,6 +340,8 @@ def conv2d(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, ac
                   N=N, H=H, W=W_, Cin=Cin, OH=OH, OW=OW, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad,
                   dil=dil, res=res.data_ptr() if res is not None else None, act=act, tile=tile,
                   ksplit=ksplit, ws=ws.data_ptr() if ws is not None else None, y_nchw=int(y_nchw), w_frag=frag)
+    if tile_streamk(tile):
+        keep = streamk_ws([d], tile, x.device)
     check(lib().usot_conv2d_f32(stream(), C.byref(d)), 'usot_conv2d_f32')
     return y
 
