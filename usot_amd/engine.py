@@ -351,14 +351,26 @@ class Builder:
         items: [(name, pc, x, n, h, w, kwargs)], the first one leads (its tuned tile is used unless `lead_tile` names one).
         Falls back to separate launches when batching is disabled.  Returns [(y, oh, ow)]."""
         if not self.batch or len(items) == 1:
-            return [self.conv(nm, pc, x, n, h, w, **dict(kw, **({'tile': lead_tile} if lead_tile else {})))
+            return [self.conv_deferred(nm, pc, x, n, h, w, tile=lead_tile or self.default_batch_tile, ks=kw['defer_ks']) if kw.get('defer_ks')
+                    else self.conv(nm, pc, x, n, h, w, **dict(kw, **({'tile': lead_tile} if lead_tile else {})))
                     for nm, pc, x, n, h, w, kw in items]
         descs, outs, macs = [], [], 0
         for nm, pc, x, n, h, w, kw in items:
+            kw = dict(kw)
+            dks = kw.pop('defer_ks', None)          # this problem's split-K reduction is deferred to its consumer (conv_deferred)
+            if dks:
+                kw.update(force_ks=dks, y=x)
+                kw.pop('act', None)
             d, y, oh, ow, log, geom = self.conv_desc(nm, pc, x, n, h, w, tile=lead_tile, **kw)
             if lead_tile is None:
                 lead_tile = d.tile if d.tile else self.default_batch_tile
                 d.tile = lead_tile
+            if dks:
+                if d.ksplit != dks or d.w_frag:
+                    raise hip.HipError('conv_batch %s: tile %d cannot split k %d ways' % (nm, d.tile, dks))
+                d.defer, d.act, d.bias, d.res = 1, ACT_NONE, None, None
+                slabs = next(t for t in reversed(self.plan.keep) if isinstance(t, torch.Tensor) and t.data_ptr() == d.ws)
+                y = slabs[:dks * n * oh * ow * pc.cout].view(dks, n * oh * ow, pc.cout)
             descs.append(d)
             outs.append((y, oh, ow))
             macs += log[5]
@@ -418,10 +430,19 @@ class Builder:
         t1_fused = None                               # conv1 output of this block when the previous conv3 produced it
         for bi, (c1, c2, c3, ds) in enumerate(W.blocks):
             sc = cur
+            pre_t2 = None                             # conv2's deferred partial tiles when it rode in the shortcut conv's launch
             if t1_fused is not None:
                 t1, t1_fused = t1_fused, None
                 if ds is not None:
-                    sc, _, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
+                    h2_ = c2.out_hw(h, h)[0]
+                    dk_ = (n * h2_ * h2_, c2.cout, c2.kh * c2.kw * c2.cin)
+                    bd = self.opt['batch_ds_conv2'].get(dk_) if self.lanes == 0 and self.batch else None
+                    if bd and dk_ in self.opt['defer_split_f32']:
+                        # the shortcut conv and conv2 are independent (block input / conv1's map): ONE launch, conv2's reduction deferred
+                        (sc, _, _), (pre_t2, _, _) = self.conv_batch([('b%d.ds' % bi, ds, cur, n, h, h, {}),
+                                                                      ('b%d.conv2' % bi, c2, t1, n, h, h, dict(defer_ks=bd[1]))], lead_tile=bd[0])
+                    else:
+                        sc, _, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
             elif ds is not None and self.lanes < 3:   # shortcut conv shares conv1's launch
                 (sc, _, _), (t1, _, _) = self.conv_batch([('b%d.ds' % bi, ds, cur, n, h, h, {}),
                                                           ('b%d.conv1' % bi, c1, cur, n, h, h, dict(act=ACT_RELU))])
@@ -452,8 +473,12 @@ class Builder:
                 dfr = O['defer_split_f32'].get(dk) if (fuse and c2.kh == 3) else None
                 if dfr:
                     # conv2's split-K reduction rides in the pair's tile staging (DEFAULT_OPTIONS: defer_split_f32)
-                    t2, _, _ = self.conv_deferred('b%d.conv2' % bi, c2, t1, n, h, h, tile=dfr[0], ks=dfr[1])
-                    cur, t1_fused = self.pw_pair_f32(nm, c3, nxt, t2, sc, n, h2, act2=act2, t2_parts=dfr[1], t2_bias=c2.b)
+                    if pre_t2 is not None:
+                        t2, parts = pre_t2, int(pre_t2.shape[0])
+                    else:
+                        t2, _, _ = self.conv_deferred('b%d.conv2' % bi, c2, t1, n, h, h, tile=dfr[0], ks=dfr[1])
+                        parts = dfr[1]
+                    cur, t1_fused = self.pw_pair_f32(nm, c3, nxt, t2, sc, n, h2, act2=act2, t2_parts=parts, t2_bias=c2.b)
                     h = h2
                     if bi in (2, 6, 12):
                         stages.append(cur)
@@ -893,18 +918,37 @@ class Builder:
                 # both parts on the tile tuned for the WHOLE convolution (passed explicitly: the tuning table is shared by
                 # every later plan of this engine and is not written to while a plan is built)
                 full_tile = self.tuning.get((b * m * S * S, 512, W.conf.kh * W.conf.kw * W.conf.cin, 1), (0, 1))[0]
-                self.conv_batch([('conf_fusion', W.conf, dwm[:head_n], head_n, S, S, dict(y=cv[:head_n], force_ks=1, **kw)),
-                                 ('conf_fusion.tail', W.conf, dwm[head_n:], tail, S, S, dict(y=cv[head_n:], force_ks=ks, **kw))],
-                                lead_tile=full_tile or None)
+                citems = [('conf_fusion', W.conf, dwm[:head_n], head_n, S, S, dict(y=cv[:head_n], force_ks=1, **kw)),
+                          ('conf_fusion.tail', W.conf, dwm[head_n:], tail, S, S, dict(y=cv[head_n:], force_ks=ks, **kw))]
+                skew = bool(self.opt.get('skew_towers')) and self.batch
+                if skew:
+                    # the reg / cls towers do not wait for the memory branch: their first level rides in Conf_Fusion's launch
+                    # (same tile, same K), and every later launch pairs tower level i of the memory branch with level i + 1 of
+                    # reg | cls - the memory branch's conv + reduction no longer delay the other two towers (DEFAULT_OPTIONS)
+                    citems.append(('tower0.rc', W.tower[0], tin, b, S, S, dict(cout=256, act=ACT_RELU, y=tout[0], groups=2, x_gs=gs, y_gs=gs)))
+                self.conv_batch(citems, lead_tile=full_tile or None)
             else:
+                skew = False
                 cv, _, _ = self.conv('conf_fusion', W.conf, dwm, b * m, S, S, act=ACT_CONF, act2=ACT_RELU, act_split=256)
             hip.check(L.usot_plan_add_conf_reduce(self.plan.h, hip.ptr(cv), hip.ptr(tin[2]), b, m, S * S, 256),
                       'plan_add_conf_reduce')
             cur = tin
-            for i in range(4):
-                self.conv('tower%d' % i, W.tower[i], cur, b, S, S, cout=256, act=ACT_RELU, y=tout[i], groups=3,
-                          x_gs=gs, y_gs=gs)
-                cur = tout[i]
+            if skew:
+                # the memory tower runs one level behind: [tower_i(mem) | tower_{i+1}(reg, cls)] per launch, tower_3(mem) alone
+                tt = self.tuning.get((b * S * S, 256, W.tower[0].kh * W.tower[0].kw * W.tower[0].cin, 3), (0, 1))[0] or None
+                for i in range(4):
+                    items = [('tower%d.mem' % i, W.tower[i], (tin if i == 0 else tout[i - 1])[2], b, S, S,
+                              dict(cout=256, act=ACT_RELU, y=tout[i][2], row0=512))]
+                    if i < 3:
+                        items.append(('tower%d.rc' % (i + 1), W.tower[i + 1], tout[i], b, S, S,
+                                      dict(cout=256, act=ACT_RELU, y=tout[i + 1], groups=2, x_gs=gs, y_gs=gs)))
+                    self.conv_batch(items, lead_tile=tt)
+                cur = tout[3]
+            else:
+                for i in range(4):
+                    self.conv('tower%d' % i, W.tower[i], cur, b, S, S, cout=256, act=ACT_RELU, y=tout[i], groups=3,
+                              x_gs=gs, y_gs=gs)
+                    cur = tout[i]
             self.thin_convs([('bbox_pred', W.bbox_pred, cur[0], b, S, S, dict(act=ACT_EXP, y=bbox, y_nchw=True)),
                              ('cls_preds', W.cls_preds, cur[1], b, S, S, dict(cout=1, y=cls2, y_nchw=True, groups=2,
                                                                               x_gs=gs, y_gs=b * S * S, w_rows=1))])
@@ -1075,6 +1119,15 @@ DEFAULT_OPTIONS = {
     # that move fewer L2 bytes than the 32 x 32 ones.  Same-process A/B of the frame graph (scripts/ks_ab.py, two boxes): layer3's six
     # conv2 (32 x 64, ks 2) 858-871 -> 843-845 us, + layer2.0's conv2 (32 x 32, ks 2, was ks 2 with the in-launch combine) -> 838;
     # 64 x 64 tiles with ks 4 are SLOWER (862-868).  {} = every reduction inside its own launch
+    # {(M, Cout, K) of conv2: (tile, ksplit)}: a block's 3x3 / stride-2 shortcut conv and its conv2 (both inputs ready: the block's
+    # input map and conv1's output, which the previous block's fused launch produced) share ONE launch, conv2 deferred
+    # EMPTY by default: measured +8 us per frame ((961, 128, 1152): (55, 2); scripts/ks_ab.py) - a launch lasts (rounds) x (one tile's
+    # k-loop latency), and the two convolutions side by side are not shorter than one after the other
+    'batch_ds_conv2': {},
+    # the reg / cls towers run one level AHEAD of the memory tower (level 0 in Conf_Fusion's launch): see Builder.heads.  OFF: measured
+    # +33 us per frame - tower0's 160 workgroups behind Conf_Fusion's 1 264 open another round of 36 k-steps (143.6 vs 110.9 us), and
+    # the memory tower's last level alone (80 workgroups) takes the same 30 us as a three-tower level (per-op spans, ks_ab.py)
+    'skew_towers': False,
     'defer_split_f32': {(961, 256, 2304): (55, 2), (1089, 256, 2304): (55, 2), (961, 128, 1152): (53, 2), (1089, 128, 1152): (53, 2)},
 }
 ENV_SWITCHES = {      # environment variable -> (option, parser)
