@@ -719,9 +719,9 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
 // of the k-tile (BK = 64), reads issued two rounds = 16 MFMAs ahead and pinned there (sched_barrier)
 template <int BM, int BN, int WM, int WN, int BK, int D = 1, int NPW = 4, int PF = 1>
 #ifdef USOT_V3_SWZ
-__global__ __launch_bounds__(256 + 64 * NPW, (BM * BN <= 32 * 64) ? (4 + NPW) / 2 : 1) void conv_igemm_f32_v3(const ConvBatch bt)
+__global__ __launch_bounds__(64 * WM * WN + 64 * NPW, (BM * BN <= 32 * 64) ? (4 + NPW) / 2 : 1) void conv_igemm_f32_v3(const ConvBatch bt)
 #else
-__global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBatch bt)
+__global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(const ConvBatch bt)
 #endif
 {
     int pi = 0;
@@ -730,7 +730,15 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
         if (q < bt.n && (int)blockIdx.x >= bt.start[q]) pi = q;
     const ConvK &p = bt.p[pi];
     const int bid0 = (int)blockIdx.x - bt.start[pi];
-    static_assert(WM * WN == 4, "4 consumer wavefronts");
+    // WM x WN consumer wavefronts: 4 (one per SIMD) or 8 (two per SIMD, round 5: the same tile in smaller wave tiles, nothing to
+    // exchange).  Probe (scripts/probes/coissue_probe.hip, inline-asm reads, independent accumulators): a SIBLING wave's VALU / SALU /
+    // LDS / VMEM instructions do not delay a wave's back-to-back MFMAs at all (32.0 cycles each); the wave's OWN ds_read_b128, issued
+    // a round ahead, cost ~6 cycles each (292 / 286 / 298 / 310 cycles per round of 8 MFMAs with 1 / 2 / 3 / 4 reads); what stretches
+    // a round is the producers' LDS WRITES landing between a read and its use: +30 cycles per round with 3 sibling ds_write_b128 per
+    // round, +67 with 6 (v3's 24 per k-step) - 1 024 + 4 x (42 + 67) = 1 460 against the traced MFMA phase of 1 396.
+    // Measured: tower level 29.5 -> 28.2 us, Conf_Fusion's conv 113 -> 114, 64 x 64 tile 49.5 -> 46: not routed.
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 consumer wavefronts");
+    constexpr int CT = 64 * WM * WN;              // consumer threads; the producers follow
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     // LDS rows.  BK = 64: a row is 256 B = one bank row, UNPADDED, 16-byte chunk c of tile row `row` stored at chunk
     // c ^ (row & 15).  ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md
@@ -752,8 +760,8 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
     constexpr int STAGE = (BM + BN) * LD;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const bool producer = threadIdx.x >= 256;
-    const int tid = producer ? (int)threadIdx.x - 256 : (int)threadIdx.x;
+    const bool producer = threadIdx.x >= CT;
+    const int tid = producer ? (int)threadIdx.x - CT : (int)threadIdx.x;
     const int tiles = p.MT * p.NT;
     const int total = tiles * p.groups * p.ksplit;
     const int b = xcd_remap(bid0, total);
@@ -894,8 +902,17 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
 #else
 #define USOT_STAMP(slot, t)
 #endif
+#ifdef USOT_V3_STAGGER
+        // the producer waves of a workgroup leave the k-step's barrier together and would all store their part of the tile at
+        // once: 3 x NPW ds_write_b128 (13 LDS cycles each) in one burst in front of the consumers' fragment reads.  They have
+        // ~300 cycles of slack per k-step (trace: barrier wait): wave w starts its step 64 x w x USOT_V3_STAGGER / 4 cycles later
+        const int pw = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
         auto step = [&](auto dc, int t) {
             USOT_STAMP(4, t);
+#ifdef USOT_V3_STAGGER
+            for (int q = 0; q < pw * USOT_V3_STAGGER / 4; ++q) __builtin_amdgcn_s_sleep(1);
+#endif
             if (t + 2 < nt) store_tile(dc, st2);
             USOT_STAMP(5, t);
             load_next(dc);
@@ -1010,6 +1027,17 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_igemm_f32_v3(const ConvBa
                 if (r + 1 < NR) read_frags(st, r + 1, (r + 1) & 1);
                 else if (t + 1 < nt) read_frags(st1, 0, 0);
                 mma(r & 1, r == 0);
+#ifdef USOT_V3_ILV
+                // One fragment read BETWEEN two MFMAs instead of TN + TM reads in a burst in front of the round's MFMAs: a wave issues
+                // in order and a ds_read_b128 holds its issue slot for ~30 cycles (trace: MFMA phase 1 396 cycles for 1 024 cycles of
+                // MFMAs on the 32 x 64 tile, +90 per round whatever the prefetch distance) - under a running MFMA (32 cycles) that is free
+#pragma unroll
+                for (int q = 0; q < TN + TM; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TN * TM - (TN + TM), 0);
+#endif
             }
         }
         st = st1;
@@ -2053,6 +2081,7 @@ struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int t
 #define TILEP(bm, bn, wm, wn, d, npw) { bm, bn, 64, 3, 1, nullptr, 256 + 64 * npw, d, 0, 0, 0, 0, conv_igemm_f32_v3p<bm, bn, wm, wn, d, npw> }
 #define TILEP32(bm, bn, wm, wn, d, npw) { bm, bn, 32, 3, 1, nullptr, 256 + 64 * npw, d, 0, 0, 0, 0, conv_igemm_f32_v3p<bm, bn, wm, wn, d, npw, 32> }
 #define TILES(nst, rps) { 32, 32, 64, 3, 1, conv_wstat_f32<nst, rps>, 512, 2, 1, 0, nst, rps }
+#define TILE12(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw>, 64 * wm * wn + 64 * npw, d, 0, 8 }
 #define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d, 0, 0 }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
@@ -2138,6 +2167,13 @@ const TileCfg kTiles[] = {
     //  per op, graph +10; shortcut conv + conv1 97 -> 132.  128 x 64 / 64 x 128 / 128 x 128 shapes spill at 768 threads.  Not in
     //  the tuning table)
     // (61-67: parity-green, none faster than v3 - DESIGN.md section 3.1 "what a k-step waits for")
+    TILE12(32, 64, 2, 4, 64, 2, 8),   // 79: v3 with EIGHT consumer waves (two per SIMD) on the same tile: 16 x 16 wave tiles
+    TILE12(32, 64, 2, 4, 64, 3, 8),   // 80
+    TILE12(64, 64, 2, 4, 64, 2, 8),   // 81: 32 x 16 wave tiles
+    TILE12(64, 64, 4, 2, 64, 2, 8),   // 82: 16 x 32
+    TILE12(64, 32, 4, 2, 64, 2, 8),   // 83: 16 x 16
+    TILE12(32, 64, 2, 4, 64, 2, 4),   // 84
+    TILE12(64, 64, 2, 4, 64, 3, 8),   // 85
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -2178,6 +2214,7 @@ extern "C" int usot_conv_tile_name(int tile, char *buf, int len)
     if (t.nst) { snprintf(buf, len, "conv_wstat_f32<NST=%d,RPS=%d>", t.nst, t.rps); return USOT_OK; }
     if (t.skfn) { snprintf(buf, len, "conv_igemm_f32_v3p<%d,%d,BK=%d,D=%d,NPW=%d>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.wfrag) { snprintf(buf, len, "conv_igemm_f32_ws<%d,%d,D=%d,NPW=%d,DW=%d>", t.bm, t.bn, t.depth, (t.threads - 256) / 64, t.dw); return USOT_OK; }
+    if (t.dw == 8 && !t.wfrag) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,NCW=8>", t.bm, t.bn, t.bk, t.depth, (t.threads - 512) / 64); return USOT_OK; }
     if (t.dw == 2 && !t.wfrag) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=2>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.threads == 768 && t.ksw == 1) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=8>", t.bm, t.bn, t.bk, t.depth); return USOT_OK; }
     const char *fam = t.threads == 512 && t.ksw == 1 ? "conv_igemm_f32_v3" : (t.stages == 3 ? "conv_igemm_f32_v2" : "conv_igemm_f32");
