@@ -521,16 +521,25 @@ def mixed_roofline(pm, batch, size, n, dt, top=5):
             fl_conv += 2.0 * macs
             rows.append((ms, name, M, N, K, 2.0 * macs / ms / 1e9))
         else:
-            rows.append((ms, 'op kind %d' % kind, 0, 0, 0, 0.0))
+            rows.append((ms, {1: 'stem', 2: 'maxpool', 3: 'groupdw (9 samples per stream)', 4: 'conf_fusion reduce', 6: 'permute', 10: 'rows copy', 12: 'convert',
+                              13: 'maxpool (lp)', 14: 'stem + pool (lp)', 15: 'rows copy', 16: 'prediction convs (thin)'}.get(kind, 'op kind %d' % kind), 0, 0, 0, 0.0))
     gflop = batch * FRAME_GFLOP * (size / 255.0) ** 2 if size != 255 else batch * FRAME_GFLOP
     ach = gflop * n / dt / 1e3
-    alg_bytes = sum(pm.get('lp_bytes', [])) + sum(pm.get('f32_bytes', [])) + batch * 3 * size * size * 4
+    S = (size - 7) // 2 + 1                                     # stem rows -> response size: 25 at 255, 27 at 271
+    S = ((S - 1) // 2 + 1 - 1) // 2 + 1 - 6
+    # GroupDW: per sample the three fp32 search maps + kernels in, the response map out in the storage type (3 161 088 B
+    # with an fp32 output); Conf_Fusion's reduction: the 7 confidence | value maps in, one map out (storage type)
+    gdw = 9 * batch * (GROUPDW_BYTES_PER_SAMPLE - S * S * 256 * 2) if size == 255 else 0
+    red = batch * S * S * (7 * 512 + 256) * 2
+    alg_bytes = sum(pm.get('lp_bytes', [])) + sum(pm.get('f32_bytes', [])) + batch * 3 * size * size * 4 + gdw + red
     traffic, tsrc, by_kernel = None, None, None
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic_mixed.json')
-    if batch == 32 and size == 255 and os.path.exists(tpath):
+    if size == 255 and os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
         ok, tsrc = counters_current(tj.get('_meta'), 'profiles/pmc_traffic_mixed.json')
+        if ok and '--batch %d ' % batch not in tj.get('_meta', {}).get('command', ''):
+            ok, tsrc = False, 'profiles/pmc_traffic_mixed.json was measured on another batch size (%s)' % tj.get('_meta', {}).get('command')
         if ok:
             traffic = tj.get('hbm_bytes_per_step')
             tsrc += ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, summed over the step)'
@@ -540,7 +549,7 @@ def mixed_roofline(pm, batch, size, n, dt, top=5):
             'algorithmic_gflop_per_step': round(gflop, 1),
             'traffic': traffic, 'traffic_source': tsrc,
             'algorithmic_bytes_per_step': int(alg_bytes),
-            'algorithmic_bytes_note': 'every conv launch: operands + result once (storage type of each), + the fp32 crops; GroupDW / reduce / prediction maps not counted',
+            'algorithmic_bytes_note': 'every conv launch: operands + result once (storage type of each), the fp32 crops, GroupDW (9 samples per stream) and the Conf_Fusion reduction; layout permutes and prediction maps not counted',
             'traffic_to_algorithmic': round(traffic / alg_bytes, 3) if traffic else None,
             'traffic_per_launch_top_kernels': by_kernel,
             'kernel': 'conv_igemm_bf16<f16> family + heads (%d launches per step)' % len(prof),

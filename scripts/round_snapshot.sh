@@ -33,7 +33,7 @@ done
 python scripts/pmc_lp_traffic.py "$(db "$out/pmc_lp_FETCH_SIZE")" "$(db "$out/pmc_lp_WRITE_SIZE")" "$out/pmc_traffic_bf16.json" "$commit" > /dev/null
 # configs[4] per-GPU share (32 streams, fp16 backbone + head convs, fp32 xcorr): kernel table + the two PMC passes behind
 # track_mixed_b32.roofline.traffic (profiles/pmc_traffic_mixed.json) + the busy pass of its kernels (below)
-mx="--workload track_mixed --steps 20 --min-seconds 0"
+mx="--workload track_mixed --batch 32 --steps 20 --min-seconds 0"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$out/prof_mx" -- python "$root/bench.py" $mx > "$out/config5_profiled_bench.json" 2>> "$out/prof.err")
 python scripts/rocpd_stats.py "$(db "$out/prof_mx")" > "$out/config5_kernel_stats.txt"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -59,6 +59,6 @@ done
 python scripts/pmc_xcorr_to_json.py "$(db "$out/pmc_xc_FETCH_SIZE")" "$(db "$out/pmc_xc_WRITE_SIZE")" 2048 "$out/pmc_xcorr.json" "$commit" > /dev/null
 rm -rf "$out/pmc_lp_busy" "$out/pmc_mx_busy" "$out/prof_mx" "$out/pmc_mx_FETCH_SIZE" "$out/pmc_mx_WRITE_SIZE" "$out/pmc_busy_f32" "$out/prof_xc" "$out/pmc_xc_FETCH_SIZE" "$out/pmc_xc_WRITE_SIZE"
 timeout 300 python bench.py --workload backbone_bf16 > "$out/config3_bf16_bench.json" 2>> "$out/bench.err"
-timeout 300 python bench.py --workload track_mixed > "$out/config5_fp16_mixed_b32_bench.json" 2>> "$out/bench.err"
+timeout 300 python bench.py --workload track_mixed --batch 32 > "$out/config5_fp16_mixed_b32_bench.json" 2>> "$out/bench.err"
 rm -rf "$out/prof" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/prof_lp" "$out/pmc_lp_FETCH_SIZE" "$out/pmc_lp_WRITE_SIZE"
 cat "$out/smoke.log" | tail -2; head -c 600 "$out/bench.json"; echo; head -12 "$out/kernel_stats.txt"
