@@ -50,8 +50,8 @@ __global__ __launch_bounds__(512) void probe(float *out, long long *cyc, int ite
 
 // The MFMA wave's OWN fragment reads: per round NRD ds_read_b128 for the NEXT round (burst in front, or one behind each of the
 // first NRD MFMAs), then 8 MFMAs on the previous round's fragments; siblings idle or issuing NW ds_write_b128 per round.
-template <int NRD, int ILV, int NW, int NMW = 4>
-__global__ __launch_bounds__(512) void probe_self(float *out, long long *cyc, int iters)
+template <int NRD, int ILV, int NW, int NMW = 4, int NDMA = 0>
+__global__ __launch_bounds__(512) void probe_self(float *out, long long *cyc, int iters, const float *src = nullptr)
 {
     __shared__ __attribute__((aligned(16))) float lds[8192];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -88,20 +88,31 @@ __global__ __launch_bounds__(512) void probe_self(float *out, long long *cyc, in
         out[threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
     } else {
         f32x4 g = {1, 2, 3, 4};
+        const float *gp = src + (blockIdx.x * 4 + (wave - 4)) * 4096 + lane * 4;
         for (int i = 0; i < iters * 2; ++i) {
 #pragma unroll
             for (int q = 0; q < NW; ++q) asm volatile("ds_write_b128 %0, %1" :: "v"(16384 + lane * 16 + q * 1024), "v"(g));
-            if (NW == 0) asm volatile("s_nop 0");
+#pragma unroll
+            for (int q = 0; q < NDMA; ++q) {          // LDS-DMA pieces (1 KiB: lane x 16 bytes behind M0) of an L2-resident buffer
+                unsigned keep;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(20480 + (wave - 4) * 2048 + q * 1024);
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gp + ((i * NDMA + q) & 3) * 256), "s"(dst) : "memory");
+            }
+            if (NDMA) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (NW == 0 && NDMA == 0) asm volatile("s_nop 0");
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         out[threadIdx.x] = g[0];
     }
 }
 
-template <int NRD, int ILV, int NW, int NMW = 4> void run_self(float *out, long long *cyc)
+template <int NRD, int ILV, int NW, int NMW = 4, int NDMA = 0> void run_self(float *out, long long *cyc, const float *src = nullptr)
 {
     const int iters = 2000;
     if (NMW == 8) printf("TWO MFMA waves per SIMD (cycles are per wave: 512 = the pipe shared evenly and full) -> ");
-    hipLaunchKernelGGL((probe_self<NRD, ILV, NW, NMW>), dim3(256), dim3(512), 0, 0, out, cyc, iters);
+    if (NDMA) printf("siblings also issue %d LDS-DMA pieces per round each -> ", NDMA);
+    hipLaunchKernelGGL((probe_self<NRD, ILV, NW, NMW, NDMA>), dim3(256), dim3(512), 0, 0, out, cyc, iters, src);
     hipDeviceSynchronize();
     static long long h[1024];
     hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
@@ -126,7 +137,7 @@ template <int KIND, int NV> void run(const char *name, float *out, long long *cy
 int main()
 {
     float *out, *src; long long *cyc;
-    hipMalloc(&out, 4096); hipMalloc(&cyc, 8192); hipMalloc(&src, 1 << 20); hipMemset(src, 0, 1 << 20);
+    hipMalloc(&out, 4096); hipMalloc(&cyc, 8192); hipMalloc(&src, 32 << 20); hipMemset(src, 0, 32 << 20);
     run<0, 0>("idle sibling", out, cyc, src);
     run<0, 4>("v_add_u32", out, cyc, src);  run<0, 16>("v_add_u32", out, cyc, src);  run<0, 32>("v_add_u32", out, cyc, src);
     run<6, 16>("v_cndmask", out, cyc, src);
@@ -139,5 +150,6 @@ int main()
     run_self<3, 1, 0>(out, cyc); run_self<4, 1, 0>(out, cyc);
     run_self<3, 0, 0, 8>(out, cyc); run_self<2, 0, 0, 8>(out, cyc); run_self<4, 0, 0, 8>(out, cyc); run_self<1, 0, 0, 8>(out, cyc);
     run_self<3, 0, 3>(out, cyc); run_self<3, 1, 3>(out, cyc); run_self<3, 0, 6>(out, cyc); run_self<1, 0, 6>(out, cyc);
+    run_self<3, 0, 0, 4, 1>(out, cyc, src); run_self<3, 0, 1, 4, 1>(out, cyc, src); run_self<3, 0, 0, 4, 2>(out, cyc, src); run_self<3, 0, 2, 4, 0>(out, cyc, src);
     return 0;
 }

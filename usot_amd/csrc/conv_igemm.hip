@@ -733,9 +733,10 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     // WM x WN consumer wavefronts: 4 (one per SIMD) or 8 (two per SIMD, round 5: the same tile in smaller wave tiles, nothing to
     // exchange).  Probe (scripts/probes/coissue_probe.hip, inline-asm reads, independent accumulators): a SIBLING wave's VALU / SALU /
     // LDS / VMEM instructions do not delay a wave's back-to-back MFMAs at all (32.0 cycles each); the wave's OWN ds_read_b128, issued
-    // a round ahead, cost ~6 cycles each (292 / 286 / 298 / 310 cycles per round of 8 MFMAs with 1 / 2 / 3 / 4 reads); what stretches
-    // a round is the producers' LDS WRITES landing between a read and its use: +30 cycles per round with 3 sibling ds_write_b128 per
-    // round, +67 with 6 (v3's 24 per k-step) - 1 024 + 4 x (42 + 67) = 1 460 against the traced MFMA phase of 1 396.
+    // a round ahead, cost ~6 cycles each (292 / 286 / 298 / 310 cycles per round of 8 MFMAs with 1 / 2 / 3 / 4 reads); ds_write_b128 of
+    // the four sibling waves between a read and its use add +30 cycles per round at 3 per wave (12 per round), +67 at 6 per wave
+    // (24 per round) - v3 issues 24 per K-STEP, 6 per round: ~ +15; sibling LDS-DMA pieces (4-8 per round) add nothing.  So the probe
+    // accounts for 1 024 + 4 x (42 + 15) = 1 250 of the traced 1 396-cycle MFMA phase; no single mechanism measured here explains the rest.
     // Measured: tower level 29.5 -> 28.2 us, Conf_Fusion's conv 113 -> 114, 64 x 64 tile 49.5 -> 46: not routed.
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 consumer wavefronts");
     constexpr int CT = 64 * WM * WN;              // consumer threads; the producers follow
@@ -939,8 +940,8 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     const int fw_off = BM * LD + (wn * TN * 16 + l15) * LD + (SWZ ? 0 : quad * 4);
     // swizzled rows: chunk (4 r + quad) of row (16 b + l15) lives at chunk (4 r) ^ (quad ^ l15)
     const int swz = SWZ ? (quad ^ l15) * 4 : 0;     // one v_xor per round instead of four live offsets (80-VGPR budget: 2 workgroups / CU)
-    constexpr int NSLOT = PF == 2 ? NR : 2;
-    static_assert(PF == 1 || (PF == 2 && NR == 4), "PF = 2 needs BK = 64");
+    constexpr int NSLOT = PF >= 2 ? NR : 2;
+    static_assert(PF == 1 || (PF >= 2 && NR == 4), "PF >= 2 needs BK = 64");
     f32x4 fw[NSLOT][TN], fx[NSLOT][TM];
     auto read_frags = [&](int st, int r, int slot) {
 #ifdef USOT_ABL_NOREAD
@@ -1008,13 +1009,66 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
 #ifdef USOT_TRACE
     unsigned *trc = (p.ksplit == 1 && p.ws && bid0 == 0 && tid == 0) ? (unsigned *)p.ws : nullptr;
 #endif
-    if (nt > 0) read_frags(0, 0, 0);
-    if (PF == 2 && nt > 0) read_frags(0, 1, 1);
+    // PF = 3: the consumer's fragment traffic scheduled BY HAND.  hipcc's schedule of the plain loop (PF = 1) re-uses a fragment
+    // register right behind the MFMA that read it and waits for that read at once (ds_read_b128 v[34:37] ... s_waitcnt lgkmcnt(1) ...
+    // v_mfma ... v34), with s_nop 6-7 in front of reads that overwrite MFMA sources: the software pipeline of the source is gone
+    // in the ISA.  Here the reads are inline asm (the compiler neither moves them behind their MFMAs nor waits for them), issued TWO
+    // rounds ahead into one slot per round, and every round waits with a COUNTED s_waitcnt lgkmcnt(2 x reads per round) that carries
+    // the round's fragment registers as operands, so no MFMA of the round can be scheduled above it.
+    // (the registers travel as PARAMETERS: clang rejects asm operands that name captured arrays inside a generic lambda)
+    auto aread_ = [](f32x4 (&w)[TN], f32x4 (&x)[TM], unsigned bw, unsigned bx, auto rc) {
+        constexpr int r = decltype(rc)::value;
+        constexpr int LD = (BK == 64 ? BK + 4 : BK + 4);          // padded rows (the swizzled form is not built for PF = 3)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[i]) : "v"(bw), "n"((i * 16 * LD + r * 16) * 4));
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[j]) : "v"(bx), "n"((j * 16 * LD + r * 16) * 4));
+    };
+    auto aread = [&](int st, auto rc, auto sc) {
+        aread_(fw[decltype(sc)::value], fx[decltype(sc)::value], (unsigned)((st * STAGE + fw_off) * 4), (unsigned)((st * STAGE + fx_off) * 4), rc);
+    };
+    auto await_ = [](f32x4 (&w)[TN], f32x4 (&x)[TM], auto nc) {   // wait until at most nc reads are outstanding; ties the slot's registers to the wait
+        static_assert(TN <= 2 && TM <= 2, "operand list below");
+        if constexpr (TN == 2 && TM == 1) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(w[0]), "+v"(w[1]), "+v"(x[0]) : "n"(decltype(nc)::value));
+        else if constexpr (TN == 1 && TM == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[0]), "+v"(x[0]) : "n"(decltype(nc)::value));
+        else if constexpr (TN == 1 && TM == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(w[0]), "+v"(x[0]), "+v"(x[1]) : "n"(decltype(nc)::value));
+        else asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(x[0]), "+v"(x[1]) : "n"(decltype(nc)::value));
+    };
+    auto await_slot = [&](auto sc, auto nc) { await_(fw[decltype(sc)::value], fx[decltype(sc)::value], nc); };
+    using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>; using R3 = std::integral_constant<int, 3>;
+    if constexpr (PF == 3) {
+        if (nt > 0) { aread(0, R0{}, R0{}); aread(0, R1{}, R1{}); }
+    } else {
+        if (nt > 0) read_frags(0, 0, 0);
+        if (PF == 2 && nt > 0) read_frags(0, 1, 1);
+    }
     int st = 0;
     for (int t = 0; t < nt; ++t) {
         const int st1 = st == 2 ? 0 : st + 1;
         USOT_STAMP(0, t);
         flush();                                      // the previous k-tile's block (zeros at t = 0)
+        if constexpr (PF == 3) {
+            constexpr int RPR = TN + TM;              // reads per round
+            using W2 = std::integral_constant<int, 2 * RPR>;
+            const bool more = t + 1 < nt;
+            aread(st, R2{}, R2{});  await_slot(R0{}, W2{}); mma(0, true);
+            aread(st, R3{}, R3{});  await_slot(R1{}, W2{}); mma(1, false);
+            if (more) {
+                aread(st1, R0{}, R0{}); await_slot(R2{}, W2{}); mma(2, false);
+                aread(st1, R1{}, R1{}); await_slot(R3{}, W2{}); mma(3, false);
+            } else {                                   // last k-tile: nothing left to fetch, the two newest rounds drain
+                await_slot(R2{}, std::integral_constant<int, RPR>{}); mma(2, false);
+                await_slot(R3{}, R0{}); mma(3, false);
+            }
+            st = st1;
+            USOT_STAMP(1, t);
+            asm volatile("s_barrier" ::: "memory");   // not __syncthreads(): its lgkmcnt(0) would drain the reads in flight for tile t + 1
+            USOT_STAMP(2, t);
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if constexpr (PF == 2) {
@@ -2082,6 +2136,7 @@ struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int t
 #define TILEP32(bm, bn, wm, wn, d, npw) { bm, bn, 32, 3, 1, nullptr, 256 + 64 * npw, d, 0, 0, 0, 0, conv_igemm_f32_v3p<bm, bn, wm, wn, d, npw, 32> }
 #define TILES(nst, rps) { 32, 32, 64, 3, 1, conv_wstat_f32<nst, rps>, 512, 2, 1, 0, nst, rps }
 #define TILE12(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw>, 64 * wm * wn + 64 * npw, d, 0, 8 }
+#define TILE13(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw, 3>, 64 * wm * wn + 64 * npw, d, 0, 3 }
 #define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d, 0, 0 }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
@@ -2174,6 +2229,11 @@ const TileCfg kTiles[] = {
     TILE12(64, 32, 4, 2, 64, 2, 8),   // 83: 16 x 16
     TILE12(32, 64, 2, 4, 64, 2, 4),   // 84
     TILE12(64, 64, 2, 4, 64, 3, 8),   // 85
+    TILE13(32, 64, 2, 2, 64, 2, 8),   // 86: v3 with the consumer's fragment reads hand-scheduled (PF = 3: asm reads two rounds ahead, counted waits)
+    TILE13(32, 64, 2, 2, 64, 3, 8),   // 87
+    TILE13(32, 32, 2, 2, 64, 2, 8),   // 88
+    TILE13(32, 32, 2, 2, 64, 3, 8),   // 89
+    TILE13(64, 64, 2, 2, 64, 2, 8),   // 90
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -2215,6 +2275,7 @@ extern "C" int usot_conv_tile_name(int tile, char *buf, int len)
     if (t.skfn) { snprintf(buf, len, "conv_igemm_f32_v3p<%d,%d,BK=%d,D=%d,NPW=%d>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.wfrag) { snprintf(buf, len, "conv_igemm_f32_ws<%d,%d,D=%d,NPW=%d,DW=%d>", t.bm, t.bn, t.depth, (t.threads - 256) / 64, t.dw); return USOT_OK; }
     if (t.dw == 8 && !t.wfrag) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,NCW=8>", t.bm, t.bn, t.bk, t.depth, (t.threads - 512) / 64); return USOT_OK; }
+    if (t.dw == 3 && !t.wfrag) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=3>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.dw == 2 && !t.wfrag) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=2>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.threads == 768 && t.ksw == 1) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=8>", t.bm, t.bn, t.bk, t.depth); return USOT_OK; }
     const char *fam = t.threads == 512 && t.ksw == 1 ? "conv_igemm_f32_v3" : (t.stages == 3 ? "conv_igemm_f32_v2" : "conv_igemm_f32");
