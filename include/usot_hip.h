@@ -153,8 +153,11 @@ typedef struct usot_pw_pair_desc {
     void *ws;             /* fp32 form only: usot_pw_pair_f32_ws_floats() zero-initialised floats, or NULL */
     /* fp32 form only: t2 given as t2_parts > 1 partial sums [t2_parts][M][CM] of the producing convolution (usot_conv_desc.defer);
      * the kernel stages relu(sum of the parts in order + t2_bias) as its pixel tile.  0 / 1: t2 is the finished map. */
-    int32_t t2_parts, reserved0;
+    int32_t t2_parts, res_parts;
     const float *t2_bias;
+    /* fp32 form only: res given as res_parts > 1 partial sums [res_parts][M][CO] of the shortcut convolution (defer); the kernel
+     * adds (sum of the parts in order + res_bias) as the residual - no activation: the downsample branch has none */
+    const float *res_bias;
 } usot_pw_pair_desc;
 int usot_pw_pair_lp(void *stream, const usot_pw_pair_desc *d, int dtype);
 int usot_pw_pair_layout(int CM, int CO, int CN, int which, int32_t *row, int32_t *k0);   /* which: 0 = w3, 1 = w1 */

@@ -314,6 +314,7 @@ OPTION_VARIANTS = [{'fused_f32_sliced': False}, {'conf_tail_split': None}, {'con
                    {'stream_3x3_shapes': {(128, 128), (256, 256)}}, {'stream_1x1_shapes': {(256, 1024), (128, 512), (1024, 256), (512, 128)}},
                    # deferred split-K reduction of layer3's conv2 (summed by the following fused pair): on / off / another split
                    {'skew_towers': True}, {'batch_ds_conv2': {(961, 128, 1152): (55, 2), (1089, 128, 1152): (55, 2)}},
+                   {'defer_split_res_f32': {(961, 512, 2304): (56, 2), (1089, 512, 2304): (56, 2)}},
                    {'defer_split_f32': {}}, {'defer_split_f32': {(961, 256, 2304): (57, 4), (1089, 256, 2304): (57, 4)}},
                    {'defer_split_f32': {(961, 256, 2304): (55, 2), (1089, 256, 2304): (55, 3)}}]
 

@@ -144,6 +144,20 @@ def test_conv_deferred_reduction_feeds_the_fused_pair(tile, ks):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     y_ref = (t2_sum.cpu().double() @ w3.double().t() + b3.double() + res.cpu().double()).relu()
     assert rel_err(outs[0][0].numpy(), y_ref.numpy()) < 2e-5
+    # the RESIDUAL as deferred partial sums of the shortcut conv (res_parts / res_bias): parts in order, then the bias, no activation
+    rparts = torch.randn(3, M, CO, generator=g).to(DEV)
+    rbias = (torch.randn(CO, generator=g) * 0.1).to(DEV)
+    rsum = ((rparts[0] + rparts[1]) + rparts[2] + rbias).contiguous()
+    outs = []
+    for rr, parts in ((rparts, 3), (rsum, 0)):
+        y = torch.empty(M, CO, device=DEV); t = torch.empty(M, CN, device=DEV)
+        wsp = hip.pw_pair_f32_ws(M, Cout, CO, CN, DEV)
+        pd = hip.pw_pair_desc(t2_sum.data_ptr(), w3p.data_ptr(), b3d.data_ptr(), rr.data_ptr(), y.data_ptr(), w1p.data_ptr(), b1d.data_ptr(),
+                              t.data_ptr(), M, Cout, CO, CN, hip.ACT_RELU, wsp.data_ptr() if wsp is not None else None,
+                              res_parts=parts, res_bias=rbias.data_ptr() if parts else None)
+        hip.check(hip.lib().usot_pw_pair_f32(hip.stream(), C.byref(pd)), 'pw_pair_f32 (residual parts)')
+        outs.append((y.cpu(), t.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize('tile', [72, 73, 76])

@@ -55,6 +55,8 @@ struct PwF {
     int M, act2;
     int parts = 0;                 // > 1: t2 = `parts` partial sums [parts][M][CM] of the producing conv (usot_conv_desc.defer)
     const float *tbias = nullptr;  //      ... staged as relu(sum in part order + tbias)
+    int rparts = 0;                // > 1: res = `rparts` partial sums [rparts][M][CO] of the shortcut conv; residual = sum + rbias
+    const float *rbias = nullptr;
 };
 
 // acc[u] (u < CBW) = sum over rounds [r0, r0 + RS) of W fragment (cb0 + u, r) x the B operand rows in LDS.
@@ -144,6 +146,10 @@ __device__ __forceinline__ void pair_tail(const PwF &p, const float *Xs, float *
         for (int u = 0; u < CBW1; ++u) {
             const int cog = sl * CO + (wave * CBW1 + u) * 16 + quad * 4;
             rr[u] = mok ? *(const f32x4 *)(p.res + (long)m * COT + cog) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.rparts > 1 && mok) {       // deferred split-K reduction of the shortcut convolution: parts in order, then its bias
+                for (int q = 1; q < p.rparts; ++q) rr[u] += *(const f32x4 *)(p.res + ((long)q * p.M + m) * COT + cog);
+                rr[u] += *(const f32x4 *)(p.rbias + cog);
+            }
             bb[u] = *(const f32x4 *)(p.b3 + cog);
         }
         f32x4 acc[CBW1];
@@ -573,6 +579,9 @@ extern "C" int usot_pw_pair_f32(void *stream, const usot_pw_pair_desc *d)
           (float *)d->y, (float *)d->t, (float *)d->ws, d->M, d->act2};
     p.parts = d->t2_parts > 1 ? d->t2_parts : 0;
     p.tbias = d->t2_bias;
+    if (d->res_parts > 1 && (!d->res_bias || ((uintptr_t)d->res_bias & 15) || d->res_parts > 16)) return USOT_EINVAL;
+    p.rparts = d->res_parts > 1 ? d->res_parts : 0;
+    p.rbias = d->res_bias;
     hipStream_t s = (hipStream_t)stream;
     const bool sliced = slices(d->M, d->CM, d->CN) > 1 && d->ws;          /* no workspace: the unsliced form */
     if (d->CM == 64 && d->CO == 256 && d->CN == 64) return launch<64, 256, 64>(s, p);

@@ -428,21 +428,50 @@ class Builder:
         cur, h = p0, ph
         stages = [s0]
         t1_fused = None                               # conv1 output of this block when the previous conv3 produced it
+        O = self.opt
+
+        def pair_path(bi, c2, c3, h):
+            """How the tail of block bi is lowered: (nxt, fuse, triple, dfr) - the next 1x1 conv, whether conv3 | next-conv1 fuse into one
+            launch, whether conv2 joins that launch too, and the (tile, ksplit) of a conv2 whose reduction is deferred to the pair."""
+            h2 = c2.out_hw(h, h)[0]
+            last = bi + 1 == len(W.blocks)
+            nxt = W.neck if last else W.blocks[bi + 1][0]
+            shape = (c3.cin, c3.cout, nxt.cout)
+            m2 = n * h2 * h2
+            fuse = self.lanes == 0 and nxt.kh == 1 and (
+                (shape in O['fused_pointwise_f32'] and m2 <= O['fused_pointwise_f32_max_m']) or
+                (O['fused_f32_sliced'] and shape in O['fused_pointwise_f32_sliced_only']
+                 and hip.lib().usot_pw_pair_f32_ws_floats(m2, *shape) > 0))
+            triple = bool(fuse and O['fused_triple_f32'] and c2.kh == 3 and c2.stride == 1 and m2 <= O['fused_pointwise_f32_max_m']
+                          and (c2.cin, c3.cin, c3.cout, nxt.cout) in O['fused_triple_f32_shapes']
+                          and hip.lib().usot_pw_triple_f32_supported(c2.cin, c3.cin, c3.cout, nxt.cout))
+            dfr = O['defer_split_f32'].get((m2, c2.cout, c2.kh * c2.kw * c2.cin)) if (fuse and not triple and c2.kh == 3) else None
+            return nxt, fuse, triple, dfr
+
         for bi, (c1, c2, c3, ds) in enumerate(W.blocks):
             sc = cur
             pre_t2 = None                             # conv2's deferred partial tiles when it rode in the shortcut conv's launch
+            sc_parts, sc_bias = 0, None               # the shortcut conv's deferred partial tiles (summed by the pair's residual read)
             if t1_fused is not None:
                 t1, t1_fused = t1_fused, None
                 if ds is not None:
                     h2_ = c2.out_hw(h, h)[0]
                     dk_ = (n * h2_ * h2_, c2.cout, c2.kh * c2.kw * c2.cin)
+                    will_defer = pair_path(bi, c2, c3, h)[3] is not None       # this block's pair sums deferred partial tiles
                     bd = self.opt['batch_ds_conv2'].get(dk_) if self.lanes == 0 and self.batch else None
-                    if bd and dk_ in self.opt['defer_split_f32']:
+                    if bd and will_defer:
                         # the shortcut conv and conv2 are independent (block input / conv1's map): ONE launch, conv2's reduction deferred
                         (sc, _, _), (pre_t2, _, _) = self.conv_batch([('b%d.ds' % bi, ds, cur, n, h, h, {}),
                                                                       ('b%d.conv2' % bi, c2, t1, n, h, h, dict(defer_ks=bd[1]))], lead_tile=bd[0])
                     else:
-                        sc, _, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
+                        rk_ = (n * h2_ * h2_, ds.cout, ds.kh * ds.kw * ds.cin)
+                        rd = self.opt['defer_split_res_f32'].get(rk_) if will_defer else None
+                        if rd:
+                            # the shortcut conv's reduction rides in the pair's residual read (consumed ONLY there: the deferred-conv2 path below)
+                            sc, _, _ = self.conv_deferred('b%d.ds' % bi, ds, cur, n, h, h, tile=rd[0], ks=rd[1])
+                            sc_parts, sc_bias = rd[1], ds.b
+                        else:
+                            sc, _, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
             elif ds is not None and self.lanes < 3:   # shortcut conv shares conv1's launch
                 (sc, _, _), (t1, _, _) = self.conv_batch([('b%d.ds' % bi, ds, cur, n, h, h, {}),
                                                           ('b%d.conv1' % bi, c1, cur, n, h, h, dict(act=ACT_RELU))])
@@ -454,23 +483,13 @@ class Builder:
                 t1, _, _ = self.conv1x1('b%d.conv1' % bi, c1, cur, n, h, act=ACT_RELU)
             h2 = c2.out_hw(h, h)[0]
             last = bi + 1 == len(W.blocks)
-            nxt = W.neck if last else W.blocks[bi + 1][0]
-            shape = (c3.cin, c3.cout, nxt.cout)
             m2 = n * h2 * h2
-            O = self.opt
-            fuse = self.lanes == 0 and nxt.kh == 1 and (
-                (shape in O['fused_pointwise_f32'] and m2 <= O['fused_pointwise_f32_max_m']) or
-                (O['fused_f32_sliced'] and shape in O['fused_pointwise_f32_sliced_only']
-                 and hip.lib().usot_pw_pair_f32_ws_floats(m2, *shape) > 0))
+            nxt, fuse, triple, dfr = pair_path(bi, c2, c3, h)
             nm = 'b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1))
             act2 = ACT_NONE if last else ACT_RELU
-            if (fuse and O['fused_triple_f32'] and c2.kh == 3 and c2.stride == 1 and m2 <= O['fused_pointwise_f32_max_m']
-                    and (c2.cin, c3.cin, c3.cout, nxt.cout) in O['fused_triple_f32_shapes']
-                    and hip.lib().usot_pw_triple_f32_supported(c2.cin, c3.cin, c3.cout, nxt.cout)):
+            if triple:
                 cur, t1_fused = self.pw_triple_f32('b%d.conv2+' % bi + nm, c2, c3, nxt, t1, sc, n, h, act2=act2)
             else:
-                dk = (m2, c2.cout, c2.kh * c2.kw * c2.cin)
-                dfr = O['defer_split_f32'].get(dk) if (fuse and c2.kh == 3) else None
                 if dfr:
                     # conv2's split-K reduction rides in the pair's tile staging (DEFAULT_OPTIONS: defer_split_f32)
                     if pre_t2 is not None:
@@ -478,7 +497,8 @@ class Builder:
                     else:
                         t2, _, _ = self.conv_deferred('b%d.conv2' % bi, c2, t1, n, h, h, tile=dfr[0], ks=dfr[1])
                         parts = dfr[1]
-                    cur, t1_fused = self.pw_pair_f32(nm, c3, nxt, t2, sc, n, h2, act2=act2, t2_parts=parts, t2_bias=c2.b)
+                    cur, t1_fused = self.pw_pair_f32(nm, c3, nxt, t2, sc, n, h2, act2=act2, t2_parts=parts, t2_bias=c2.b,
+                                                     res_parts=sc_parts, res_bias=sc_bias)
                     h = h2
                     if bi in (2, 6, 12):
                         stages.append(cur)
@@ -641,7 +661,7 @@ class Builder:
         self.lp_bytes.append(2 * (m * (c2.cin + 2 * c3.cout + nxt.cout) + w2.numel() + w3.numel() + wn.numel()))
         return y, t
 
-    def pw_pair_f32(self, name, c3, nxt, t2, res, n, h, act2=ACT_RELU, t2_parts=0, t2_bias=None):
+    def pw_pair_f32(self, name, c3, nxt, t2, res, n, h, act2=ACT_RELU, t2_parts=0, t2_bias=None, res_parts=0, res_bias=None):
         """fp32: conv3 + residual + ReLU and the next block's conv1 in ONE launch (csrc/smallm_f32.hip).
         Returns (y [n,h,h,c3.cout], t [n,h,h,nxt.cout]).  t2_parts > 1: t2 holds that many partial sums of the producing
         convolution (conv_deferred); the kernel stages relu(sum + t2_bias)."""
@@ -656,9 +676,10 @@ class Builder:
         d = hip.pw_pair_desc(t2.data_ptr(), w3p.data_ptr(), c3.b.data_ptr(), res.data_ptr(), y.data_ptr(), w1p.data_ptr(),
                              nxt.b.data_ptr(), t.data_ptr(), m, c3.cin, c3.cout, nxt.cout, act2,
                              ws.data_ptr() if ws is not None else None,
-                             t2_parts=t2_parts, t2_bias=t2_bias.data_ptr() if t2_bias is not None else None)
+                             t2_parts=t2_parts, t2_bias=t2_bias.data_ptr() if t2_bias is not None else None,
+                             res_parts=res_parts, res_bias=res_bias.data_ptr() if res_bias is not None else None)
         hip.check(hip.lib().usot_plan_add_pw_pair(self.plan.h, C.byref(d), 2), 'plan_add_pw_pair(f32) ' + name)
-        self.plan.keep += [t2, res, w3p, w1p, c3.b, nxt.b, ws, t2_bias]
+        self.plan.keep += [t2, res, w3p, w1p, c3.b, nxt.b, ws, t2_bias, res_bias]
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
         self.f32_bytes.append(4 * (m * (c3.cin + 2 * c3.cout + nxt.cout) + c3.cout * c3.cin + nxt.cout * c3.cout))
         return y, t
@@ -1128,6 +1149,11 @@ DEFAULT_OPTIONS = {
     # +33 us per frame - tower0's 160 workgroups behind Conf_Fusion's 1 264 open another round of 36 k-steps (143.6 vs 110.9 us), and
     # the memory tower's last level alone (80 workgroups) takes the same 30 us as a three-tower level (per-op spans, ks_ab.py)
     'skew_towers': False,
+    # {(M, Cout, K) of a block's 3x3 shortcut conv: (tile, ksplit)}: the same for the SHORTCUT branch of a block whose conv2 is deferred - the
+    # pair adds (sum of the parts + the shortcut's bias) as its residual
+    # EMPTY by default: measured slower ((961, 512, 2304): (55, 2) 858 vs 834 us of graph, (56, 2) 836.5, (55, 3) 843): the 3 x 3 / stride-2
+    # shortcut conv of layer2.0 already fills one round, a second workgroup per CU stretches every k-step by more than the halved loop saves
+    'defer_split_res_f32': {},
     'defer_split_f32': {(961, 256, 2304): (55, 2), (1089, 256, 2304): (55, 2), (961, 128, 1152): (53, 2), (1089, 128, 1152): (53, 2)},
 }
 ENV_SWITCHES = {      # environment variable -> (option, parser)

@@ -67,7 +67,7 @@ class PwPairDesc(C.Structure):
     _fields_ = [('t2', C.c_void_p), ('w3p', C.c_void_p), ('res', C.c_void_p), ('w1', C.c_void_p),
                 ('b3', C.c_void_p), ('b1', C.c_void_p), ('y', C.c_void_p), ('t', C.c_void_p),
                 ('M', C.c_int32), ('CM', C.c_int32), ('CO', C.c_int32), ('CN', C.c_int32), ('act2', C.c_int32),
-                ('ws', C.c_void_p), ('t2_parts', C.c_int32), ('reserved0', C.c_int32), ('t2_bias', C.c_void_p)]
+                ('ws', C.c_void_p), ('t2_parts', C.c_int32), ('res_parts', C.c_int32), ('t2_bias', C.c_void_p), ('res_bias', C.c_void_p)]
 
 
 class BneckDesc(C.Structure):
@@ -650,12 +650,13 @@ def pw_pair_supported(cm, co, cn):
     return bool(lib().usot_pw_pair_supported(int(cm), int(co), int(cn)))
 
 
-def pw_pair_desc(t2, w3p, b3, res, y, w1, b1, t, M, CM, CO, CN, act2, ws=None, t2_parts=0, t2_bias=None):
+def pw_pair_desc(t2, w3p, b3, res, y, w1, b1, t, M, CM, CO, CN, act2, ws=None, t2_parts=0, t2_bias=None, res_parts=0, res_bias=None):
     d = PwPairDesc()
     d.t2, d.w3p, d.res, d.w1, d.b3, d.b1, d.y, d.t = t2, w3p, res, w1, b3, b1, y, t
     d.M, d.CM, d.CO, d.CN, d.act2 = M, CM, CO, CN, act2
     d.ws = ws
     d.t2_parts, d.t2_bias = t2_parts, t2_bias
+    d.res_parts, d.res_bias = res_parts, res_bias
     return d
 
 
