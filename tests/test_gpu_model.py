@@ -394,6 +394,26 @@ def test_backbone_bf16_batch64_tracks_fp32(net, oracle_sd, lp_options):
     assert np.abs(alone[0] - got[21]).max() <= (5e-2 if fused_first else 2e-2) * np.abs(got[21]).max()
 
 
+@pytest.mark.parametrize('chains', [dict(lp_chains=2), dict(lp_chains=2, lp_chain_skew=0), dict(lp_chains=4, lp_chain_skew=3),
+                                    dict(lp_chains=2, lp_chains_from=3)], ids=lambda d: '_'.join('%s%s' % kv for kv in d.items()))
+def test_backbone_lp_chains_are_bitwise_the_single_chain(chains):
+    """engine option `lp_chains`: layer3 (or the blocks from lp_chains_from on) of the batched low-precision backbone as
+    independent batch slices on parallel graph branches.  Every kernel computes a pixel from that pixel's crop alone and the
+    kernels are chosen as for the whole batch, so the features must equal the one-chain plan's bit for bit."""
+    x = t(synth.crop(43, 64, 255)).to(DEV)
+    outs = []
+    for opts in ({}, chains):
+        m = USOT()
+        m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True), strict=True)
+        m = m.eval().to(DEV)
+        m.engine_options['options'] = opts
+        y = m.engine.features_bf16(x)
+        y = m.engine.features_bf16(x).clone()             # second call: the captured graph with its branches
+        outs.append((y, next(v for k, v in m.engine._feat.items() if k[1] == 64)['p3'].clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])            # layer3's output map too (the memory path reads it)
+
+
 def test_head_pieces_vs_reference_golden(net, gold_model):
     """a5-a9 piece by piece on the GPU against the reference's own module outputs (golden_model.npz
     `enc/*`, `groupdw/*`, `conf_fusion/out`, `tower/bbox`: matrix encoders, GroupDW, Conf_Fusion and the

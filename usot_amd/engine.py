@@ -251,6 +251,19 @@ class Builder:
         self.geoms = []         # full geometry per conv, for the tuner
 
     def buf(self, *shape, dtype=torch.float32):
+        ch = getattr(self, '_chain', None)
+        if ch is not None:
+            # chain mode (backbone_bf16, 'lp_chains'): this builder pass works on slice `idx` of `nch` equal batch slices; the
+            # k-th buffer every chain asks for is ONE full-batch tensor (whichever chain gets there first allocates it)
+            idx, nch, store, cursor = ch
+            k = cursor[idx]
+            cursor[idx] += 1
+            if k == len(store):
+                store.append(torch.empty((shape[0] * nch,) + tuple(shape[1:]), device=self.dev, dtype=dtype))
+                self.plan.keep.append(store[k])
+            full = store[k]
+            assert full.shape[0] == shape[0] * nch and tuple(full.shape[1:]) == tuple(shape[1:]) and full.dtype == dtype, (full.shape, shape)
+            return full[idx * shape[0]:(idx + 1) * shape[0]]
         t = torch.empty(shape, device=self.dev, dtype=dtype)
         self.plan.keep.append(t)
         return t
@@ -532,11 +545,12 @@ class Builder:
                 self.buf(n, oh, ow, cout, dtype=torch.float32 if out_f32 else dtype)
         wb = pc.w_lp(dtype)
         k = pc.kh * pc.kw * pc.cin
+        rs = getattr(self, '_nscale', 1)      # chain mode: kernels are chosen as for the whole batch
         if (tile == 0 and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and tuple(pc.pad) == (1, 1) and tuple(pc.dil) == (1, 1)
                 and groups == 1 and not out_f32 and res is None and cout == pc.cout and act in (ACT_NONE, ACT_RELU)
                 and act_split == 0 and (pc.cin, cout) in self.opt['halo_3x3_lp']
                 and hip.lib().usot_conv3x3_halo_supported(pc.cin, cout)
-                and n * ((h + 15) // 16) * ((w + 15) // 16) >= 256):
+                and rs * n * ((h + 15) // 16) * ((w + 15) // 16) >= 256):
             hip.check(hip.lib().usot_plan_add_conv3x3_halo(self.plan.h, hip.ptr(x), hip.ptr(wb), hip.ptr(pc.b), hip.ptr(y), n, h, w,
                                                            pc.cin, cout, act, 1 if dtype == torch.float16 else 0),
                       'plan_add_conv3x3_halo ' + name)
@@ -547,7 +561,7 @@ class Builder:
         if (tile == 0 and pc.kh == 1 and pc.kw == 1 and pc.stride == 1 and groups == 1 and not out_f32 and cout == pc.cout
                 and act in (ACT_NONE, ACT_RELU) and act_split == 0 and (k, cout) in self.opt['panel_1x1_lp']
                 and hip.lib().usot_pw_panel_supported(k, cout)
-                and n * oh * ow >= self.opt['panel_min_panels'] * hip.lib().usot_pw_panel_min_pixels(k, cout)):
+                and rs * n * oh * ow >= self.opt['panel_min_panels'] * hip.lib().usot_pw_panel_min_pixels(k, cout)):
             hip.check(hip.lib().usot_plan_add_pw_panel(self.plan.h, hip.ptr(x), hip.ptr(wb), hip.ptr(pc.b),
                                                        hip.ptr(res) if res is not None else None, hip.ptr(y), n * oh * ow, k, cout,
                                                        act, 1 if dtype == torch.float16 else 0), 'plan_add_pw_panel ' + name)
@@ -558,7 +572,7 @@ class Builder:
         if (tile == 0 and pc.kh == 3 and pc.kw == 3 and groups == 1 and not out_f32 and cout == pc.cout and res is None
                 and act in (ACT_NONE, ACT_RELU) and act_split == 0 and (pc.cin, cout) in self.opt['kstream_3x3_lp']
                 and pc.pad[0] == pc.pad[1] and pc.dil[0] == pc.dil[1] and pc.pad[0] <= pc.dil[0] and pc.stride in (1, 2)
-                and hip.lib().usot_conv_kstream_supported(pc.cin, cout, 3, 3) and n * oh * ow >= self.opt['panel_min_panels'] * 256):
+                and hip.lib().usot_conv_kstream_supported(pc.cin, cout, 3, 3) and rs * n * oh * ow >= self.opt['panel_min_panels'] * 256):
             hip.check(hip.lib().usot_plan_add_conv_kstream(self.plan.h, hip.ptr(x), hip.ptr(wb), hip.ptr(pc.b), hip.ptr(y), n, h, w,
                                                            pc.cin, cout, pc.stride, pc.pad[0], pc.dil[0], act,
                                                            1 if dtype == torch.float16 else 0), 'plan_add_conv_kstream ' + name)
@@ -568,7 +582,7 @@ class Builder:
             return y, oh, ow
         if (tile == 0 and pc.kh == 1 and pc.kw == 1 and pc.stride == 1 and groups == 1 and not out_f32 and cout == pc.cout
                 and res is None and act in (ACT_NONE, ACT_RELU) and act_split == 0 and (k, cout) in self.opt['kstream_1x1_lp']
-                and hip.lib().usot_pw_kstream_supported(k, cout) and n * oh * ow >= self.opt['panel_min_panels'] * 256):
+                and hip.lib().usot_pw_kstream_supported(k, cout) and rs * n * oh * ow >= self.opt['panel_min_panels'] * 256):
             hip.check(hip.lib().usot_plan_add_pw_kstream(self.plan.h, hip.ptr(x), hip.ptr(wb), hip.ptr(pc.b), hip.ptr(y), n * oh * ow,
                                                          k, cout, act, 1 if dtype == torch.float16 else 0), 'plan_add_pw_kstream ' + name)
             self.plan.keep += [x, wb, pc.b]
@@ -576,7 +590,7 @@ class Builder:
             self.lp_bytes.append(2 * (n * h * w * pc.cin + n * oh * ow * cout + cout * k))
             return y, oh, ow
         if tile == 0:
-            tile = LP_TUNING.get((n * oh * ow, cout, k), 0)
+            tile = LP_TUNING.get((rs * n * oh * ow, cout, k), 0)
         if hasattr(self, 'lp_geoms'):       # scripts/tune_lp.py collects the shapes this way
             self.lp_geoms.append(dict(name=name, N=n, H=h, W=w, Cin=pc.cin, OH=oh, OW=ow, Cout=cout, KH=pc.kh, KW=pc.kw,
                                       stride=pc.stride, pad=pc.pad, dil=pc.dil, has_res=res is not None,
@@ -828,30 +842,86 @@ class Builder:
         self.plan.keep += [wf, wb]
         self.plan.keep += [x]
         cur, h = p0, ph
-        fuse = getattr(self, 'fuse_pointwise', True)
-        t1 = None                                    # the block's conv1 output when the previous launch made it
         nb = len(W.blocks)
-        for bi, (c1, c2, c3, ds) in enumerate(W.blocks):
+        nch, b0 = int(self.opt['lp_chains'] or 0), int(self.opt['lp_chains_from'])
+        out = {}
+        if nch < 2 or nch > 4 or self.lanes or n % nch or n // nch < self.opt['lp_chains_min_batch'] or not 0 < b0 < nb:
+            for _ in self._lp_blocks(out, cur, None, h, n, 0, nb, dtype, neck_f32):
+                pass
+            self.p3 = out['cur']
+            return out['xf'], out['h']
+        # 'lp_chains': from block b0 on (layer3: MFMA-bound 3x3 convs alternating with HBM-bound 1x1 convs) the batch runs as
+        # `nch` independent slices on parallel graph branches, chain i released `i * lp_chain_skew` launches of chain 0 late, so
+        # that one chain's matrix-pipe phase meets another's HBM phase
+        for _ in self._lp_blocks(out, cur, None, h, n, 0, b0, dtype, neck_f32):
+            pass
+        cur, t1, h = out['cur'], out['t1'], out['h']
+        nc = n // nch
+        store, cursor = [], [0] * nch
+        outs = [dict() for _ in range(nch)]
+        gens = [self._lp_blocks(outs[ci], cur[ci * nc:(ci + 1) * nc], t1[ci * nc:(ci + 1) * nc] if t1 is not None else None,
+                                h, nc, b0, nb, dtype, neck_f32) for ci in range(nch)]
+
+        def advance(ci, k=None):
+            self._chain, self._nscale = (ci, nch, store, cursor), nch
+            try:
+                while k is None or k > 0:
+                    next(gens[ci])
+                    k = None if k is None else k - 1
+            except StopIteration:
+                pass
+            finally:
+                self._chain, self._nscale = None, 1
+        skew = int(self.opt['lp_chain_skew'])
+        for ci in range(1, nch):
+            advance(0, skew)
+            self.plan.fork(ci)                       # lane ci waits for what lane 0 holds so far, then runs its whole chain
+            advance(ci)
+            self.plan.fork(0)                        # back to lane 0 (no dependency)
+        advance(0)
+        for ci in range(1, nch):
+            self.plan.join(ci)
+
+        def whole(t):                                # the full-batch tensor a chain's result is a slice of
+            return next(f for f in store if f.data_ptr() == t.data_ptr())
+        self.p3 = whole(outs[0]['cur'])
+        return whole(outs[0]['xf']), outs[0]['h']
+
+    def _lp_blocks(self, out, cur, t1, h, n, b_from, b_to, dtype, neck_f32):
+        """Generator: records bottlenecks [b_from, b_to) of the low-precision backbone (and the neck when b_to is the last block)
+        for `n` crops, yielding after every launch; t1 = conv1 output of block b_from when the previous launch made it.
+        Leaves out['cur'] (block output), out['t1'], out['h'] and, after the neck, out['xf']."""
+        W = self.W
+        fuse = getattr(self, 'fuse_pointwise', True)
+        nb = len(W.blocks)
+        rs = getattr(self, '_nscale', 1)
+        for bi in range(b_from, b_to):
+            c1, c2, c3, ds = W.blocks[bi]
             sc = cur
             nx1 = W.blocks[bi + 1][0] if bi + 1 < nb else None
             if (fuse and self.opt['bneck_first_lp'] and t1 is None and ds is not None and nx1 is not None
                     and ds.kh == 1 and ds.stride == 1 and c1.kh == 1 and nx1.kh == 1
                     and c2.kh == 3 and c2.stride == 1 and tuple(c2.pad) == (1, 1) and tuple(c2.dil) == (1, 1)
                     and hip.lib().usot_bneck_first_supported(c1.cin, c1.cout, c3.cout, nx1.cout)
-                    and n * ((h + 7) // 8) * ((h + 15) // 16) >= self.opt['bneck_first_min_tiles']):
+                    and rs * n * ((h + 7) // 8) * ((h + 15) // 16) >= self.opt['bneck_first_min_tiles']):
                 cur, t1 = self.bneck_first('b%d+b%d.conv1' % (bi, bi + 1), c1, c2, c3, ds, nx1, cur, n, h, dtype)
+                yield
                 continue
             if (fuse and self.opt['bneck_tail_lp'] and t1 is not None and ds is None and nx1 is not None and nx1.kh == 1
                     and nx1.stride == 1 and c2.kh == 3 and c2.stride == 1 and tuple(c2.pad) == (1, 1) and tuple(c2.dil) == (1, 1)
                     and c2.cin == 64 and hip.lib().usot_bneck_tail_supported(c2.cout, c3.cout, nx1.cout)
-                    and n * ((h + 7) // 8) * ((h + 15) // 16) >= self.opt['bneck_first_min_tiles']):
+                    and rs * n * ((h + 7) // 8) * ((h + 15) // 16) >= self.opt['bneck_first_min_tiles']):
                 cur, t1 = self.bneck_tail('b%d.conv2+conv3+b%d.conv1' % (bi, bi + 1), c2, c3, nx1, t1, cur, n, h, dtype)
+                yield
                 continue
             if ds is not None:
                 sc, _, _ = self.conv_bf16('b%d.ds' % bi, ds, cur, n, h, h, dtype=dtype)
+                yield
             if t1 is None:
                 t1, _, _ = self.conv_bf16('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU, dtype=dtype)
+                yield
             t2, h2, _ = self.conv_bf16('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU, dtype=dtype)
+            yield
             # conv3 + residual + ReLU shares a launch with the NEXT 1x1 conv (the following block's conv1, or the
             # neck after the last block): the 4x-wide map is written once and not read back
             last = bi + 1 == nb
@@ -859,7 +929,7 @@ class Builder:
             nm = 'b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1))
             if (fuse and nxt is not None and nxt.kh == 1 and (c3.cin, c3.cout, nxt.cout) in self.opt['panel_pair_lp']
                     and hip.lib().usot_pw_panel_pair_supported(c3.cin, c3.cout, nxt.cout)
-                    and n * h2 * h2 >= self.opt['panel_min_panels'] * hip.lib().usot_pw_panel_pixels(c3.cin, c3.cout, nxt.cout)):
+                    and rs * n * h2 * h2 >= self.opt['panel_min_panels'] * hip.lib().usot_pw_panel_pixels(c3.cin, c3.cout, nxt.cout)):
                 cur, t1 = self.pw_panel_pair(nm, c3, nxt, t2, sc, n, h2, ACT_NONE if last else ACT_RELU, dtype)
             elif fuse and nxt is not None and (c3.cin, c3.cout, nxt.cout) in self.opt['fused_pointwise_lp']:
                 cur, t1 = self.pw_pair('b%d.conv3+%s' % (bi, 'neck' if last else 'b%d.conv1' % (bi + 1)), c3, nxt, t2, sc, n, h2,
@@ -867,12 +937,16 @@ class Builder:
             else:
                 cur, _, _ = self.conv_bf16('b%d.conv3' % bi, c3, t2, n, h2, h2, act=ACT_RELU, res=sc, dtype=dtype)
                 t1 = None
+            yield
             h = h2
-        self.p3 = cur
+        out.update(cur=cur, t1=t1, h=h)
+        if b_to < nb:
+            return
         if t1 is not None:
-            return t1, h                             # the neck rode along with the last conv3
-        xf, _, _ = self.conv_bf16('neck', W.neck, cur, n, h, h, dtype=dtype, out_f32=neck_f32)
-        return xf, h
+            out['xf'] = t1                           # the neck rode along with the last conv3
+            return
+        out['xf'], _, _ = self.conv_bf16('neck', W.neck, cur, n, h, h, dtype=dtype, out_f32=neck_f32)
+        yield
 
     # ---- a5 template side: zf NHWC [n,7,7,256] -> 3 maps NHWC [n,hk,wk,cout]
     def encode_kernel(self, zf, n, cout, tag):
@@ -1059,6 +1133,12 @@ DEFAULT_OPTIONS = {
     # conv3 89 -> 66 us, layer1's 1x1 shortcut 50 -> 38 at batch 64
     'panel_1x1_lp': {(256, 1024), (128, 512), (64, 256)},
     'panel_min_panels': 192,
+    # layer3 (from block lp_chains_from on) as lp_chains independent batch slices on parallel graph branches, chain i released
+    # i * lp_chain_skew launches of chain 0 late (backbone_bf16); 0 = one chain
+    'lp_chains': 0,
+    'lp_chains_from': 7,
+    'lp_chain_skew': 2,
+    'lp_chains_min_batch': 8,
     # layer1's FIRST bottleneck (1x1 downsample) + the next block's conv1 as ONE launch of the batched low-precision backbone
     # (csrc/bneck_lp.hip: t1 / t2 stay in LDS, the shortcut conv rides on conv3's k axis) when the launch has at least
     # bneck_first_min_tiles 8 x 16 tiles (two per CU)
