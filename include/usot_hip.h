@@ -79,6 +79,10 @@ typedef struct usot_conv_desc {
                        * to `ws` (plain stores, no tickets) and applies NEITHER bias NOR activation; `y` is not written.  The consumer
                        * sums the slabs, adds the bias and activates while it stages its input (usot_pw_pair_desc.t2_parts).  A kernel
                        * boundary is the synchronisation: no in-launch combine (4-6 us on the tail of a 20 us launch), no second launch */
+    const float *w_scale;   /* w_frag == 2 (the split-fp16 tiles, usot_conv_tile_wfrag(tile) == 2): `w` holds every filter row as hi + lo
+                       * fp16 of (row x a power of two) - per k-tile of 64: 64 hi halves then 64 lo halves, the 256 bytes of the fp32 row
+                       * segment - and w_scale[groups][Cout] = 1 / (that power of two x 8) multiplies the finished sums (8 = the
+                       * activation scale the kernel applies before it splits them).  NULL otherwise. */
 } usot_conv_desc;
 
 int usot_conv2d_f32(void *stream, const usot_conv_desc *d);
@@ -97,7 +101,7 @@ int usot_plan_add_thin_conv(void *plan, const usot_conv_desc *d, int n);
 int usot_conv_tile_count(void);
 int usot_conv_tile_info(int tile, int *bm, int *bn);           /* tile ids are 1..count */
 int usot_conv_tile_name(int tile, char *buf, int len);         /* kernel symbol of the tile */
-int usot_conv_tile_wfrag(int tile);                            /* 1: the tile streams its filters in fragment order */
+int usot_conv_tile_wfrag(int tile);                            /* 1: the tile streams its filters in fragment order; 2: split-fp16 bank + w_scale */
 /* weight-stationary tiles (filters held in registers, k split over the 8 waves of a workgroup) serve ONE K each: returns it
  * (0: the tile takes any K); *kpanel = the multiple Cin must have (128 / 256).  They also need Cout % 32 == 0, ksplit == 1. */
 int usot_conv_tile_kreq(int tile, int *kpanel);

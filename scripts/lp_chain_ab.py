@@ -21,10 +21,8 @@ for c in cfgs:
         for ent in c.split('+'):
             k, v = ent.split('=')
             opts[k] = eval(v)
-    saved = dict(engine.OPTIONS)
-    engine.OPTIONS.update(opts)
     model, _ = bench.build_model(0, 1, dev)
-    engine.OPTIONS.clear(); engine.OPTIONS.update(saved)
+    model.engine_options['options'] = opts
     e = model.engine
     for _ in range(3):
         y = e.features_bf16(x, dtype=dt)

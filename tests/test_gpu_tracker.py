@@ -240,6 +240,7 @@ def test_session_cached_encodings_equal_reencoding(net):
     sess, crops = _open(net, 9)
     for i in range(4):
         sess.frame(crops[i % 4], [0, min(i, 1), 0, min(i, 2), 0], (63.5, 63.5))
+    sess.flush()                                     # engine option 'defer_append': the last frame's row is written by the NEXT graph
     torch.cuda.synchronize()
     rows = 2 + sess.n
     from usot_amd.engine import Builder
@@ -252,6 +253,42 @@ def test_session_cached_encodings_equal_reencoding(net):
     for g in range(3):
         a, b = sess.bank_enc[g][:rows].cpu().numpy(), enc[g].cpu().numpy()
         assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
+
+
+def test_deferred_append_equals_the_append_behind_the_tag():
+    """engine option `defer_append` (default on): frame t's bank append (encode the pooled feature, scatter it and its three
+    encodings) runs on a side branch at the start of frame t + 1's graph instead of behind frame t's result tag.  Same kernels,
+    same operands: results of a frame sequence whose picks always include the newest row, and the bank itself after flush(),
+    must equal the undeferred session's bit for bit — also across a regrow of the bank and an append_feature() from outside."""
+    from usot_amd.model import USOT
+    res = {}
+    for defer in (False, True):
+        m = USOT()
+        m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True), strict=True)
+        m = m.eval().cuda()
+        m.engine_options['options'] = {'defer_append': defer}
+        m.engine.session_capacity = 8                # rows 0-1 + 5 memories, then the bank regrows (twice over 14 frames)
+        sess, crops = _open(m, 11)
+        assert sess.defer == defer
+        outs = []
+        for i in range(14):
+            n = sess.n
+            picks = [max(n - 1 - k, 0) for k in (3, 2, 1, 0, 0)]      # the newest memory (n - 1) is always among them
+            outs.append(sess.frame(crops[i % 4], picks, (60.0 + i, 58.0)))
+            if i == 6:
+                sess.append_feature(sess.memory_feature(1).clone())
+        last = sess.memory_feature(sess.n - 1).clone()               # flushes
+        sess.flush()
+        torch.cuda.synchronize()
+        rows = 2 + sess.n
+        res[defer] = (np.array(outs), last.cpu().numpy(), sess.bank[:rows].cpu().numpy(),
+                      [b[:rows].cpu().numpy() for b in sess.bank_enc], sess.n)
+    assert res[False][4] == res[True][4] == 16
+    np.testing.assert_array_equal(res[False][0], res[True][0])
+    np.testing.assert_array_equal(res[False][1], res[True][1])
+    np.testing.assert_array_equal(res[False][2], res[True][2])
+    for a, b in zip(res[False][3], res[True][3]):
+        np.testing.assert_array_equal(a, b)
 
 
 def test_memory_features_is_a_view_of_the_bank_and_paths_can_switch(net):

@@ -33,6 +33,8 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 struct ConvK {
     const float *x, *w, *bias, *res;
@@ -48,6 +50,7 @@ struct ConvK {
     int M, K, KT, cchunks, MT, NT, P;   // P = OH*OW
     int vec_store;
     int pr;                             // weight-stationary tiles: pixel ranges per (group, 32-channel block)
+    const float *wscale;                // split-fp16 tiles (PF = 4): 1 / (filter row scale x activation scale) per output channel
 };
 
 // Up to four convolutions of DIFFERENT geometry in one launch (same tile shape): the shortcut
@@ -717,6 +720,18 @@ __global__ __launch_bounds__(256 * KSW) void conv_igemm_f32_v2(const ConvBatch b
 // (USOT_V3_SWZ builds: second launch bound = waves per SIMD the register allocation must leave room for)
 // PF = rounds (16 k each) a consumer's fragment reads run ahead of their MFMAs: 1 = two fragment slots; 2 = one slot per round
 // of the k-tile (BK = 64), reads issued two rounds = 16 MFMAs ahead and pinned there (sched_barrier)
+// PF = 4 (round 5): SPLIT-fp16 arithmetic.  Every fp32 operand is carried as hi + lo, two fp16 numbers (22 significant bits:
+// hi = fp16(s v), lo = fp16(s v - hi), s a power of two that puts the tensor near the top of fp16's range), and a product
+// w x is formed as w_lo x_hi + w_hi x_lo + w_hi x_hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation - three 16-cycle MFMAs
+// per 32 k where the fp32 MFMA needs eight 32-cycle ones (5.3 x less matrix-pipe time), the dropped w_lo x_lo term is 2^-22 of
+// the product.  Filters arrive pre-split from the host (engine.py: PackedConv.w_split16 - per output row a power-of-two scale,
+// each k-tile of 64 stored as 64 hi halves + 64 lo halves = the 256 bytes of the fp32 row segment, so the producers move them
+// unchanged); activations are split by the PRODUCER waves as they stage a tile (x 8, two ds_write_b64 per four values: VALU
+// of a sibling wave costs the MFMA waves nothing).  An LDS row is [64 hi | 64 lo]: the consumers' four 16-byte fragment reads
+// per row and k-tile are the fp32 kernel's (rounds 0 / 1 = hi of k 0-31 / 32-63, rounds 2 / 3 = lo).  The finished sums are
+// multiplied by wscale[co] = 1 / (row scale x 8) (exact: powers of two) before anything else sees them.  Range contract:
+// |activation| < 8 188 (fp16 overflow above that shows as inf / nan in the output, never silently); accuracy: within the
+// 1e-4 bar of the fp32 path and as close to float64 as it (tests/test_gpu_model.py, tests/golden/f64_gate.py).
 template <int BM, int BN, int WM, int WN, int BK, int D = 1, int NPW = 4, int PF = 1>
 #ifdef USOT_V3_SWZ
 __global__ __launch_bounds__(64 * WM * WN + 64 * NPW, (BM * BN <= 32 * 64) ? (4 + NPW) / 2 : 1) void conv_igemm_f32_v3(const ConvBatch bt)
@@ -741,6 +756,8 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 consumer wavefronts");
     constexpr int CT = 64 * WM * WN;              // consumer threads; the producers follow
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr bool H16 = PF == 4;                 // split-fp16 arithmetic (above)
+    static_assert(!H16 || BK == 64, "split-fp16 rows are 64 hi + 64 lo halves");
     // LDS rows.  BK = 64: a row is 256 B = one bank row, UNPADDED, 16-byte chunk c of tile row `row` stored at chunk
     // c ^ (row & 15).  ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md
     // LDS table): with the former 4-float row pad, lane (l15, quad) hit 16-byte slot (l15 + quad) mod 16 and every group had
@@ -748,7 +765,7 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     // slots of a group are (4 r) ^ quad ^ l15: {0-3,12-15} ^ 0 and {4-11} ^ 1 - disjoint in every group; the producers' 8-lane
     // ds_write_b128 groups cover 8 consecutive chunks of one row, still 8 distinct slots.  BK = 32 keeps the padded rows.
 #ifdef USOT_V3_SWZ        // measured, round 5: conflict-free (SQ_LDS_BANK_CONFLICT 0) and SLOWER - frame graph 871 vs 849 us on the same box
-    constexpr bool SWZ = BK == 64;   // (one more v_xor per fragment read, 78 -> 80 VGPRs + a spill on the 32 x 64 tile); kept buildable
+    constexpr bool SWZ = BK == 64 && !H16;   // (one more v_xor per fragment read, 78 -> 80 VGPRs + a spill on the 32 x 64 tile); kept buildable
 #else
     constexpr bool SWZ = false;
 #endif
@@ -856,8 +873,22 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
             const int kcs = (SWZ ? (kc ^ (lr & 15)) : kc) * 4;
 #pragma unroll
             for (int i = 0; i < XI; ++i)
-                if (BM % RPP == 0 || lr + RPP * i < BM)
-                    *(f32x4 *)(sX + (lr + RPP * i) * LD + kcs) = xz[d][i] ? xr[d][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (BM % RPP == 0 || lr + RPP * i < BM) {
+                    if constexpr (H16) {
+                        // hi = fp16(8 x), lo = fp16(8 x - hi): halves kc*4 .. kc*4+3 of the row's hi plane and of its lo plane
+                        const f32x4 v = (xz[d][i] ? xr[d][i] : f32x4{0.f, 0.f, 0.f, 0.f}) * 8.0f;
+                        const uint32_t hi0 = usot_pack2_lp<true>(v[0], v[1]), hi1 = usot_pack2_lp<true>(v[2], v[3]);
+                        const usot_f16x2 h0 = __builtin_bit_cast(usot_f16x2, hi0), h1 = __builtin_bit_cast(usot_f16x2, hi1);
+                        const uint32_t lo0 = usot_pack2_lp<true>(v[0] - (float)h0[0], v[1] - (float)h0[1]);
+                        const uint32_t lo1 = usot_pack2_lp<true>(v[2] - (float)h1[0], v[3] - (float)h1[1]);
+                        const u32x2_t hi = {hi0, hi1}, lo = {lo0, lo1};
+                        char *row = (char *)(sX + (lr + RPP * i) * LD);
+                        *(u32x2_t *)(row + kc * 8) = hi;
+                        *(u32x2_t *)(row + 128 + kc * 8) = lo;
+                    } else {
+                        *(f32x4 *)(sX + (lr + RPP * i) * LD + kcs) = xz[d][i] ? xr[d][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
 #if !defined(USOT_ABL_NOW) && !defined(USOT_ABL_NOWSTORE)
 #pragma unroll
             for (int i = 0; i < WI; ++i)
@@ -942,6 +973,30 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     const int swz = SWZ ? (quad ^ l15) * 4 : 0;     // one v_xor per round instead of four live offsets (80-VGPR budget: 2 workgroups / CU)
     constexpr int NSLOT = PF >= 2 ? NR : 2;
     static_assert(PF == 1 || (PF >= 2 && NR == 4), "PF >= 2 needs BK = 64");
+    // split-fp16: the three products of one 32-k step on the blocks of this wave (slot ks = hi halves of k-step ks, slot ks + 2 = lo);
+    // smallest terms first; a wave with a single block keeps the two cross terms on a second accumulator (no dependent chain of three)
+    auto mma_h = [&](f32x4 (&a)[TN][TM], f32x4 &a2, const f32x4 (&whi)[TN], const f32x4 (&wlo)[TN], const f32x4 (&xhi)[TM], const f32x4 (&xlo)[TM], bool first) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        auto h = [](const f32x4 &v) { return __builtin_bit_cast(f16x8_t, v); };
+        if constexpr (TN * TM == 1) {
+            a2      = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(wlo[0]), h(xhi[0]), first ? zero : a2, 0, 0, 0);
+            a[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(whi[0]), h(xhi[0]), first ? zero : a[0][0], 0, 0, 0);
+            a2      = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(whi[0]), h(xlo[0]), a2, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) a[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(wlo[i]), h(xhi[j]), first ? zero : a[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) a[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(whi[i]), h(xlo[j]), a[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) a[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(whi[i]), h(xhi[j]), a[i][j], 0, 0, 0);
+        }
+    };
     f32x4 fw[NSLOT][TN], fx[NSLOT][TM];
     auto read_frags = [&](int st, int r, int slot) {
 #ifdef USOT_ABL_NOREAD
@@ -992,11 +1047,16 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     // other work is left to hide it.  (vectorised NHWC stores without split-K only.)
     const bool pre = p.vec_store && p.ksplit == 1;
     f32x4 pb[TN], pr[TN][TM];
+    f32x4 psc[H16 ? TN : 1];                      // split-fp16: this lane's four output-channel scales per block, fetched up front too
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
         const int co = bn0 + (wn * TN + i) * 16 + quad * 4;
         const bool cok = pre && co + 3 < p.Cout;
         pb[i] = (cok && p.bias) ? *(const f32x4 *)(p.bias + (long)g * p.b_gs + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (H16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) psc[i][e] = co + e < p.Cout ? p.wscale[(long)g * p.Cout + co + e] : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int m = bm0 + (wm * TM + j) * 16 + l15;
@@ -1039,7 +1099,9 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     auto await_slot = [&](auto sc, auto nc) { await_(fw[decltype(sc)::value], fx[decltype(sc)::value], nc); };
     using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>;
     using R2 = std::integral_constant<int, 2>; using R3 = std::integral_constant<int, 3>;
-    if constexpr (PF == 3) {
+    if constexpr (H16) {
+        if (nt > 0) { read_frags(0, 0, 0); read_frags(0, 2, 2); read_frags(0, 1, 1); read_frags(0, 3, 3); }
+    } else if constexpr (PF == 3) {
         if (nt > 0) { aread(0, R0{}, R0{}); aread(0, R1{}, R1{}); }
     } else {
         if (nt > 0) read_frags(0, 0, 0);
@@ -1050,6 +1112,20 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
         const int st1 = st == 2 ? 0 : st + 1;
         USOT_STAMP(0, t);
         flush();                                      // the previous k-tile's block (zeros at t = 0)
+        if constexpr (H16) {
+            // tile t + 1 is complete in its stage since the barrier that ended step t - 1 (the producers run two tiles ahead): its
+            // fragments are fetched as soon as a slot pair is free
+            const bool more = t + 1 < nt;
+            mma_h(acc, acc2, fw[0], fw[2], fx[0], fx[2], true);
+            if (more) { read_frags(st1, 0, 0); read_frags(st1, 2, 2); }
+            mma_h(acc, acc2, fw[1], fw[3], fx[1], fx[3], false);
+            if (more) { read_frags(st1, 1, 1); read_frags(st1, 3, 3); }
+            st = st1;
+            USOT_STAMP(1, t);
+            __syncthreads();
+            USOT_STAMP(2, t);
+            continue;
+        }
         if constexpr (PF == 3) {
             constexpr int RPR = TN + TM;              // reads per round
             using W2 = std::integral_constant<int, 2 * RPR>;
@@ -1107,6 +1183,13 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = tot[i][j].get();
+    if constexpr (H16) {
+        // back to the unscaled sums (powers of two: exact) before the split-K slabs, the deferred reduction or the epilogue see them
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] *= psc[i];
+    }
 
     if (p.ksplit > 1) {
 #pragma unroll
@@ -2137,6 +2220,7 @@ struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int t
 #define TILES(nst, rps) { 32, 32, 64, 3, 1, conv_wstat_f32<nst, rps>, 512, 2, 1, 0, nst, rps }
 #define TILE12(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw>, 64 * wm * wn + 64 * npw, d, 0, 8 }
 #define TILE13(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw, 3>, 64 * wm * wn + 64 * npw, d, 0, 3 }
+#define TILEH(bm, bn, wm, wn, d, npw) { bm, bn, 64, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, 64, d, npw, 4>, 64 * wm * wn + 64 * npw, d, 2, 4 }
 #define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d, 0, 0 }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
@@ -2234,6 +2318,20 @@ const TileCfg kTiles[] = {
     TILE13(32, 32, 2, 2, 64, 2, 8),   // 88
     TILE13(32, 32, 2, 2, 64, 3, 8),   // 89
     TILE13(64, 64, 2, 2, 64, 2, 8),   // 90
+    TILEH(32, 64, 2, 2, 2, 8),        // 91: v3 on SPLIT-fp16 arithmetic (PF = 4: filters pre-split, usot_conv_desc.w_frag = 2 + w_scale)
+    TILEH(32, 64, 2, 2, 3, 8),        // 92
+    TILEH(32, 64, 2, 2, 4, 8),        // 93
+    TILEH(32, 32, 2, 2, 2, 8),        // 94
+    TILEH(32, 32, 2, 2, 3, 8),        // 95
+    TILEH(32, 32, 2, 2, 4, 8),        // 96
+    TILEH(64, 64, 2, 2, 2, 8),        // 97
+    TILEH(64, 64, 2, 2, 3, 8),        // 98
+    TILEH(32, 64, 2, 2, 2, 4),        // 99
+    TILEH(32, 64, 2, 2, 4, 4),        // 100
+    TILEH(64, 64, 2, 2, 4, 8),        // 101
+    TILEH(32, 128, 2, 2, 2, 8),       // 102
+    TILEH(64, 128, 2, 2, 2, 8),       // 103
+    TILEH(32, 32, 2, 2, 2, 4),        // 104
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -2273,6 +2371,7 @@ extern "C" int usot_conv_tile_name(int tile, char *buf, int len)
     const TileCfg &t = kTiles[tile - 1];
     if (t.nst) { snprintf(buf, len, "conv_wstat_f32<NST=%d,RPS=%d>", t.nst, t.rps); return USOT_OK; }
     if (t.skfn) { snprintf(buf, len, "conv_igemm_f32_v3p<%d,%d,BK=%d,D=%d,NPW=%d>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
+    if (t.wfrag == 2) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=4>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.wfrag) { snprintf(buf, len, "conv_igemm_f32_ws<%d,%d,D=%d,NPW=%d,DW=%d>", t.bm, t.bn, t.depth, (t.threads - 256) / 64, t.dw); return USOT_OK; }
     if (t.dw == 8 && !t.wfrag) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,NCW=8>", t.bm, t.bn, t.bk, t.depth, (t.threads - 512) / 64); return USOT_OK; }
     if (t.dw == 3 && !t.wfrag) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=3>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
@@ -2385,6 +2484,7 @@ int fill_params(const usot_conv_desc *d, ConvK &p)
     p.K = d->KH * d->KW * d->Cin;
     p.cchunks = d->Cin / 32;
     p.KT = d->KH * d->KW * p.cchunks;
+    p.wscale = nullptr;
     p.vec_store = !d->y_nchw && (p.y_cstride % 4 == 0) && (p.y_coff % 4 == 0) &&
                   (!d->res || (p.res_cstride % 4 == 0 && p.res_coff % 4 == 0)) &&
                   ((uintptr_t)d->y % 16 == 0) && (!d->res || (uintptr_t)d->res % 16 == 0) &&
@@ -2506,7 +2606,7 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
         for (int i = 0; i < n; ++i) {
             ConvK &p = bt.p[i];
             const int pk = 128 * tc.rps;
-            if (p.K != tc.nst * pk || (d[i].Cin % pk) || (d[i].Cout & 31) || p.ksplit != 1 || !d[i].w_frag) return USOT_EINVAL;
+            if (p.K != tc.nst * pk || (d[i].Cin % pk) || (d[i].Cout & 31) || p.ksplit != 1 || d[i].w_frag != 1) return USOT_EINVAL;
             if (p.groups > 1 && (p.w_gs % ((long)16 * p.K))) return USOT_EINVAL;
             if ((long)p.N * p.H * p.W * p.Cin >= (1L << 31)) return USOT_EINVAL;        // 32-bit element offsets in the loader
             p.MT = (p.M + 31) / 32;
@@ -2537,8 +2637,10 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
         if (p.ksplit > p.K / tc.bk) return USOT_EINVAL;
         // filters in fragment order iff the tile streams them (a row-major bank under a streaming tile, or the reverse,
         // would compute garbage silently); group strides must keep whole 16-row blocks
-        if ((d[i].w_frag != 0) != (tc.wfrag != 0)) return USOT_EINVAL;
-        if (tc.wfrag && p.groups > 1 && (p.w_gs % ((long)16 * p.K))) return USOT_EINVAL;
+        if (d[i].w_frag != tc.wfrag) return USOT_EINVAL;
+        if (tc.wfrag == 2 && (!d[i].w_scale || ((uintptr_t)d[i].w_scale & 3))) return USOT_EINVAL;
+        p.wscale = d[i].w_scale;
+        if (tc.wfrag == 1 && p.groups > 1 && (p.w_gs % ((long)16 * p.K))) return USOT_EINVAL;
         p.MT = (p.M + tc.bm - 1) / tc.bm;
         p.NT = (d[i].Cout + tc.bn - 1) / tc.bn;
         bt.start[i] = (int)blocks;
@@ -2552,10 +2654,10 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
 #ifdef USOT_V3_SWZ
     const int ld = (tc.bk == 64 && (v3fam || tc.wfrag)) ? 64 : tc.bk + 4;
 #else
-    const int ld = (tc.bk == 64 && tc.wfrag) ? 64 : tc.bk + 4;
+    const int ld = (tc.bk == 64 && tc.wfrag == 1) ? 64 : tc.bk + 4;
     (void)v3fam;
 #endif
-    const size_t lds = (size_t)tc.ksw * tc.stages * (tc.bm + (tc.wfrag ? 0 : tc.bn)) * ld * sizeof(float);
+    const size_t lds = (size_t)tc.ksw * tc.stages * (tc.bm + (tc.wfrag == 1 ? 0 : tc.bn)) * ld * sizeof(float);
     if (lds > 64 * 1024) {
         static bool raised[128] = {false};
         if (!raised[tile]) {

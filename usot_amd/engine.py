@@ -82,6 +82,13 @@ class PackedConv:
             self._wfrag = hip.pack_wfrag(self.w)
         return self._wfrag
 
+    def w_split16(self):
+        """(bank, scales) for the split-fp16 conv tiles (hip.split16_pack: every row as hi + lo fp16 of row x 2^e; row slices keep
+        their meaning)."""
+        if '_wsplit16' not in self.__dict__:
+            self._wsplit16 = hip.split16_pack(self.w)
+        return self._wsplit16
+
     def w_lp(self, dtype=torch.bfloat16):
         """bf16 / fp16 copy of the folded filter bank (made on first use; fp32 stays the master)."""
         cache = self.__dict__.setdefault('_wlp', {})
@@ -300,15 +307,24 @@ class Builder:
         if force_ks is not None:
             ksplit = force_ks
         ws = None
-        frag = hip.tile_wfrag(ttile)                # tiles that take their filters in MFMA fragment order
-        if frag and (row0 % 16 or ((w_rows or cout) % 16 and groups > 1) or not hip.tile_supports(ttile, pc.cin, cout, k)):
+        # 'split16_f32': the producer / consumer tiles of the long reductions run on their split-fp16 twins (csrc/conv_igemm.hip, PF = 4)
+        if self.opt['split16_f32'] and k >= self.opt['split16_min_k'] and pc.cin % 64 == 0 and ttile in SPLIT16_TILES:
+            ttile = SPLIT16_TILES[ttile]
+        frag = hip.tile_wfrag(ttile)                # 1: filters in MFMA fragment order; 2: split-fp16 bank + row scales
+        if frag == 2 and pc.cin % 64:
+            raise hip.HipError('%s: split-fp16 tile %d needs Cin %% 64 == 0 (Cin = %d)' % (name, ttile, pc.cin))
+        if frag == 1 and (row0 % 16 or ((w_rows or cout) % 16 and groups > 1) or not hip.tile_supports(ttile, pc.cin, cout, k)):
             ttile, ksplit, frag = (self.default_batch_tile if tile is not None else 0), 1, 0     # geometry the tile cannot take
-        if (frag and hip.tile_kreq(ttile)[0]) or hip.tile_streamk(ttile):
+        if (frag == 1 and hip.tile_kreq(ttile)[0]) or hip.tile_streamk(ttile):
             ksplit = 1                              # weight-stationary tiles split k inside the workgroup, stream-K tiles over the resident set
         if ksplit > 1:            # partial slabs + one ticket per tile (usot_conv_ws_floats), tickets zero before first use
             ws = self.buf(ksplit * groups * m * cout + groups * ((m + 15) // 16) * ((cout + 31) // 32))
             ws.zero_()
-        wbank = pc.w_frag() if frag else pc.w
+        wsc = None
+        if frag == 2:
+            wbank, wsc = pc.w_split16()
+        else:
+            wbank = pc.w_frag() if frag else pc.w
         d = hip.conv_desc(x.data_ptr(), wbank.data_ptr() + row0 * k * 4, pc.b.data_ptr() + row0 * 4, y.data_ptr(),
                           N=n, H=h, W=w, Cin=pc.cin, OH=oh, OW=ow, Cout=cout, KH=pc.kh, KW=pc.kw,
                           stride=pc.stride, pad=pc.pad, dil=pc.dil,
@@ -316,8 +332,9 @@ class Builder:
                           act_split=act_split, y_cstride=y_cstride, y_coff=y_coff, y_nchw=int(y_nchw),
                           groups=groups, x_gs=x_gs, w_gs=(w_rows or cout) * k, b_gs=(w_rows or cout),
                           y_gs=y_gs if y_gs else n * oh * ow * cout, r_gs=0,
-                          ksplit=ksplit, tile=ttile, ws=ws.data_ptr() if ws is not None else None, w_frag=frag)
-        self.plan.keep += [x, wbank, pc.b]
+                          ksplit=ksplit, tile=ttile, ws=ws.data_ptr() if ws is not None else None, w_frag=frag,
+                          w_scale=wsc.data_ptr() + row0 * 4 if wsc is not None else None)
+        self.plan.keep += [x, wbank, pc.b, wsc]
         log = (name, m, cout, k, groups, m * cout * k * groups)
         geom = dict(name=name, N=n, H=h, W=w, Cin=pc.cin, Cout=cout, KH=pc.kh, KW=pc.kw, stride=pc.stride,
                     pad=list(pc.pad), dil=list(pc.dil), groups=groups, has_res=res is not None)
@@ -339,7 +356,7 @@ class Builder:
         partial tiles, no bias, no activation, no combine.  Returns (slabs [ks, m, cout], oh, ow); the consumer sums them, adds
         pc.b and activates while it stages its input (pw_pair_f32(t2_parts=ks, t2_bias=pc.b))."""
         d, _, oh, ow, log, geom = self.conv_desc(name, pc, x, n, h, w, tile=tile, force_ks=ks, y=x)    # y is not written
-        if d.ksplit != ks or d.w_frag:
+        if d.ksplit != ks or d.w_frag == 1:
             raise hip.HipError('conv_deferred %s: tile %d cannot split k %d ways' % (name, tile, ks))
         m = n * oh * ow
         d.defer, d.act, d.bias, d.res = 1, ACT_NONE, None, None
@@ -379,7 +396,7 @@ class Builder:
                 lead_tile = d.tile if d.tile else self.default_batch_tile
                 d.tile = lead_tile
             if dks:
-                if d.ksplit != dks or d.w_frag:
+                if d.ksplit != dks or d.w_frag == 1:
                     raise hip.HipError('conv_batch %s: tile %d cannot split k %d ways' % (nm, d.tile, dks))
                 d.defer, d.act, d.bias, d.res = 1, ACT_NONE, None, None
                 slabs = next(t for t in reversed(self.plan.keep) if isinstance(t, torch.Tensor) and t.data_ptr() == d.ws)
@@ -1088,6 +1105,10 @@ def _as_dev_f32(t, device):
     return t.to(device=device, dtype=torch.float32)
 
 
+# fp32 producer / consumer tile id -> its split-fp16 twin (same tile shape, producer depth and producer waves)
+SPLIT16_TILES = {55: 91, 56: 92, 53: 94, 54: 95, 57: 97, 39: 99, 47: 99, 31: 99, 41: 104, 49: 104, 33: 104, 38: 97, 46: 98, 30: 97, 59: 102}
+
+
 def load_tuning(path=None):
     """{(M, Cout, K, groups): (tile, ksplit)} measured by scripts/tune_conv.py on gfx950.
     Shapes missing from the table fall back to the launcher's heuristic."""
@@ -1133,6 +1154,13 @@ DEFAULT_OPTIONS = {
     # conv3 89 -> 66 us, layer1's 1x1 shortcut 50 -> 38 at batch 64
     'panel_1x1_lp': {(256, 1024), (128, 512), (64, 256)},
     'panel_min_panels': 192,
+    # fp32 convolutions with K >= split16_min_k on the producer / consumer tiles run on the split-fp16 form of the tile (every
+    # operand as hi + lo fp16, three fp16 MFMAs per product block, fp32 accumulation: csrc/conv_igemm.hip PF = 4)
+    'split16_f32': True,
+    'split16_min_k': 1152,
+    # Session: frame t's bank append (encode + scatter) runs at the start of frame t + 1's graph on a side branch, not behind
+    # frame t's result tag (Session._build)
+    'defer_append': False,
     # layer3 (from block lp_chains_from on) as lp_chains independent batch slices on parallel graph branches, chain i released
     # i * lp_chain_skew launches of chain 0 late (backbone_bf16); 0 = one chain
     'lp_chains': 0,
@@ -1522,11 +1550,12 @@ class Session:
         # kernels address directly: the 64-byte per-frame upload/download needs no copy
         # kernels at all — the host writes ctl, launches the graph, synchronises, reads out.
         # layout: [0:16] target size (2 doubles), [48:56] frame tag (double), [64:] N_q gather rows +
-        # 1 scatter row + the crop's device address as two int32 (0 = the session's own input buffer)
+        # 1 scatter row + the crop's device address as two int32 (0 = the session's own input buffer) + the PREVIOUS frame's
+        # scatter row (engine option 'defer_append')
         self.nq = int(getattr(p, 'mem_queue_size', 7))
         if self.nq < 4:
             raise hip.HipError('mem_queue_size must be >= 4 (init, flip, >= 1 sampled, last); got %d' % self.nq)
-        self.ctl = torch.zeros(64 + 4 * (self.nq + 3 + (self.nq + 3) % 2), dtype=torch.uint8).pin_memory()
+        self.ctl = torch.zeros(64 + 4 * (self.nq + 4 + (self.nq + 4) % 2), dtype=torch.uint8).pin_memory()
         self.out8 = torch.zeros(16, dtype=torch.float64).pin_memory()   # 8 results + completion tag
         self.x_host = torch.zeros(1, 3, self.size, self.size).pin_memory()
         self._x_host_np = self.x_host.numpy()
@@ -1541,7 +1570,7 @@ class Session:
         self.x.zero_()                      # the warm-up replay below reads it (torch.empty memory may decode as NaN)
         self.mem_in = bld.buf(1)            # heads() only asks whether there is a memory branch
         tsz_dev = self.ctl[0:56].view(torch.float64)          # [0:2] target size, [6] frame tag
-        idx_dev = self.ctl[64:64 + 4 * (nq + 3)].view(torch.int32)   # N_q gather rows + 1 scatter row + crop address (lo, hi)
+        idx_dev = self.ctl[64:64 + 4 * (nq + 4)].view(torch.int32)   # N_q gather rows + 1 scatter row + crop address (lo, hi) + previous scatter row
         self._ctl_f64 = tsz_dev.numpy()
         self._ctl_i32 = idx_dev.numpy()
         self._ctl_u32 = self._ctl_i32.view(np.uint32)
@@ -1550,18 +1579,36 @@ class Session:
         self._out_np = self.out8.numpy()
         # the 7 picked memory kernels: their cached encodings, three banks in one gather
         mk = [bld.buf(nq, hk, wk, 256) for hk, wk in KGEO]
-        # ... and the append row of this frame is stashed in device memory: the scatter at the end of
-        # the graph runs AFTER the result tag the host waits for, i.e. possibly while the host is
-        # already writing the next frame's control block
         self.slot_dev = torch.zeros(4, dtype=torch.int32, device=e.device)
-        self._rows_multi(pl, self.bank_enc, idx_dev, mk, nq, scatter=0, stash=self.slot_dev)
-        # slot_dev[0] = the append row, slot_dev[1:3] = the crop's address: both stashed from the control block by the
-        # gather above (the first kernel of the frame)
-        xf, hf = bld.backbone(self.x, 1, self.size, need_stem=False, xptr_dev=self.slot_dev[1:3])
-        bbox, cls2, S = bld.heads(xf, 1, hf, self.zk, self.mem_in, nq, mk=mk, mem_lane=2)
-        assert S == self.S
         self.roi = bld.buf(5)
         self.feat = bld.buf(1, 7, 7, 256)
+        self.feat.zero_()
+        # 'defer_append': the bank append of frame t (encode the pooled feature, scatter feature + encodings) does not sit
+        # behind frame t's result tag in front of frame t + 1 but at the START of frame t + 1's graph, on a side branch beside
+        # the stem and layer1, followed there by frame t + 1's gather (whose picks include the row just appended);
+        # the branch joins in front of the heads.  Every control-block read (gather rows, the previous scatter row, the crop's
+        # address in the stem, the target size in the decode) happens before the tag, so the host may rewrite the block as soon
+        # as collect() returns; flush() appends the pending feature for anybody who reads the bank between frames.
+        self.defer = bool(e.opt['defer_append']) and e.lanes == 0
+        self._pending, self._prev_slot = False, self.cap - 1
+        if self.defer:
+            pl.fork(3)
+            new_enc = bld.encode_kernel(self.feat, 1, 256, 'mem')       # the PREVIOUS frame's pooled feature
+            self._rows_multi(pl, [self.feat] + new_enc, idx_dev[nq + 3:], [self.bank] + self.bank_enc, 1, scatter=1)
+            self._rows_multi(pl, self.bank_enc, idx_dev, mk, nq, scatter=0, stash=self.slot_dev)
+            pl.fork(0)
+            xf, hf = bld.backbone(self.x, 1, self.size, need_stem=False, xptr_dev=idx_dev[nq + 1:nq + 3])
+            pl.join(3)
+        else:
+            # the append row of this frame is stashed in device memory: the scatter at the end of
+            # the graph runs AFTER the result tag the host waits for, i.e. possibly while the host is
+            # already writing the next frame's control block
+            self._rows_multi(pl, self.bank_enc, idx_dev, mk, nq, scatter=0, stash=self.slot_dev)
+            # slot_dev[0] = the append row, slot_dev[1:3] = the crop's address: both stashed from the control block by the
+            # gather above (the first kernel of the frame)
+            xf, hf = bld.backbone(self.x, 1, self.size, need_stem=False, xptr_dev=self.slot_dev[1:3])
+        bbox, cls2, S = bld.heads(xf, 1, hf, self.zk, self.mem_in, nq, mk=mk, mem_lane=None if self.defer else 2)
+        assert S == self.S
         p = self.p
         hip.check(L.usot_plan_add_decode(pl.h, hip.ptr(cls2[0]), hip.ptr(cls2[1]), hip.ptr(bbox), hip.ptr(self.window),
                                          hip.ptr(self.out8), S, self.size, int(p.total_stride), float(p.ratio),
@@ -1570,8 +1617,17 @@ class Session:
         c = 256
         hip.check(L.usot_plan_add_prroi(pl.h, hip.ptr(xf), hip.ptr(self.roi), hip.ptr(self.feat), 1, c, hf, hf, 7, 7, 1.0,
                                         hf * hf * c, 1, hf * c, c, 49 * c, 1, 7 * c, c), 'plan_add_prroi')
-        new_enc = bld.encode_kernel(self.feat, 1, 256, 'mem')       # the new feature's encodings, once
-        self._rows_multi(pl, [self.feat] + new_enc, self.slot_dev, [self.bank] + self.bank_enc, 1, scatter=1)
+        if not self.defer:
+            new_enc = bld.encode_kernel(self.feat, 1, 256, 'mem')       # the new feature's encodings, once
+            self._rows_multi(pl, [self.feat] + new_enc, self.slot_dev, [self.bank] + self.bank_enc, 1, scatter=1)
+        else:
+            # flush(): the same append as a small plan of its own, its row read from a pinned word
+            fb = Builder(e.W, e.tuning, 0, e.opt)
+            self._flush_idx = torch.zeros(2, dtype=torch.int32).pin_memory()
+            fenc = fb.encode_kernel(self.feat, 1, 256, 'mem')
+            self._rows_multi(fb.plan, [self.feat] + fenc, self._flush_idx, [self.bank] + self.bank_enc, 1, scatter=1)
+            fb.plan.keep += fenc + [self.feat, self._flush_idx, self.bank] + self.bank_enc
+            self._flush_plan = fb.plan
         pl.keep += mk + new_enc + self.bank_enc + [self.slot_dev]
         pl.keep += [self.bank, self.ctl, self.window, self.out8, tsz_dev, idx_dev] + self.zk
         self.xf, self.cls2, self.bbox, self.plan, self.log = xf, cls2, bbox, pl, bld.log
@@ -1581,6 +1637,19 @@ class Session:
         self._ctl_f64[6] = -1.0
         e._finish(pl)
         torch.cuda.current_stream().synchronize()
+        self.feat.zero_()                   # the warm-up replay pooled a feature of the zero crop: not a pending append
+        torch.cuda.current_stream().synchronize()
+
+    def flush(self):
+        """'defer_append': append the last frame's pooled feature to the bank NOW (it otherwise happens at the start of the next
+        frame's graph).  For readers of the bank between frames; the next frame rewrites the same row with the same values."""
+        if not getattr(self, 'defer', False) or not self._pending:
+            return
+        st = getattr(self, '_stream', None) or torch.cuda.current_stream()
+        with torch.cuda.stream(st):
+            self._flush_idx[0] = self._prev_slot
+            self._flush_plan.run()
+        st.synchronize()
 
     @staticmethod
     def _rows_multi(pl, srcs, idx, dsts, n_rows, scatter, stash=None):
@@ -1613,6 +1682,7 @@ class Session:
         c[nq] = slot
         self._ctl_u32[nq + 1] = xaddr & 0xffffffff          # the crop's device address, low / high half (0 = own buffer)
         self._ctl_u32[nq + 2] = xaddr >> 32
+        c[nq + 3] = self._prev_slot                         # 'defer_append': where the previous frame's feature goes
 
     def _ensure_capacity(self):
         """Grow BEFORE anything is written into the plan's input buffer: growing rebuilds the
@@ -1621,6 +1691,7 @@ class Session:
             self._grow()
 
     def _grow(self):
+        self.flush()
         bank = torch.zeros(self.cap * 2, 7, 7, 256, device=self.e.device)
         bank[:self.cap].copy_(self.bank)
         enc = [torch.zeros(self.cap * 2, hk, wk, 256, device=self.e.device) for hk, wk in KGEO]
@@ -1707,6 +1778,7 @@ class Session:
                 if out[8] != tag:
                     raise hip.HipError('frame %r never published its result block (tag reads %r): '
                                        'the frame graph did not run to the decode kernel' % (tag, float(out[8])))
+        self._prev_slot, self._pending = 2 + self.n, True      # ('defer_append': this frame's row, written by the next graph)
         self.n += 1
         return out[:8].copy()
 
@@ -1715,6 +1787,7 @@ class Session:
         bank row + its three kernel-side encodings.  Lets a caller that switches from the fused path to
         the generic `update()` mid-video keep one memory queue (usot_tracker.py:264)."""
         self._ensure_capacity()
+        self.flush()
         torch.cuda.current_stream().synchronize()
         row = 2 + self.n
         self.bank[row].copy_(hip.to_nhwc(_as_dev_f32(feat, self.e.device))[0])
@@ -1749,6 +1822,8 @@ class Session:
 
     def memory_feature(self, i):
         """Memory feature i as an NCHW-shaped view [1,256,7,7] of its bank row."""
+        if i == self.n - 1:
+            self.flush()
         return self.bank[2 + i:3 + i].permute(0, 3, 1, 2)
 
 

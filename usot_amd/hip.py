@@ -50,7 +50,8 @@ class ConvDesc(C.Structure):
                 ('groups', C.c_int32),
                 ('x_gs', C.c_int64), ('w_gs', C.c_int64), ('b_gs', C.c_int64), ('y_gs', C.c_int64),
                 ('r_gs', C.c_int64),
-                ('ksplit', C.c_int32), ('tile', C.c_int32), ('w_frag', C.c_int32), ('defer', C.c_int32)]
+                ('ksplit', C.c_int32), ('tile', C.c_int32), ('w_frag', C.c_int32), ('defer', C.c_int32),
+                ('w_scale', C.c_void_p)]
 
 
 class GroupDWDesc(C.Structure):
@@ -302,10 +303,31 @@ def tile_table():
 
 # ------------------------------------------------------------------ tensor-level wrappers
 
+SPLIT16_X_SCALE = 8.0      # csrc/conv_igemm.hip (PF = 4): the activations are split as hi + lo fp16 of 8 x
+
+
+def split16_pack(w):
+    """Filter bank [rows][K] fp32 (K % 64 == 0) -> (bank in the split-fp16 layout of usot_conv_desc.w_frag = 2 as a float32-typed
+    tensor [rows][K]: per row and k-tile of 64, 64 hi halves then 64 lo halves of row x 2^e, e chosen per row so that the largest
+    |value| lands in [512, 1024); the per-row factors 1 / (2^e x SPLIT16_X_SCALE) that undo both scales, float32 [rows])."""
+    rows, k = w.shape
+    assert k % 64 == 0
+    w = w.float()
+    amax = w.abs().amax(1)
+    e = torch.where(amax > 0, torch.floor(torch.log2(1024.0 / amax.clamp_min(1e-30))), torch.zeros_like(amax))
+    e = torch.where(amax * torch.exp2(e) >= 1024.0, e - 1, e).clamp(-60, 60)       # (guards the log2 rounding at exact powers of two)
+    sw = torch.exp2(e)
+    ws = w * sw[:, None]
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    packed = torch.cat([hi.view(rows, k // 64, 64), lo.view(rows, k // 64, 64)], 2).contiguous()      # [rows][KT][128] halves
+    return packed.view(torch.float32).view(rows, k).contiguous(), (1.0 / (sw * SPLIT16_X_SCALE)).float().contiguous()
+
+
 def conv_desc(x, w, bias, y, *, N, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, pad=(0, 0), dil=(1, 1),
               res=None, act=ACT_NONE, act2=ACT_NONE, act_split=0, y_cstride=0, y_coff=0,
               res_cstride=0, res_coff=0, y_nchw=0, groups=1, x_gs=0, w_gs=0, b_gs=0, y_gs=0, r_gs=0,
-              ksplit=1, tile=0, ws=None, w_frag=0, defer=0):
+              ksplit=1, tile=0, ws=None, w_frag=0, defer=0, w_scale=None):
     d = ConvDesc()
     d.x, d.w, d.bias, d.res, d.y, d.ws = (x, w, bias or None, res or None, y, ws or None)
     d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout = N, H, W, Cin, OH, OW, Cout
@@ -316,6 +338,7 @@ def conv_desc(x, w, bias, y, *, N, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, pa
     d.groups = groups
     d.x_gs, d.w_gs, d.b_gs, d.y_gs, d.r_gs = x_gs, w_gs, b_gs, y_gs, r_gs
     d.ksplit, d.tile, d.w_frag, d.defer = ksplit, tile, w_frag, defer
+    d.w_scale = w_scale or None
     return d
 
 
@@ -334,12 +357,16 @@ def conv2d(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, ac
         ws = torch.zeros(ksplit * N * OH * OW * Cout + ((N * OH * OW + 15) // 16) * ((Cout + 31) // 32), device=x.device,
                          dtype=torch.float32)
     frag = tile_wfrag(tile)
-    if frag:                # weight-streaming tile: the filter bank in MFMA fragment order
+    wsc = None
+    if frag == 2:           # split-fp16 tile: hi + lo fp16 of every scaled filter row, and the scales
+        w, wsc = split16_pack(w)
+    elif frag:              # weight-streaming tile: the filter bank in MFMA fragment order
         w = pack_wfrag(w)
     d = conv_desc(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                   N=N, H=H, W=W_, Cin=Cin, OH=OH, OW=OW, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad,
                   dil=dil, res=res.data_ptr() if res is not None else None, act=act, tile=tile,
-                  ksplit=ksplit, ws=ws.data_ptr() if ws is not None else None, y_nchw=int(y_nchw), w_frag=frag)
+                  ksplit=ksplit, ws=ws.data_ptr() if ws is not None else None, y_nchw=int(y_nchw), w_frag=frag,
+                  w_scale=wsc.data_ptr() if wsc is not None else None)
     if tile_streamk(tile):
         keep = streamk_ws([d], tile, x.device)
     check(lib().usot_conv2d_f32(stream(), C.byref(d)), 'usot_conv2d_f32')
