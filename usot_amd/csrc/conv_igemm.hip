@@ -976,6 +976,9 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     // split-fp16: the three products of one 32-k step on the blocks of this wave (slot ks = hi halves of k-step ks, slot ks + 2 = lo);
     // smallest terms first; a wave with a single block keeps the two cross terms on a second accumulator (no dependent chain of three)
     auto mma_h = [&](f32x4 (&a)[TN][TM], f32x4 &a2, const f32x4 (&whi)[TN], const f32x4 (&wlo)[TN], const f32x4 (&xhi)[TM], const f32x4 (&xlo)[TM], bool first) {
+#ifdef USOT_ABL_NOMMA
+        return;
+#endif
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         auto h = [](const f32x4 &v) { return __builtin_bit_cast(f16x8_t, v); };
         if constexpr (TN * TM == 1) {

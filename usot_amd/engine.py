@@ -248,7 +248,14 @@ class Builder:
         self.opt = merged_options() if options is None else options
         self.dev = weights.device
         self.plan = Plan()
-        self.tuning = tuning or {}
+        self.tuning = dict(tuning or {})
+        if self.opt['split16_f32']:
+            # shapes tuned on the split-fp16 tiles themselves (data/tuning_split16_gfx950.json) replace the fp32 table's entries;
+            # an entry that already names a split-fp16 tile (an experiment's override) stays
+            for key, val in S16_TUNING.items():
+                cur = self.tuning.get(key)
+                if cur is None or hip.tile_wfrag(cur[0]) != 2:
+                    self.tuning[key] = val
         self.lanes = int(lanes)
         self.batch = True                 # heterogeneous conv batching (one launch for sibling convs)
         self.default_batch_tile = 15      # v2 32x64 BK64 when the lead shape has no tuned entry
@@ -308,7 +315,8 @@ class Builder:
             ksplit = force_ks
         ws = None
         # 'split16_f32': the producer / consumer tiles of the long reductions run on their split-fp16 twins (csrc/conv_igemm.hip, PF = 4)
-        if self.opt['split16_f32'] and k >= self.opt['split16_min_k'] and pc.cin % 64 == 0 and ttile in SPLIT16_TILES:
+        if (self.opt['split16_f32'] and k >= self.opt['split16_min_k'] and m >= self.opt['split16_min_m'] and pc.cin % 64 == 0
+                and ttile in SPLIT16_TILES):
             ttile = SPLIT16_TILES[ttile]
         frag = hip.tile_wfrag(ttile)                # 1: filters in MFMA fragment order; 2: split-fp16 bank + row scales
         if frag == 2 and pc.cin % 64:
@@ -1136,6 +1144,21 @@ def load_lp_tuning(path=None):
 LP_TUNING = load_lp_tuning()
 
 
+def load_split16_tuning(path=None):
+    """{(M, Cout, K, groups): (split-fp16 tile, ksplit)} measured in the frame graph (scripts/ks_ab.py) on gfx950; shapes missing here
+    run on the split-fp16 twin (SPLIT16_TILES) of their fp32 tile."""
+    import json
+    import os
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'tuning_split16_gfx950.json')
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return {tuple(int(v) for v in k.split(',')): (int(t[0]), int(t[1])) for k, t in json.load(f).items()}
+
+
+S16_TUNING = load_split16_tuning()
+
+
 def _shapes(text):
     return {tuple(int(v) for v in t.split('x')) for t in text.split(',') if t}
 
@@ -1158,6 +1181,7 @@ DEFAULT_OPTIONS = {
     # operand as hi + lo fp16, three fp16 MFMAs per product block, fp32 accumulation: csrc/conv_igemm.hip PF = 4)
     'split16_f32': True,
     'split16_min_k': 1152,
+    'split16_min_m': 64,
     # Session: frame t's bank append (encode + scatter) runs at the start of frame t + 1's graph on a side branch, not behind
     # frame t's result tag (Session._build)
     'defer_append': False,
