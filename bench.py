@@ -35,6 +35,7 @@ from usot_amd.model import USOT  # noqa: E402
 from usot_amd.tracker import USOTConfig, select_memory  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+LP_PEAK_TFLOPS = 2500.0          # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF is 2:1 sparse)
 HBM_PEAK_GBPS = 8000.0
 GROUPDW_BYTES_PER_SAMPLE = 3161088   # x 2 464 768 + k 56 320 + out 640 000
 
@@ -171,10 +172,18 @@ def roofline(sess, frames):
             traffic_src += ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)'
     except Exception:
         pass
-    busy = pmc_busy(hip.tile_name(tile), MFMA_F32_PEAK_TFLOPS)
+    # the peak that bounds the dominant kernel's ARITHMETIC: the fp32 MFMA (157.3 TFLOP/s) for the exact-fp32 tiles; for the
+    # split-fp16 tiles (hip.tile_wfrag == 2: every product block as three v_mfma_f32_16x16x32_f16, csrc/conv_igemm.hip PF = 4) the
+    # dense fp16 peak over the three products an algorithmic product costs - `achieved` stays ALGORITHMIC flops per second
+    split16 = hip.tile_wfrag(tile) == 2
+    peak = round(LP_PEAK_TFLOPS / 3.0, 1) if split16 else MFMA_F32_PEAK_TFLOPS
+    busy = pmc_busy(hip.tile_name(tile), peak)
     return {
-        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), **busy_fields(busy, ach),
+        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+        'frac': round(ach / peak, 4), **busy_fields(busy, ach),
+        'arithmetic': ('split fp16: operands as hi + lo fp16 (22 significant bits), 3 x v_mfma_f32_16x16x32_f16 per product block, fp32 '
+                       'accumulation; peak = dense fp16 MFMA peak %.0f / 3' % LP_PEAK_TFLOPS) if split16 else 'v_mfma_f32_16x16x4_f32 (exact fp32)',
+        'executed_tflops': round(ach * (3 if split16 else 1), 2), 'frac_of_fp32_mfma_peak': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
         'traffic': traffic, 'traffic_source': traffic_src,
         # algorithmic bytes: every launch's input map, filter bank, bias and result (+ residual) once — SURVEY 8(d); the
         # measured traffic above it is Infinity-Cache-served re-reads of the activations by each XCD's L2 (~150 FLOP/B:
@@ -185,7 +194,8 @@ def roofline(sess, frames):
         'avg_launch_us': round(ms / n * 1e3, 2), 'algorithmic_gflop_per_frame': round(fl / 1e9, 3),
         'all_convs': {'gflop_per_frame': round(conv_flops / 1e9, 3), 'us_per_frame': round(conv_ms * 1e3, 1),
                       'tflops': round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
-                      'frac': round(conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
+                      'frac': round(conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                      'frac_is': 'of the fp32 MFMA peak %.1f (the launches mix exact-fp32 and split-fp16 tiles)' % MFMA_F32_PEAK_TFLOPS},
         'frame_op_spans_us': round(total_ms * 1e3, 1),
     }
 
@@ -724,7 +734,11 @@ def main():
             'metric': 'tracker FPS (255x255 search, ResNet-50)', 'value': round(fps, 2), 'unit': 'frames/s',
             'n_gpus': world, 'steps': steps, 'steps_requested': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            # fp32 storage and accumulation everywhere; the K >= 1152 convolutions form their products from fp16 hi + lo splits of the
+            # fp32 operands (22 significant bits, engine option split16_f32; False = exact fp32 MFMA) - same 1e-4 parity bar
+            'dtype': 'f32 (split-fp16 products, fp32 accumulate, for K>=1152 convs)' if model.engine.opt.get('split16_f32') else 'f32',
+            'data': 'synthetic',
             'config': {'workload': 'configs[1]: batch=1 ResNet-50(layer3)+neck, fused depthwise xcorr, cls/reg/'
                                    'memory heads (N_q=7), decode + PrRoIPool, fp32, 1 stream per GPU',
                        'search': a.size, 'template': 127, 'streams': world * S, 'streams_per_gpu': S, 'weights': 'synthetic seed 0 '

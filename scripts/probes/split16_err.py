@@ -4,7 +4,7 @@ import numpy as np, torch, torch.nn.functional as F
 from usot_amd import hip
 import test_gpu_ops as T
 DEV='cuda:0'
-for tile in (91, 94, 97, 99):
+for tile in [int(v) for v in sys.argv[1:]] or (91, 94, 97, 99):
     for ci, case in enumerate(T.CONV_CASES):
         N, Cin, H, W, Cout, k, stride, pad, dil = case
         g = torch.Generator().manual_seed(hash(case) % (2 ** 31))

@@ -24,7 +24,8 @@ b = torch.randn(Cout, device=dev); y = torch.empty(N, H, H, Cout, device=dev)
 for tile in [int(v) for v in sys.argv[1:]] or [41, 53]:
     ws = torch.zeros(8 * 64, dtype=torch.int32, device=dev)
     d = hip.conv_desc(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N=N, H=H, W=W, Cin=Cin, OH=H, OW=H, Cout=Cout,
-                      KH=k, KW=k, pad=(pad, pad), dil=(dil, dil), act=1, tile=tile, ws=ws.data_ptr())
+                      KH=k, KW=k, pad=(pad, pad), dil=(dil, dil), act=1, tile=tile, ws=ws.data_ptr(), w_frag=hip.tile_wfrag(tile),
+                      w_scale=b.data_ptr() if hip.tile_wfrag(tile) == 2 else None)      # timing only: random bits are as good as split filters
     for _ in range(2):
         hip.check(L.usot_conv2d_f32(hip.stream(), C.byref(d)))
     torch.cuda.synchronize()

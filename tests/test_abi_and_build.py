@@ -83,3 +83,26 @@ def test_low_precision_tuning_table_names_existing_tiles(libpath):
         m, cout, k = (int(v) for v in key.split(','))
         assert m > 0 and cout > 0 and k % 64 == 0, key
         assert 1 <= tile <= n, (key, tile, n)
+
+
+def test_split16_tuning_table_names_split_fp16_tiles(libpath):
+    """usot_amd/data/tuning_split16_gfx950.json (fp32 conv shape -> (tile, ksplit) on the split-fp16 tiles) and engine.SPLIT16_TILES
+    (fp32 tile -> its split-fp16 twin) must only name tiles whose filters the library takes pre-split (usot_conv_tile_wfrag == 2),
+    of the twin's own shape; the reductions they serve are whole 64-k tiles."""
+    import ctypes
+    import json
+    L = ctypes.CDLL(libpath)
+    with open(os.path.join(ROOT, 'usot_amd', 'data', 'tuning_split16_gfx950.json')) as f:
+        table = json.load(f)
+    assert table
+    for key, (tile, ks) in table.items():
+        m, cout, k, groups = (int(v) for v in key.split(','))
+        assert m > 0 and cout > 0 and groups >= 1 and k % 64 == 0 and ks >= 1, key
+        assert 1 <= tile <= L.usot_conv_tile_count() and L.usot_conv_tile_wfrag(tile) == 2, (key, tile)
+    from usot_amd import engine
+    bm, bn, bm2, bn2 = (ctypes.c_int() for _ in range(4))
+    for src, dst in engine.SPLIT16_TILES.items():
+        assert L.usot_conv_tile_wfrag(src) == 0 and L.usot_conv_tile_wfrag(dst) == 2, (src, dst)
+        assert L.usot_conv_tile_info(src, ctypes.byref(bm), ctypes.byref(bn)) == 0
+        assert L.usot_conv_tile_info(dst, ctypes.byref(bm2), ctypes.byref(bn2)) == 0
+        assert (bm.value, bn.value) == (bm2.value, bn2.value), (src, dst)

@@ -736,7 +736,7 @@ template <int BM, int BN, int WM, int WN, int BK, int D = 1, int NPW = 4, int PF
 #ifdef USOT_V3_SWZ
 __global__ __launch_bounds__(64 * WM * WN + 64 * NPW, (BM * BN <= 32 * 64) ? (4 + NPW) / 2 : 1) void conv_igemm_f32_v3(const ConvBatch bt)
 #else
-__global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(const ConvBatch bt)
+__global__ __launch_bounds__(64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void conv_igemm_f32_v3(const ConvBatch bt)
 #endif
 {
     int pi = 0;
@@ -756,8 +756,20 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 consumer wavefronts");
     constexpr int CT = 64 * WM * WN;              // consumer threads; the producers follow
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr bool H16 = PF == 4;                 // split-fp16 arithmetic (above)
+    constexpr bool H16 = PF == 4 || PF == 5;      // split-fp16 arithmetic (above)
     static_assert(!H16 || BK == 64, "split-fp16 rows are 64 hi + 64 lo halves");
+    // PF = 5: split-fp16 with the FILTER tile moved by LDS-DMA.  The pre-split filter rows are copied to LDS unchanged, and the
+    // producers' ds_write_b128 of them were two thirds of the 24 KB a k-step pushes through the VGPR -> LDS store path (~79 B/clk
+    // per CU: 310 of the traced 560-cycle store phase the consumers end up waiting for).  Four extra wavefronts (one per SIMD) do
+    // nothing but issue global_load_lds_dwordx4 for the filter rows of k-tile t + 4 into a ring of FIVE filter stages (the
+    // activation tile keeps its three register-staged stages and its producers, which now move only the 8 KB that need splitting),
+    // wait with a counted s_waitcnt vmcnt until the pieces of tile t + 2 have landed, and join the k-step's barrier.  A stage is
+    // the same padded row image as before (17 chunks of 16 bytes per row: linear chunk c = 17 row + chunk, the 17th a pad that
+    // receives a dummy load), so the consumers' fragment addresses do not change; 1 KiB pieces are c = 64 piece + lane.
+    constexpr bool WDMA = PF == 5;
+    constexpr int NDW = WDMA ? 4 : 0;             // filter-DMA wavefronts
+    constexpr int NSW = WDMA ? 5 : 3;             // filter stages
+    constexpr int LA = NSW - 1;                   // the DMA runs LA k-tiles ahead
     // LDS rows.  BK = 64: a row is 256 B = one bank row, UNPADDED, 16-byte chunk c of tile row `row` stored at chunk
     // c ^ (row & 15).  ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md
     // LDS table): with the former 4-float row pad, lane (l15, quad) hit 16-byte slot (l15 + quad) mod 16 and every group had
@@ -776,6 +788,10 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     constexpr int XI = (BM + RPP - 1) / RPP, WI = (BN + RPP - 1) / RPP;
     constexpr int NR = BK / 16;
     constexpr int STAGE = (BM + BN) * LD;
+    // LDS: without the filter DMA three stages of [activation rows | filter rows]; with it three activation stages, then NSW filter stages
+    constexpr int XSTRIDE = WDMA ? BM * LD : STAGE;            // floats between activation stages
+    constexpr int WBASE = WDMA ? 3 * BM * LD : BM * LD;        // first filter stage
+    constexpr int WSTRIDE = WDMA ? BN * LD : STAGE;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const bool producer = threadIdx.x >= CT;
@@ -791,6 +807,64 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     const int kt0 = (int)((long)KT * ks / p.ksplit);
     const int kt1 = (int)((long)KT * (ks + 1) / p.ksplit);
     const int nt = kt1 - kt0;
+
+    if constexpr (WDMA) {
+        if ((int)threadIdx.x >= CT + NPT) {
+            // ---------------- filter-DMA wavefronts (PF = 5)
+            const int dt = (int)threadIdx.x - CT - NPT;
+            const int dwv = __builtin_amdgcn_readfirstlane(dt >> 6), lane = dt & 63;
+            constexpr int NCH = BN * 17;                       // 16-byte chunks of a filter stage: 16 data + 1 pad per row
+            constexpr int NPIECE = (NCH + 63) / 64;            // 1 KiB pieces (64 lanes x 16 bytes)
+            constexpr int MAXP = (NPIECE + NDW - 1) / NDW;
+            const float *__restrict__ wg = p.w + (long)g * p.w_gs + (long)kt0 * BK;
+            const float *src[MAXP];
+            bool live[MAXP];
+            int mine = 0;                                      // pieces this wave moves per k-tile (wave-uniform)
+#pragma unroll
+            for (int q = 0; q < MAXP; ++q) {
+                const int piece = dwv + q * NDW, c = 64 * piece + lane;
+                live[q] = piece < NPIECE && c < NCH;
+                const int row = c / 17, ch = c - row * 17, co = bn0 + row;
+                const bool ok = live[q] && ch < 16 && co < p.Cout;
+                src[q] = wg + (ok ? (long)co * p.K + ch * 4 : 0L);      // pad chunks and rows past Cout fetch the bank's first bytes
+                mine += piece < NPIECE ? 1 : 0;
+            }
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(smem + WBASE);
+            auto issue = [&](int tile) {                       // k-tile `tile` of this workgroup's range -> stage tile % NSW
+                const uint32_t stg = lds0 + (uint32_t)((tile % NSW) * BN * LD * 4);
+#pragma unroll
+                for (int q = 0; q < MAXP; ++q) {
+                    const int piece = dwv + q * NDW;
+                    if (piece < NPIECE && live[q]) {
+                        const uint32_t dst = __builtin_amdgcn_readfirstlane(stg + (uint32_t)(piece * 1024));
+                        const float *sp = src[q] + (long)tile * BK;
+                        unsigned keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(sp), "s"(dst) : "memory");
+                    }
+                }
+            };
+            // at most the pieces of the LA - 2 newest k-tiles may stay in flight (drain = true: none - the tail, where fewer exist)
+            auto land = [&](bool drain) {
+                if (drain || mine < 1 || mine > 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (mine == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * (LA - 2)) : "memory");
+                else if (mine == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (LA - 2)) : "memory");
+                else if (mine == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (LA - 2)) : "memory");
+                else if (mine == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (LA - 2)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * (LA - 2)) : "memory");
+            };
+            for (int j = 0; j < LA && j < nt; ++j) issue(j);
+            land(nt < LA);                                     // k-tiles 0 and 1 are in LDS before the first barrier
+            asm volatile("s_barrier" ::: "memory");
+            for (int t = 0; t < nt; ++t) {
+                const bool more = t + LA < nt;
+                if (more) issue(t + LA);
+                land(!more);                                   // k-tile t + 2 has landed when the consumers pass this step's barrier
+                asm volatile("s_barrier" ::: "memory");
+            }
+            return;
+        }
+    }
 
     if (producer) {
         const float *__restrict__ xg = p.x + (long)g * p.x_gs;
@@ -849,6 +923,7 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
 #endif
                 xz[d][i] = xin[i];
             }
+            if constexpr (!WDMA) {
 #pragma unroll
             for (int i = 0; i < WI; ++i) {
 #if defined(USOT_ABL_NOLOAD) || defined(USOT_ABL_NOW) || defined(USOT_ABL_NOWLOAD)   // NOW: the W operand never travels; NOWLOAD / NOWSTORE / NOWREAD: one leg of it removed
@@ -858,6 +933,7 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
 #endif
                 wp[i] += advance ? BK : 0;
             }
+            }
             if (advance && ++cur_cc == cch) {
                 cur_cc = 0;
                 set_tap(++cur_tap);
@@ -865,7 +941,7 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
         };
         auto store_tile = [&](auto dc, int st) {
             constexpr int d = decltype(dc)::value;
-            float *sX = smem + st * STAGE, *sW = sX + BM * LD;
+            float *sX = smem + st * XSTRIDE, *sW = smem + WBASE + st * WSTRIDE;
 #ifdef USOT_ABL_NOSTORE
             return;
 #endif
@@ -890,9 +966,11 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
                     }
                 }
 #if !defined(USOT_ABL_NOW) && !defined(USOT_ABL_NOWSTORE)
+            if constexpr (!WDMA) {
 #pragma unroll
             for (int i = 0; i < WI; ++i)
                 if (BN % RPP == 0 || lr + RPP * i < BN) *(f32x4 *)(sW + (lr + RPP * i) * LD + kcs) = wr[d][i];
+            }
 #elif defined(USOT_ABL_NOWSTORE)
 #pragma unroll
             for (int i = 0; i < WI; ++i) {
@@ -1001,17 +1079,18 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
         }
     };
     f32x4 fw[NSLOT][TN], fx[NSLOT][TM];
-    auto read_frags = [&](int st, int r, int slot) {
+    auto read_frags = [&](int st, int r, int slot, int stw = 0) {       // stw: the filter stage (filter-DMA tiles only)
 #ifdef USOT_ABL_NOREAD
         return;
 #endif
-        const float *base = smem + st * STAGE + ((r * 16) ^ swz);
+        const float *base = smem + st * XSTRIDE + ((r * 16) ^ swz);
+        const float *wbase = WDMA ? smem + WBASE - BM * LD + stw * WSTRIDE + r * 16 : base;     // (fw_off carries BM * LD)
 #if defined(USOT_ABL_NOW) || defined(USOT_ABL_NOWREAD)
 #pragma unroll
         for (int i = 0; i < TN; ++i) fw[slot][i] = f32x4{1.f + st, 2.f, 3.f + r, 4.f};
 #else
 #pragma unroll
-        for (int i = 0; i < TN; ++i) fw[slot][i] = *(const f32x4 *)(base + fw_off + i * 16 * LD);
+        for (int i = 0; i < TN; ++i) fw[slot][i] = *(const f32x4 *)(wbase + fw_off + i * 16 * LD);
 #endif
 #pragma unroll
         for (int j = 0; j < TM; ++j) fx[slot][j] = *(const f32x4 *)(base + fx_off + j * 16 * LD);
@@ -1102,6 +1181,7 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
     auto await_slot = [&](auto sc, auto nc) { await_(fw[decltype(sc)::value], fx[decltype(sc)::value], nc); };
     using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>;
     using R2 = std::integral_constant<int, 2>; using R3 = std::integral_constant<int, 3>;
+    int stw = 0;                                  // filter stage of k-tile t (filter-DMA tiles: t % NSW)
     if constexpr (H16) {
         if (nt > 0) { read_frags(0, 0, 0); read_frags(0, 2, 2); read_frags(0, 1, 1); read_frags(0, 3, 3); }
     } else if constexpr (PF == 3) {
@@ -1119,11 +1199,13 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW) void conv_igemm_f32_v3(con
             // tile t + 1 is complete in its stage since the barrier that ended step t - 1 (the producers run two tiles ahead): its
             // fragments are fetched as soon as a slot pair is free
             const bool more = t + 1 < nt;
+            const int stw1 = stw == NSW - 1 ? 0 : stw + 1;
             mma_h(acc, acc2, fw[0], fw[2], fx[0], fx[2], true);
-            if (more) { read_frags(st1, 0, 0); read_frags(st1, 2, 2); }
+            if (more) { read_frags(st1, 0, 0, stw1); read_frags(st1, 2, 2, stw1); }
             mma_h(acc, acc2, fw[1], fw[3], fx[1], fx[3], false);
-            if (more) { read_frags(st1, 1, 1); read_frags(st1, 3, 3); }
+            if (more) { read_frags(st1, 1, 1, stw1); read_frags(st1, 3, 3, stw1); }
             st = st1;
+            stw = stw1;
             USOT_STAMP(1, t);
             __syncthreads();
             USOT_STAMP(2, t);
@@ -2224,6 +2306,7 @@ struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int t
 #define TILE12(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw>, 64 * wm * wn + 64 * npw, d, 0, 8 }
 #define TILE13(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw, 3>, 64 * wm * wn + 64 * npw, d, 0, 3 }
 #define TILEH(bm, bn, wm, wn, d, npw) { bm, bn, 64, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, 64, d, npw, 4>, 64 * wm * wn + 64 * npw, d, 2, 4 }
+#define TILEHD(bm, bn, wm, wn, d, npw) { bm, bn, 64, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, 64, d, npw, 5>, 64 * wm * wn + 64 * npw + 256, d, 2, 5 }
 #define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d, 0, 0 }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
@@ -2335,6 +2418,14 @@ const TileCfg kTiles[] = {
     TILEH(32, 128, 2, 2, 2, 8),       // 102
     TILEH(64, 128, 2, 2, 2, 8),       // 103
     TILEH(32, 32, 2, 2, 2, 4),        // 104
+    TILEHD(32, 64, 2, 2, 2, 4),       // 105: split-fp16 with the filter tile moved by four LDS-DMA wavefronts into five stages (PF = 5)
+    TILEHD(32, 64, 2, 2, 3, 4),       // 106
+    TILEHD(32, 64, 2, 2, 2, 8),       // 107
+    TILEHD(32, 32, 2, 2, 2, 4),       // 108
+    TILEHD(64, 64, 2, 2, 2, 4),       // 109
+    TILEHD(64, 64, 2, 2, 2, 8),       // 110
+    TILEHD(32, 32, 2, 2, 3, 4),       // 111
+    TILEHD(64, 64, 2, 2, 3, 4),       // 112
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -2374,6 +2465,7 @@ extern "C" int usot_conv_tile_name(int tile, char *buf, int len)
     const TileCfg &t = kTiles[tile - 1];
     if (t.nst) { snprintf(buf, len, "conv_wstat_f32<NST=%d,RPS=%d>", t.nst, t.rps); return USOT_OK; }
     if (t.skfn) { snprintf(buf, len, "conv_igemm_f32_v3p<%d,%d,BK=%d,D=%d,NPW=%d>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
+    if (t.wfrag == 2 && t.dw == 5) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=5>", t.bm, t.bn, t.bk, t.depth, (t.threads - 512) / 64); return USOT_OK; }
     if (t.wfrag == 2) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=4>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.wfrag) { snprintf(buf, len, "conv_igemm_f32_ws<%d,%d,D=%d,NPW=%d,DW=%d>", t.bm, t.bn, t.depth, (t.threads - 256) / 64, t.dw); return USOT_OK; }
     if (t.dw == 8 && !t.wfrag) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,NCW=8>", t.bm, t.bn, t.bk, t.depth, (t.threads - 512) / 64); return USOT_OK; }
@@ -2660,7 +2752,8 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
     const int ld = (tc.bk == 64 && tc.wfrag == 1) ? 64 : tc.bk + 4;
     (void)v3fam;
 #endif
-    const size_t lds = (size_t)tc.ksw * tc.stages * (tc.bm + (tc.wfrag == 1 ? 0 : tc.bn)) * ld * sizeof(float);
+    size_t lds = (size_t)tc.ksw * tc.stages * (tc.bm + (tc.wfrag == 1 ? 0 : tc.bn)) * ld * sizeof(float);
+    if (tc.wfrag == 2 && tc.dw == 5) lds = (size_t)(3 * tc.bm + 5 * tc.bn) * ld * sizeof(float);      // three activation + five filter stages
     if (lds > 64 * 1024) {
         static bool raised[128] = {false};
         if (!raised[tile]) {

@@ -483,7 +483,10 @@ class Builder:
             triple = bool(fuse and O['fused_triple_f32'] and c2.kh == 3 and c2.stride == 1 and m2 <= O['fused_pointwise_f32_max_m']
                           and (c2.cin, c3.cin, c3.cout, nxt.cout) in O['fused_triple_f32_shapes']
                           and hip.lib().usot_pw_triple_f32_supported(c2.cin, c3.cin, c3.cout, nxt.cout))
-            dfr = O['defer_split_f32'].get((m2, c2.cout, c2.kh * c2.kw * c2.cin)) if (fuse and not triple and c2.kh == 3) else None
+            dk2_ = (m2, c2.cout, c2.kh * c2.kw * c2.cin)
+            dfr = O['defer_split_f32'].get(dk2_) if (fuse and not triple and c2.kh == 3) else None
+            if dfr is not None and O['split16_f32'] and dk2_ in O['defer_split_s16']:
+                dfr = O['defer_split_s16'][dk2_]         # the (tile, ksplit) tuned on the split-fp16 tiles
             return nxt, fuse, triple, dfr
 
         for bi, (c1, c2, c3, ds) in enumerate(W.blocks):
@@ -1287,6 +1290,8 @@ DEFAULT_OPTIONS = {
     # shortcut conv of layer2.0 already fills one round, a second workgroup per CU stretches every k-step by more than the halved loop saves
     'defer_split_res_f32': {},
     'defer_split_f32': {(961, 256, 2304): (55, 2), (1089, 256, 2304): (55, 2), (961, 128, 1152): (53, 2), (1089, 128, 1152): (53, 2)},
+    # ... and the (tile, ksplit) those deferred launches use when split16_f32 is on (filter-DMA tiles, csrc/conv_igemm.hip PF = 5)
+    'defer_split_s16': {(961, 256, 2304): (106, 2), (1089, 256, 2304): (106, 2), (961, 128, 1152): (111, 2), (1089, 128, 1152): (111, 2)},
 }
 ENV_SWITCHES = {      # environment variable -> (option, parser)
     'USOT_FUSED_TRIPLE_F32': ('fused_triple_f32', lambda v: v == '1'),
