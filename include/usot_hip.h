@@ -251,6 +251,12 @@ int usot_plan_add_conv_kstream(void *plan, const void *x, const void *w, const f
  * usot_pw_pair_f32_ws_floats (0 = not needed), zero before the first launch, owned by the caller; NULL = unsliced. */
 int usot_pw_pair_f32(void *stream, const usot_pw_pair_desc *d);
 int usot_pw_pair_f32_supported(int CM, int CO, int CN);
+/* The same pair on SPLIT-fp16 operands (csrc/smallm_f32.hip: GemmRing BLO > 0; the arithmetic of the split-fp16 conv tiles): d->w3p and
+ * d->w1 are the banks pre-split by the host - per column block of 16 rows and 32-k step a hi fragment (lane (quad, row) = 8 halves of
+ * row x 2^e, k = 32 step + 8 quad ..) then the lo fragment, followed by the bank's per-row factors 1 / (2^e x 8) as floats - and the
+ * kernel splits the staged pixel tile and its Y tile itself (x 8).  dtype 3 of usot_plan_add_pw_pair.  Shape (256, 1024, 256), sliced. */
+int usot_pw_pair_f32s(void *stream, const usot_pw_pair_desc *d);
+int usot_pw_pair_f32s_supported(int CM, int CO, int CN);
 int64_t usot_pw_pair_f32_ws_floats(int M, int CM, int CO, int CN);
 
 /* one pointwise convolution of the fp32 frame in the same style (16 pixels per workgroup, the pixel tile in LDS, filters

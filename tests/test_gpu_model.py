@@ -319,7 +319,7 @@ OPTION_VARIANTS = [{'fused_f32_sliced': False}, {'conf_tail_split': None}, {'con
                    {'defer_split_f32': {(961, 256, 2304): (55, 2), (1089, 256, 2304): (55, 3)}},
                    # split-fp16 arithmetic of the K >= 1152 convolutions: off (exact-fp32 MFMA everywhere), on for every K >= 256 tile
                    # conv too, without the filter-DMA tiles of the deferred launches
-                   {'split16_f32': False}, {'split16_min_k': 256, 'split16_min_m': 0}, {'defer_split_s16': {}}]
+                   {'split16_f32': False}, {'split16_min_k': 256, 'split16_min_m': 0}, {'defer_split_s16': {}}, {'split16_pairs': set()}]
 
 
 @pytest.mark.parametrize('variant', OPTION_VARIANTS, ids=lambda v: ','.join('%s=%s' % (k, str(v[k])[:40].replace(' ', '')) for k in sorted(v)))

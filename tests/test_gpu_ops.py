@@ -423,6 +423,36 @@ def test_pw_pair_f32_equals_the_two_convolutions(cm, co, cn, M):
     assert rel_err(tn.reshape(M, cn).cpu().numpy(), (y64 @ w1.double().t() + b1.double()).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('M', [961, 1089, 37])
+def test_pw_pair_f32_split_fp16_operands(M):
+    """usot_pw_pair_f32s: layer3's fused pair with every operand as hi + lo fp16 (three fp16 MFMAs per product block, fp32
+    accumulation; banks pre-split by hip.pw_pair_s16_pack, the pixel tile and the Y tile split in the kernel) against float64
+    at the fp32 kernel's own tolerance, and against the exact-fp32 form of the pair."""
+    cm, co, cn = 256, 1024, 256
+    g = torch.Generator().manual_seed(cm + cn + M)
+    t2 = torch.randn(M, cm, generator=g).abs()
+    w3 = torch.randn(co, cm, generator=g) / np.sqrt(cm)
+    b3 = torch.randn(co, generator=g)
+    res = torch.randn(M, co, generator=g)
+    w1 = torch.randn(cn, co, generator=g) / np.sqrt(co)
+    b1 = torch.randn(cn, generator=g)
+    y64 = F.relu(t2.double() @ w3.double().t() + b3.double() + res.double())
+    t64 = F.relu(y64 @ w1.double().t() + b1.double())
+    d = lambda t: t.to(DEV)
+    args = (d(t2).reshape(1, 1, M, cm), d(w3), d(b3), d(res).reshape(1, 1, M, co), d(w1), d(b1))
+    y, t = hip.pw_pair_f32(*args, split16=True)
+    e_y, e_t = rel_err(y.reshape(M, co).cpu().numpy(), y64.numpy()), rel_err(t.reshape(M, cn).cpu().numpy(), t64.numpy())
+    assert e_y < 1e-5 and e_t < 1e-5, (e_y, e_t)
+    y0, t0 = hip.pw_pair_f32(*args)
+    assert rel_err(y.cpu().numpy(), y0.cpu().numpy()) < 1e-5 and rel_err(t.cpu().numpy(), t0.cpu().numpy()) < 1e-5
+    # a second launch finds the slice tickets reset, and a very wide dynamic range inside one row of the tile survives the split
+    t2w = t2.clone(); t2w[:, ::7] *= 1e-4; t2w[:, 3::11] *= 300.0
+    y64 = F.relu(t2w.double() @ w3.double().t() + b3.double() + res.double())
+    t64 = F.relu(y64 @ w1.double().t() + b1.double())
+    y, t = hip.pw_pair_f32(d(t2w).reshape(1, 1, M, cm), *args[1:], split16=True)
+    assert rel_err(y.reshape(M, co).cpu().numpy(), y64.numpy()) < 1e-5 and rel_err(t.reshape(M, cn).cpu().numpy(), t64.numpy()) < 1e-5
+
+
 @pytest.mark.parametrize('K,N,M,res', [(256, 1024, 961, True), (128, 512, 961, True), (1024, 256, 961, False), (512, 128, 1089, False),
                                        (256, 1024, 5, True)])
 def test_pw_single_f32_streaming_conv(K, N, M, res):

@@ -768,7 +768,7 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void
     // receives a dummy load), so the consumers' fragment addresses do not change; 1 KiB pieces are c = 64 piece + lane.
     constexpr bool WDMA = PF == 5;
     constexpr int NDW = WDMA ? 4 : 0;             // filter-DMA wavefronts
-    constexpr int NSW = WDMA ? 5 : 3;             // filter stages
+    constexpr int NSW = WDMA ? (D >= 4 ? 6 : 5) : 3;   // filter stages (six on the tiles whose activation producers run four k-tiles deep)
     constexpr int LA = NSW - 1;                   // the DMA runs LA k-tiles ahead
     // LDS rows.  BK = 64: a row is 256 B = one bank row, UNPADDED, 16-byte chunk c of tile row `row` stored at chunk
     // c ^ (row & 15).  ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md
@@ -2426,6 +2426,9 @@ const TileCfg kTiles[] = {
     TILEHD(64, 64, 2, 2, 2, 8),       // 110
     TILEHD(32, 32, 2, 2, 3, 4),       // 111
     TILEHD(64, 64, 2, 2, 3, 4),       // 112
+    TILEHD(32, 64, 2, 2, 4, 4),       // 113: D = 4 and SIX filter stages (the DMA five k-tiles ahead)
+    TILEHD(32, 32, 2, 2, 4, 4),       // 114
+    TILEHD(32, 64, 2, 2, 4, 8),       // 115
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -2753,7 +2756,7 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
     (void)v3fam;
 #endif
     size_t lds = (size_t)tc.ksw * tc.stages * (tc.bm + (tc.wfrag == 1 ? 0 : tc.bn)) * ld * sizeof(float);
-    if (tc.wfrag == 2 && tc.dw == 5) lds = (size_t)(3 * tc.bm + 5 * tc.bn) * ld * sizeof(float);      // three activation + five filter stages
+    if (tc.wfrag == 2 && tc.dw == 5) lds = (size_t)(3 * tc.bm + (tc.depth >= 4 ? 6 : 5) * tc.bn) * ld * sizeof(float);      // three activation + five (six) filter stages
     if (lds > 64 * 1024) {
         static bool raised[128] = {false};
         if (!raised[tile]) {

@@ -125,7 +125,7 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
         case K_KSTREAM:
             rc = usot_pw_kstream_lp(s, op.p[0], op.p[1], (const float *)op.p[2], (void *)op.p[3], op.l[0], op.i[1], op.i[2], op.i[3], op.i[6]);
             break;
-        case K_PWPAIR: rc = op.i[6] == 2 ? usot_pw_pair_f32(s, &op.pw) : usot_pw_pair_lp(s, &op.pw, op.i[6]); break;
+        case K_PWPAIR: rc = op.i[6] == 3 ? usot_pw_pair_f32s(s, &op.pw) : op.i[6] == 2 ? usot_pw_pair_f32(s, &op.pw) : usot_pw_pair_lp(s, &op.pw, op.i[6]); break;
         case K_PW3:
             rc = usot_pw_triple_f32(s, (const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], &op.pw,
                                     op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], op.i[7], (int)op.l[0], (int)op.l[1]);
@@ -273,10 +273,10 @@ extern "C" int usot_plan_add_conv_bf16(void *plan, const usot_conv_desc *d) { re
 
 extern "C" int usot_plan_add_pw_pair(void *plan, const usot_pw_pair_desc *d, int dtype)
 {
-    if (!d || !(dtype == 2 ? usot_pw_pair_f32_supported(d->CM, d->CO, d->CN) : usot_pw_pair_supported(d->CM, d->CO, d->CN))) return USOT_EINVAL;
+    if (!d || !(dtype == 3 ? usot_pw_pair_f32s_supported(d->CM, d->CO, d->CN) : dtype == 2 ? usot_pw_pair_f32_supported(d->CM, d->CO, d->CN) : usot_pw_pair_supported(d->CM, d->CO, d->CN))) return USOT_EINVAL;
     // the fp32 (256, 1024, 256) pair exists in the channel-sliced form only: it needs M small enough to slice AND a workspace —
     // refuse it here, at build time, not at the first run / graph capture
-    if (dtype == 2 && d->CM == 256 && !(d->ws && usot_pw_pair_f32_ws_floats(d->M, d->CM, d->CO, d->CN) > 0)) return USOT_EINVAL;
+    if ((dtype == 2 || dtype == 3) && d->CM == 256 && !(d->ws && usot_pw_pair_f32_ws_floats(d->M, d->CM, d->CO, d->CN) > 0)) return USOT_EINVAL;
     Op *op = push(plan, K_PWPAIR);
     if (!op) return USOT_ESTATE;
     op->pw = *d;

@@ -48,6 +48,8 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 struct PwF {
     const float *t2, *w3p, *b3, *res, *w1p, *b1;
@@ -63,9 +65,15 @@ struct PwF {
 // wf: the bank's fragment (cb, r) at wf[(cb * RT + r) * 64] (lane offset already applied); bs: this lane's LDS row.
 // A ring of PF filter fragments (1 KiB per wave each) stays in flight; gemm_prefetch fills it (callable before the B
 // operand is ready: in front of the barrier that publishes it), gemm_run consumes and refills it.
-template <int CBW, int RS, int RT, int PF>
+// BLO > 0: SPLIT-fp16 operands (conv_igemm.hip, PF = 4: every value as hi + lo fp16 of value x a power of two, a product block
+// as w_lo x_hi + w_hi x_lo + w_hi x_hi on v_mfma_f32_16x16x32_f16, fp32 accumulation).  The bank then holds, per column block
+// and 32-k step, a hi fragment followed by a lo fragment (1 KiB each: lane (quad, row) = 8 halves of k = 32 step + 8 quad ..),
+// i.e. the same RT fragments per column block; a B row in LDS is its K hi halves followed by its K lo halves (BLO = K / 2
+// floats in), so lane (l15, quad) finds the hi fragment of step s at float 16 s + 4 quad as before and the lo one BLO further.
+template <int CBW, int RS, int RT, int PF, int BLO = 0>
 struct GemmRing {
     static constexpr int N = CBW * RS;
+    static_assert(BLO == 0 || (RS % 4 == 0 && PF % 2 == 0), "split-fp16: whole 64-k blocks, fragments in pairs");
     static_assert(PF <= N, "ring deeper than the work");
     f32x4 ring[PF];
     __device__ __forceinline__ f32x4 frag(const f32x4 *__restrict__ wf, int cb0, int r0, int n) const
@@ -88,6 +96,23 @@ struct GemmRing {
         BlockTotal tot[CBW];                              // running total of finished blocks (common.h)
 #pragma unroll
         for (int u = 0; u < CBW; ++u) { part[u][0] = part[u][1] = zero; tot[u].clear(); }
+        if constexpr (BLO > 0) {
+            auto h = [](const f32x4 &v) { return __builtin_bit_cast(f16x8_t, v); };
+#pragma unroll
+            for (int n = 0; n < N; n += 2) {
+                const int step = (r0 + n % RS) >> 1;
+                const f32x4 bh = *(const f32x4 *)(bs + step * 16), bl = *(const f32x4 *)(bs + BLO + step * 16);
+                const f32x4 ah = ring[n % PF], al = ring[(n + 1) % PF];
+                if (n + PF < N) ring[n % PF] = frag(wf, cb0, r0, n + PF);
+                if (n + 1 + PF < N) ring[(n + 1) % PF] = frag(wf, cb0, r0, n + 1 + PF);
+                const int u = n / RS, rr = n % RS, g = rr / G, s = g & 1;
+                const bool first = rr % G == 0;
+                if (first && g >= 2) tot[u].add(part[u][s]);
+                part[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(al), h(bh), first ? zero : part[u][s], 0, 0, 0);
+                part[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(ah), h(bl), part[u][s], 0, 0, 0);
+                part[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h(ah), h(bh), part[u][s], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int n = 0; n < N; ++n) {
             const f32x4 b = *(const f32x4 *)(bs + (r0 + n % RS) * 16);
@@ -100,6 +125,7 @@ struct GemmRing {
             for (int c = 0; c < 4; ++c)
                 part[u][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], (first && c == 0) ? zero : part[u][s], 0, 0, 0);
         }
+        }
 #pragma unroll
         for (int u = 0; u < CBW; ++u) {                   // the last one or two blocks of every column block are still open
             constexpr int GL = (RS - 1) / G;              // index of the last block
@@ -110,17 +136,32 @@ struct GemmRing {
     }
 };
 
-template <int CBW, int RS, int RT>
+template <int CBW, int RS, int RT, int BLO = 0>
 __device__ __forceinline__ void gemm_blocks(const f32x4 *__restrict__ wf, const float *bs, int cb0, int r0, f32x4 (&acc)[CBW])
 {
-    GemmRing<CBW, RS, RT, (CBW * RS < USOT_RING ? CBW * RS : USOT_RING)> g;
+    GemmRing<CBW, RS, RT, (CBW * RS < USOT_RING ? CBW * RS : USOT_RING), BLO> g;
     g.prefetch(wf, cb0, r0);
     g.run(wf, bs, cb0, r0, acc);
 }
 
+// four consecutive values of an LDS operand row in the split-fp16 layout: halves k .. k + 3 of the hi plane and of the lo plane
+// (`row` = the row's first byte, `plane` = bytes from the hi plane to the lo plane = 2 K); the values are scaled by 8 first
+__device__ __forceinline__ void store_split4(char *row, int k, int plane, f32x4 v)
+{
+    v *= 8.0f;
+    const uint32_t hi0 = usot_pack2_lp<true>(v[0], v[1]), hi1 = usot_pack2_lp<true>(v[2], v[3]);
+    const usot_f16x2 h0 = __builtin_bit_cast(usot_f16x2, hi0), h1 = __builtin_bit_cast(usot_f16x2, hi1);
+    const uint32_t lo0 = usot_pack2_lp<true>(v[0] - (float)h0[0], v[1] - (float)h0[1]);
+    const uint32_t lo1 = usot_pack2_lp<true>(v[2] - (float)h1[0], v[3] - (float)h1[1]);
+    *(u32x2_t *)(row + k * 2) = u32x2_t{hi0, hi1};
+    *(u32x2_t *)(row + plane + k * 2) = u32x2_t{lo0, lo1};
+}
+
 // Everything after "the pixel tile is in LDS": GEMM1 + residual + ReLU -> Y (global + LDS), GEMM2 (+ wave-group / workgroup
 // meeting) -> T.  Xs: the [16][CM + 4] tile (published by a barrier before the call); Ys / Ps: scratch.
-template <int CM, int COT, int CN, int S>
+// H16: split-fp16 operands (GemmRing, BLO > 0): both banks pre-split with their per-row factors 1 / (row scale x 8) appended
+// (w3p[COT CM ..], w1p[CN COT ..]: hip.pw_pair_s16_pack), the pixel tile staged split by the caller, the Y tile split here.
+template <int CM, int COT, int CN, int S, bool H16 = false>
 __device__ __forceinline__ void pair_tail(const PwF &p, const float *Xs, float *Ys, float *Ps, int pt, int sl)
 {
     constexpr int NW = 8, BM = 16;
@@ -141,10 +182,11 @@ __device__ __forceinline__ void pair_tail(const PwF &p, const float *Xs, float *
 
     // ---- GEMM1: K = CM from the pixel tile; this wave's CBW1 column blocks of the slice (residual and bias fly under it)
     {
-        f32x4 rr[CBW1], bb[CBW1];
+        f32x4 rr[CBW1], bb[CBW1], sc[H16 ? CBW1 : 1];
 #pragma unroll
         for (int u = 0; u < CBW1; ++u) {
             const int cog = sl * CO + (wave * CBW1 + u) * 16 + quad * 4;
+            if constexpr (H16) sc[u] = *(const f32x4 *)(p.w3p + (long)COT * CM + cog);
             rr[u] = mok ? *(const f32x4 *)(p.res + (long)m * COT + cog) : f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.rparts > 1 && mok) {       // deferred split-K reduction of the shortcut convolution: parts in order, then its bias
                 for (int q = 1; q < p.rparts; ++q) rr[u] += *(const f32x4 *)(p.res + ((long)q * p.M + m) * COT + cog);
@@ -153,15 +195,17 @@ __device__ __forceinline__ void pair_tail(const PwF &p, const float *Xs, float *
             bb[u] = *(const f32x4 *)(p.b3 + cog);
         }
         f32x4 acc[CBW1];
-        gemm_blocks<CBW1, R1, R1>((const f32x4 *)p.w3p + lane + (long)sl * NB1 * R1 * 64, Xs + l15 * XP + quad * 4, wave * CBW1, 0, acc);
+        gemm_blocks<CBW1, R1, R1, H16 ? CM / 2 : 0>((const f32x4 *)p.w3p + lane + (long)sl * NB1 * R1 * 64, Xs + l15 * XP + quad * 4, wave * CBW1, 0, acc);
 #pragma unroll
         for (int u = 0; u < CBW1; ++u) {
             const int co = (wave * CBW1 + u) * 16 + quad * 4;              // within the slice
+            if constexpr (H16) acc[u] *= sc[u];
             f32x4 v = acc[u] + bb[u] + rr[u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             if (mok) *(f32x4 *)(p.y + (long)m * COT + sl * CO + co) = v;
-            *(f32x4 *)(Ys + l15 * YP + co) = v;
+            if constexpr (H16) store_split4((char *)(Ys + l15 * YP), co, CO * 2, v);
+            else *(f32x4 *)(Ys + l15 * YP + co) = v;
         }
     }
     __syncthreads();                                      // Y tile (slice) complete
@@ -170,7 +214,11 @@ __device__ __forceinline__ void pair_tail(const PwF &p, const float *Xs, float *
     const int ksl = KS > 1 ? wave / NB2 : 0;
     const int cb0 = KS > 1 ? wave % NB2 : wave * CBW2;
     f32x4 acc[CBW2];
-    gemm_blocks<CBW2, RS2, R2T>((const f32x4 *)p.w1p + lane + (long)sl * R2 * 64, Ys + l15 * YP + quad * 4, cb0, ksl * RS2, acc);
+    gemm_blocks<CBW2, RS2, R2T, H16 ? CO / 2 : 0>((const f32x4 *)p.w1p + lane + (long)sl * R2 * 64, Ys + l15 * YP + quad * 4, cb0, ksl * RS2, acc);
+    if constexpr (H16) {                                  // unscaled partial sums from here on (exact: powers of two)
+#pragma unroll
+        for (int u = 0; u < CBW2; ++u) acc[u] *= *(const f32x4 *)(p.w1p + (long)CN * COT + (cb0 + u) * 16 + quad * 4);
+    }
     if constexpr (KS > 1) {                               // wave groups meet in LDS
         const int cn = cb0 * 16 + quad * 4;
         if (ksl > 0) *(f32x4 *)(Ps + ((ksl - 1) * BM + l15) * PP + cn) = acc[0];
@@ -222,7 +270,7 @@ __device__ __forceinline__ void pair_tail(const PwF &p, const float *Xs, float *
 
 template <int CN, int KSG> constexpr int ps_floats() { return KSG > 1 ? (KSG - 1) * 16 * (CN + 4) : 16; }
 
-template <int CM, int COT, int CN, int S = 1>
+template <int CM, int COT, int CN, int S = 1, bool H16 = false>
 __global__ __launch_bounds__(512) void pw_pair_f32_kernel(const PwF p)
 {
     constexpr int NW = 8, BM = 16, XP = CM + 4, NB2 = CN / 16, KS = NB2 >= NW ? 1 : NW / NB2;
@@ -249,18 +297,20 @@ __global__ __launch_bounds__(512) void pw_pair_f32_kernel(const PwF p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            *(f32x4 *)(Xs + row * XP + c4 * 4) = v;
+            if constexpr (H16) store_split4((char *)(Xs + row * XP), c4 * 4, CM * 2, v);
+            else *(f32x4 *)(Xs + row * XP + c4 * 4) = v;
         }
     } else {
         for (int i = tid; i < BM * (CM / 4); i += NW * 64) {
             const int row = i / (CM / 4), c4 = i - row * (CM / 4);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (bm0 + row < p.M) v = *(const f32x4 *)(p.t2 + (long)(bm0 + row) * CM + c4 * 4);
-            *(f32x4 *)(Xs + row * XP + c4 * 4) = v;
+            if constexpr (H16) store_split4((char *)(Xs + row * XP), c4 * 4, CM * 2, v);
+            else *(f32x4 *)(Xs + row * XP + c4 * 4) = v;
         }
     }
     __syncthreads();
-    pair_tail<CM, COT, CN, S>(p, Xs, Ys, Ps, pt, sl);
+    pair_tail<CM, COT, CN, S, H16>(p, Xs, Ys, Ps, pt, sl);
 }
 
 // ---- a whole bottleneck tail in one launch (layer1 at batch 1): conv2 (3x3 / stride 1, CIN -> CM) + BN + ReLU, then the
@@ -339,9 +389,9 @@ __global__ __launch_bounds__(512) void pw_triple_f32_kernel(const PwT q)
     pair_tail<CM, COT, CN, 1>(p, Xs, Ys, Ps, pt, 0);
 }
 
-template <int CM, int CO, int CN, int S = 1> int launch(hipStream_t s, const PwF &p)
+template <int CM, int CO, int CN, int S = 1, bool H16 = false> int launch(hipStream_t s, const PwF &p)
 {
-    hipLaunchKernelGGL((pw_pair_f32_kernel<CM, CO, CN, S>), dim3(((p.M + 15) / 16) * S), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((pw_pair_f32_kernel<CM, CO, CN, S, H16>), dim3(((p.M + 15) / 16) * S), dim3(512), 0, s, p);
     return hipGetLastError() == hipSuccess ? USOT_OK : USOT_ELAUNCH;
 }
 
@@ -567,7 +617,18 @@ extern "C" int64_t usot_pw_pair_f32_ws_floats(int M, int CM, int CO, int CN)
     return S > 1 ? (int64_t)S * M * CN + (M + 15) / 16 : 0;
 }
 
-extern "C" int usot_pw_pair_f32(void *stream, const usot_pw_pair_desc *d)
+static int pw_pair_f32_launch(void *stream, const usot_pw_pair_desc *d, bool split16);
+
+extern "C" int usot_pw_pair_f32(void *stream, const usot_pw_pair_desc *d) { return pw_pair_f32_launch(stream, d, false); }
+
+/* The same pair on SPLIT-fp16 operands (shapes: usot_pw_pair_f32s_supported): d->w3p / d->w1 are the banks pre-split by
+ * usot_amd/hip.py: pw_pair_s16_pack - per column block of 16 rows and 32-k step a hi fragment then a lo fragment, followed by the
+ * bank's per-row factors 1 / (row scale x 8); everything else as usot_pw_pair_f32.  Values staged into LDS must be below 8 188. */
+extern "C" int usot_pw_pair_f32s(void *stream, const usot_pw_pair_desc *d) { return pw_pair_f32_launch(stream, d, true); }
+
+extern "C" int usot_pw_pair_f32s_supported(int CM, int CO, int CN) { return CM == 256 && CO == 1024 && CN == 256; }
+
+static int pw_pair_f32_launch(void *stream, const usot_pw_pair_desc *d, bool split16)
 {
     if (!d || !d->t2 || !d->w3p || !d->b3 || !d->res || !d->w1 || !d->b1 || !d->y || !d->t || d->M <= 0) return USOT_EINVAL;
     if (d->act2 != USOT_ACT_NONE && d->act2 != USOT_ACT_RELU) return USOT_EINVAL;
@@ -584,6 +645,10 @@ extern "C" int usot_pw_pair_f32(void *stream, const usot_pw_pair_desc *d)
     p.rbias = d->res_bias;
     hipStream_t s = (hipStream_t)stream;
     const bool sliced = slices(d->M, d->CM, d->CN) > 1 && d->ws;          /* no workspace: the unsliced form */
+    if (split16) {
+        if (d->CM == 256 && d->CO == 1024 && d->CN == 256 && sliced) return launch<256, 1024, 256, 4, true>(s, p);
+        return USOT_EINVAL;
+    }
     if (d->CM == 64 && d->CO == 256 && d->CN == 64) return launch<64, 256, 64>(s, p);
     if (d->CM == 64 && d->CO == 256 && d->CN == 128) return launch<64, 256, 128>(s, p);
     if (d->CM == 128 && d->CO == 512 && d->CN == 128) return sliced ? launch<128, 512, 128, 4>(s, p) : launch<128, 512, 128>(s, p);

@@ -75,6 +75,12 @@ class PackedConv:
             self._wpp32 = hip.pw_pair_f32_pack(self.w)
         return self._wpp32
 
+    def w_pw_pair_s16(self):
+        """split-fp16 bank + row factors for the split-fp16 form of the fused pair (hip.pw_pair_s16_pack)."""
+        if '_wpps16' not in self.__dict__:
+            self._wpps16 = hip.pw_pair_s16_pack(self.w)
+        return self._wpps16
+
     def w_frag(self):
         """fp32 filter bank in MFMA fragment order for the weight-streaming / weight-stationary conv tiles
         (hip.pack_wfrag: a permutation inside every 16-row block, so row offsets that are multiples of 16 keep their meaning)."""
@@ -710,7 +716,11 @@ class Builder:
         m = n * h * h
         y = self.buf(n, h, h, c3.cout)
         t = self.buf(n, h, h, nxt.cout)
-        w3p, w1p = c3.w_pw_pair_f32(), nxt.w_pw_pair_f32()
+        # 'split16_pairs': the pair on split-fp16 operands (usot_pw_pair_f32s; the arithmetic of the split-fp16 conv tiles)
+        s16 = bool(self.opt['split16_f32'] and (c3.cin, c3.cout, nxt.cout) in self.opt['split16_pairs'] and self.opt['fused_f32_sliced']
+                   and hip.lib().usot_pw_pair_f32s_supported(c3.cin, c3.cout, nxt.cout)
+                   and hip.lib().usot_pw_pair_f32_ws_floats(m, c3.cin, c3.cout, nxt.cout) > 0)
+        w3p, w1p = (c3.w_pw_pair_s16(), nxt.w_pw_pair_s16()) if s16 else (c3.w_pw_pair_f32(), nxt.w_pw_pair_f32())
         # channel-sliced form (four workgroups per pixel tile when there are few tiles): 13.6 -> 8.7 us per layer2 pair, but
         # its k-sliced second GEMM moved ONE end-to-end golden output from 9.3e-5 to 1.011e-4 of the 1e-4 bar
         # (scripts/golden_margins.py; rounding noise, every variant sits at 8-9.5e-5) - off unless asked for
@@ -720,7 +730,7 @@ class Builder:
                              ws.data_ptr() if ws is not None else None,
                              t2_parts=t2_parts, t2_bias=t2_bias.data_ptr() if t2_bias is not None else None,
                              res_parts=res_parts, res_bias=res_bias.data_ptr() if res_bias is not None else None)
-        hip.check(hip.lib().usot_plan_add_pw_pair(self.plan.h, C.byref(d), 2), 'plan_add_pw_pair(f32) ' + name)
+        hip.check(hip.lib().usot_plan_add_pw_pair(self.plan.h, C.byref(d), 3 if s16 else 2), 'plan_add_pw_pair(f32) ' + name)
         self.plan.keep += [t2, res, w3p, w1p, c3.b, nxt.b, ws, t2_bias, res_bias]
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
         self.f32_bytes.append(4 * (m * (c3.cin + 2 * c3.cout + nxt.cout) + c3.cout * c3.cin + nxt.cout * c3.cout))
@@ -1184,6 +1194,8 @@ DEFAULT_OPTIONS = {
     # operand as hi + lo fp16, three fp16 MFMAs per product block, fp32 accumulation: csrc/conv_igemm.hip PF = 4)
     'split16_f32': True,
     'split16_min_k': 1152,
+    # (CM, CO, CN) of the fused fp32 pointwise pairs that run on split-fp16 operands too (layer3's six conv3 + conv1 pairs)
+    'split16_pairs': {(256, 1024, 256)},
     'split16_min_m': 64,
     # Session: frame t's bank append (encode + scatter) runs at the start of frame t + 1's graph on a side branch, not behind
     # frame t's result tag (Session._build)

@@ -29,7 +29,7 @@ EXPORTS = (
     'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
     'PrRoIPoolingForwardGpu', 'usot_groupdw_auto_variant',
-    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_bw_probe', 'usot_conv_kstream_lp', 'usot_conv_kstream_supported', 'usot_plan_add_conv_kstream', 'usot_pw_kstream_lp', 'usot_pw_kstream_supported', 'usot_plan_add_pw_kstream', 'usot_conv3x3_halo_lp', 'usot_conv3x3_halo_supported', 'usot_plan_add_conv3x3_halo', 'usot_bneck_first_lp', 'usot_bneck_first_supported', 'usot_plan_add_bneck_first', 'usot_bneck_tail_lp', 'usot_bneck_tail_supported', 'usot_plan_add_bneck_tail', 'usot_pw_panel_lp', 'usot_pw_panel_supported', 'usot_pw_panel_pixels', 'usot_pw_panel_min_pixels', 'usot_plan_add_pw_panel', 'usot_pw_panel_pair_lp', 'usot_pw_panel_pair_supported', 'usot_plan_add_pw_panel_pair', 'usot_stem_conv_mu_f32', 'usot_stem_pool_mu_f32', 'usot_plan_add_stem_pool_mu', 'usot_plan_add_stem_mu', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single', 'usot_stream_conv3x3_f32', 'usot_stream_conv3x3_f32_supported', 'usot_plan_add_stream_conv3x3', 'usot_pw_triple_f32', 'usot_pw_triple_f32_supported', 'usot_plan_add_pw_triple',
+    'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_bw_probe', 'usot_conv_kstream_lp', 'usot_conv_kstream_supported', 'usot_plan_add_conv_kstream', 'usot_pw_kstream_lp', 'usot_pw_kstream_supported', 'usot_plan_add_pw_kstream', 'usot_conv3x3_halo_lp', 'usot_conv3x3_halo_supported', 'usot_plan_add_conv3x3_halo', 'usot_bneck_first_lp', 'usot_bneck_first_supported', 'usot_plan_add_bneck_first', 'usot_bneck_tail_lp', 'usot_bneck_tail_supported', 'usot_plan_add_bneck_tail', 'usot_pw_panel_lp', 'usot_pw_panel_supported', 'usot_pw_panel_pixels', 'usot_pw_panel_min_pixels', 'usot_plan_add_pw_panel', 'usot_pw_panel_pair_lp', 'usot_pw_panel_pair_supported', 'usot_plan_add_pw_panel_pair', 'usot_stem_conv_mu_f32', 'usot_stem_pool_mu_f32', 'usot_plan_add_stem_pool_mu', 'usot_plan_add_stem_mu', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32s', 'usot_pw_pair_f32s_supported', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single', 'usot_stream_conv3x3_f32', 'usot_stream_conv3x3_f32_supported', 'usot_plan_add_stream_conv3x3', 'usot_pw_triple_f32', 'usot_pw_triple_f32_supported', 'usot_plan_add_pw_triple',
 )
 
 
@@ -151,6 +151,8 @@ def lib():
         L.usot_pw_pair_supported.argtypes = [C.c_int] * 3
         L.usot_pw_pair_f32.argtypes = [C.c_void_p, C.c_void_p]
         L.usot_pw_pair_f32_supported.argtypes = [C.c_int] * 3
+        L.usot_pw_pair_f32s.argtypes = [C.c_void_p, C.c_void_p]
+        L.usot_pw_pair_f32s_supported.argtypes = [C.c_int] * 3
         L.usot_pw_pair_f32_ws_floats.argtypes = [C.c_int] * 4
         L.usot_pw_pair_f32_ws_floats.restype = C.c_int64
         L.usot_pw_single_f32.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4
@@ -607,11 +609,29 @@ def pw_pair_f32_pack(w):
     return w.reshape(rows // 16, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
 
 
+def pw_pair_s16_pack(w):
+    """fp32 filter bank [rows, K] -> the split-fp16 bank of usot_pw_pair_f32s as one float32 tensor: rows x K floats of fragments
+    (column block of 16 rows, 32-k step, hi | lo, quad, row in block, 8 halves) followed by the rows' factors 1 / (2^e x 8)."""
+    rows, k = w.shape
+    assert rows % 16 == 0 and k % 32 == 0
+    w = w.float()
+    amax = w.abs().amax(1)
+    e = torch.where(amax > 0, torch.floor(torch.log2(1024.0 / amax.clamp_min(1e-30))), torch.zeros_like(amax))
+    e = torch.where(amax * torch.exp2(e) >= 1024.0, e - 1, e).clamp(-60, 60)
+    sw = torch.exp2(e)
+    ws = w * sw[:, None]
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    frag = lambda t: t.reshape(rows // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4)          # (cb, step, quad, row, 8)
+    packed = torch.stack([frag(hi), frag(lo)], 2).contiguous().reshape(-1)                      # (cb, step, hi | lo, quad, row, 8)
+    return torch.cat([packed.view(torch.float32), (1.0 / (sw * SPLIT16_X_SCALE)).float()]).contiguous()
+
+
 def pw_pair_f32_supported(cm, co, cn):
     return bool(lib().usot_pw_pair_f32_supported(int(cm), int(co), int(cn)))
 
 
-def pw_pair_f32(t2, w3, b3, res, w1, b1, act2=ACT_RELU, sliced=True):
+def pw_pair_f32(t2, w3, b3, res, w1, b1, act2=ACT_RELU, sliced=True, split16=False):
     """fp32 NHWC: Y = relu(t2 . w3^T + b3 + res), T = act2(Y . w1^T + b1); w3 [CO,CM], w1 [CN,CO] in natural order
     (packed here).  Returns (Y, T)."""
     for t in (t2, w3, b3, res, w1, b1):
@@ -620,13 +640,14 @@ def pw_pair_f32(t2, w3, b3, res, w1, b1, act2=ACT_RELU, sliced=True):
     M = t2.numel() // CM
     y = torch.empty(tuple(t2.shape[:-1]) + (CO,), device=t2.device, dtype=torch.float32)
     t = torch.empty(tuple(t2.shape[:-1]) + (CN,), device=t2.device, dtype=torch.float32)
-    w3p, w1p = pw_pair_f32_pack(w3), pw_pair_f32_pack(w1)
+    w3p, w1p = (pw_pair_s16_pack(w3), pw_pair_s16_pack(w1)) if split16 else (pw_pair_f32_pack(w3), pw_pair_f32_pack(w1))
     ws = pw_pair_f32_ws(M, CM, CO, CN, t2.device) if sliced else None
     d = pw_pair_desc(t2.data_ptr(), w3p.data_ptr(), b3.data_ptr(), res.data_ptr(), y.data_ptr(), w1p.data_ptr(), b1.data_ptr(),
                      t.data_ptr(), M, CM, CO, CN, act2, ws.data_ptr() if ws is not None else None)
-    check(lib().usot_pw_pair_f32(stream(), C.byref(d)), 'usot_pw_pair_f32')
+    fn = lib().usot_pw_pair_f32s if split16 else lib().usot_pw_pair_f32
+    check(fn(stream(), C.byref(d)), 'usot_pw_pair_f32')
     if ws is not None:
-        check(lib().usot_pw_pair_f32(stream(), C.byref(d)), 'usot_pw_pair_f32')      # a second launch finds the tickets reset
+        check(fn(stream(), C.byref(d)), 'usot_pw_pair_f32')      # a second launch finds the tickets reset
     return y, t
 
 
