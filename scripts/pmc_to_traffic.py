@@ -38,6 +38,8 @@ def norm(sym):
         return 'conv_igemm_f32<%d,%d>' % (a[0], a[1])
     if fam == '_v3':
         d = a[5] if len(a) > 5 else 1                 # register prefetch depth (tile ids 37-52)
+        if len(a) > 7 and a[7] in (4, 5):             # split-fp16 tiles (usot_conv_tile_name: ...,NPW=n,PF=4|5)
+            return 'conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=%d>' % (a[0], a[1], a[4], d, a[6], a[7])
         if len(a) > 6 and a[6] == 8:                  # eight producer waves (tile ids 53-60)
             return 'conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=8>' % (a[0], a[1], a[4], d)
         return ('conv_igemm_f32_v3<%d,%d,BK=%d,D=%d>' % (a[0], a[1], a[4], d)) if d > 1 else \
