@@ -735,9 +735,11 @@ def main():
             'n_gpus': world, 'steps': steps, 'steps_requested': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            # fp32 storage and accumulation everywhere; the K >= 1152 convolutions form their products from fp16 hi + lo splits of the
-            # fp32 operands (22 significant bits, engine option split16_f32; False = exact fp32 MFMA) - same 1e-4 parity bar
-            'dtype': 'f32 (split-fp16 products, fp32 accumulate, for K>=1152 convs)' if model.engine.opt.get('split16_f32') else 'f32',
+            # fp32 storage and accumulation everywhere; the K >= 1152 convolutions and layer3's fused 1x1 pairs form their products from
+            # fp16 hi + lo splits of the fp32 operands (22 significant bits, engine option split16_f32; False = exact fp32 MFMA) -
+            # same 1e-4 parity bar
+            'dtype': ('f32 (split-fp16 products with fp32 accumulation in the K>=1152 convs and layer3\'s fused 1x1 pairs)'
+                      if model.engine.opt.get('split16_f32') else 'f32'),
             'data': 'synthetic',
             'config': {'workload': 'configs[1]: batch=1 ResNet-50(layer3)+neck, fused depthwise xcorr, cls/reg/'
                                    'memory heads (N_q=7), decode + PrRoIPool, fp32, 1 stream per GPU',
