@@ -85,6 +85,38 @@ def test_conv_igemm(case, tile):
     assert rel_err(y.cpu().numpy(), ref.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize('tile', [91, 99, 106, 97, 94, 111])
+def test_split_fp16_tiles_range_contract(tile):
+    """The split-fp16 conv tiles (csrc/conv_igemm.hip PF = 4 / 5) promise fp32-level results for activations below 8 188 in
+    magnitude whatever the filter rows' scale: activations spanning 1e-6 .. 5e3 inside one pixel row, filter rows of 1e-12, 1e+3
+    and all zeros beside ordinary ones, negative values, split-K with the in-launch combine.  Against float64; the tolerance is
+    the exact-fp32 tile's (2e-5 of the output scale, measured ~1e-6).  Above the range the output must show it (inf / nan), not
+    return finite garbage."""
+    g = torch.Generator().manual_seed(17 + tile)
+    N, Cin, H, W, Cout, k = 1, 128, 13, 11, 128, 3
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x[:, ::5] *= 1e-6
+    x[:, 3::7] *= 5e3 / 4.5                     # |x| up to ~5e3
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    w[5] *= 1e-12
+    w[6] *= 1e3
+    w[7] = 0.0
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1).float()
+    xd, wd, bd = x.permute(0, 2, 3, 1).contiguous().to(DEV), pack_w(w).to(DEV), b.to(DEV)
+    for ks in (1, 3):
+        y = hip.conv2d(xd, wd, bd, KH=k, KW=k, pad=(1, 1), tile=tile, ksplit=ks).permute(0, 3, 1, 2).cpu()
+        assert torch.isfinite(y).all()
+        # per output channel: the error is judged against that channel's own scale (rows differ by 15 orders of magnitude)
+        err = (y - ref).abs().amax((0, 2, 3)) / (ref.abs().amax((0, 2, 3)) + 1e-30)
+        err[7] = (y[:, 7] - ref[:, 7]).abs().max()          # the all-zero row: bias only, exact
+        assert err.max() < 2e-5, (ks, err.max(), int(err.argmax()))
+    xo = xd.clone()
+    xo[0, 2, 3, 9] = 9.0e3                                   # beyond fp16 / 8: must be visible
+    y = hip.conv2d(xo, wd, bd, KH=k, KW=k, pad=(1, 1), tile=tile)
+    assert not torch.isfinite(y).all()
+
+
 @pytest.mark.parametrize('ksplit', _tuned_ksplits())
 def test_conv_splitk(ksplit):
     g = torch.Generator().manual_seed(5)

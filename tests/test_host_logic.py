@@ -257,3 +257,35 @@ def test_raw_pixel_range_check_guards_the_fp16_stem():
     assert engine.looks_like_raw_pixels(torch.from_numpy(synth.crop(1, 1, 127)))
     assert not engine.looks_like_raw_pixels(torch.rand(1, 3, 127, 127))                 # [0, 1]-normalised
     assert not engine.looks_like_raw_pixels(torch.randn(1, 3, 127, 127) * 50)           # mean/std-normalised, signed
+
+
+def test_split16_pack_reconstructs_the_bank_to_22_bits():
+    """usot_amd/hip.py: split16_pack / pw_pair_s16_pack (host side of the split-fp16 conv tiles and of usot_pw_pair_f32s): every
+    filter as hi + lo fp16 of (row x a power of two).  (hi + lo) x the stored factor x 8 must give the row back to 2^-21 of the
+    row's largest value (22 significant bits relative to the scaled row), whatever the row's magnitude - including all-zero rows,
+    rows of 1e-20 and of 1e+4 - and the fragment order must be the one the kernels index."""
+    import torch
+    from usot_amd import hip
+    g = torch.Generator().manual_seed(3)
+    rows, k = 48, 192
+    w = torch.randn(rows, k, generator=g)
+    w[1] = 0.0
+    w[2] *= 1e-20
+    w[3] *= 1e4
+    w[4, ::2] *= 1e-6                      # a wide dynamic range inside one row
+    packed, inv = hip.split16_pack(w)
+    assert packed.shape == (rows, k) and packed.dtype == torch.float32 and inv.shape == (rows,)
+    halves = packed.view(torch.float16).view(rows, k // 64, 2, 64).float()         # [row][k-tile][hi | lo][64]
+    rec = (halves[:, :, 0] + halves[:, :, 1]).reshape(rows, k) * (inv * hip.SPLIT16_X_SCALE)[:, None]
+    amax = w.abs().amax(1, keepdim=True)
+    assert torch.isfinite(halves).all()
+    assert ((rec - w).abs() <= amax * 2.0 ** -21).all()
+    assert (halves[:, :, 0].abs().amax((1, 2))[amax[:, 0] > 0] >= 512).all() and halves.abs().max() <= 1024      # rows sit at the top of fp16's range
+    scale = 1.0 / (inv * hip.SPLIT16_X_SCALE)
+    assert torch.equal(torch.exp2(torch.round(torch.log2(scale))), scale)            # exact powers of two
+    # the pair kernel's fragment order: (column block of 16 rows, 32-k step, hi | lo, quad, row in block, 8 halves), factors appended
+    pp = hip.pw_pair_s16_pack(w)
+    assert pp.numel() == rows * k + rows
+    fr = pp[:rows * k].view(torch.float16).view(rows // 16, k // 32, 2, 4, 16, 8).float()
+    rec2 = (fr[:, :, 0] + fr[:, :, 1]).permute(0, 3, 1, 2, 4).reshape(rows, k) * (pp[rows * k:] * hip.SPLIT16_X_SCALE)[:, None]
+    assert ((rec2 - w).abs() <= amax * 2.0 ** -21).all()

@@ -1821,6 +1821,10 @@ class Session:
                                        'the frame graph did not run to the decode kernel' % (tag, float(out[8])))
         self._prev_slot, self._pending = 2 + self.n, True      # ('defer_append': this frame's row, written by the next graph)
         self.n += 1
+        if self.e.opt['split16_f32'] and not (out[1] == out[1] and out[7] == out[7]):
+            # the split-fp16 convolutions overflow visibly (inf -> nan) when an activation exceeds 8 188: say so instead of tracking on
+            raise hip.HipError('frame %r: the response maps are not finite; if this checkpoint drives an activation beyond 8 188, run it '
+                               "with engine_options['options'] = {'split16_f32': False} (exact-fp32 products)" % (tag,))
         return out[:8].copy()
 
     def append_feature(self, feat):

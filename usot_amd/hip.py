@@ -317,7 +317,7 @@ def split16_pack(w):
     w = w.float()
     amax = w.abs().amax(1)
     e = torch.where(amax > 0, torch.floor(torch.log2(1024.0 / amax.clamp_min(1e-30))), torch.zeros_like(amax))
-    e = torch.where(amax * torch.exp2(e) >= 1024.0, e - 1, e).clamp(-60, 60)       # (guards the log2 rounding at exact powers of two)
+    e = torch.where(amax * torch.exp2(e) >= 1024.0, e - 1, e).clamp(-100, 110)     # (guards the log2 rounding at exact powers of two)
     sw = torch.exp2(e)
     ws = w * sw[:, None]
     hi = ws.half()
@@ -617,7 +617,7 @@ def pw_pair_s16_pack(w):
     w = w.float()
     amax = w.abs().amax(1)
     e = torch.where(amax > 0, torch.floor(torch.log2(1024.0 / amax.clamp_min(1e-30))), torch.zeros_like(amax))
-    e = torch.where(amax * torch.exp2(e) >= 1024.0, e - 1, e).clamp(-60, 60)
+    e = torch.where(amax * torch.exp2(e) >= 1024.0, e - 1, e).clamp(-100, 110)
     sw = torch.exp2(e)
     ws = w * sw[:, None]
     hi = ws.half()
