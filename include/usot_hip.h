@@ -83,6 +83,11 @@ typedef struct usot_conv_desc {
                        * fp16 of (row x a power of two) - per k-tile of 64: 64 hi halves then 64 lo halves, the 256 bytes of the fp32 row
                        * segment - and w_scale[groups][Cout] = 1 / (that power of two x 8) multiplies the finished sums (8 = the
                        * activation scale the kernel applies before it splits them).  NULL otherwise. */
+    int32_t x_split;  /* 1: `x` is a SPLIT map - per pixel and 64-channel block the 64 hi halves then the 64 lo halves (fp16) of 8 x value,
+                       * the 256 bytes of the fp32 block - as written by a launch with y_split = 1.  Required by, and only valid with, the
+                       * all-DMA split-fp16 tiles (usot_conv_tile_xsplit(tile) == 1): both operands then reach LDS by LDS-DMA */
+    int32_t y_split;  /* 1: the result is written as a split map (split-fp16 tiles only; dense NHWC, Cout % 64 == 0, no residual, no
+                       * split-K).  Its only readers are launches with x_split = 1 */
 } usot_conv_desc;
 
 int usot_conv2d_f32(void *stream, const usot_conv_desc *d);
@@ -101,6 +106,7 @@ int usot_plan_add_thin_conv(void *plan, const usot_conv_desc *d, int n);
 int usot_conv_tile_count(void);
 int usot_conv_tile_info(int tile, int *bm, int *bn);           /* tile ids are 1..count */
 int usot_conv_tile_name(int tile, char *buf, int len);         /* kernel symbol of the tile */
+int usot_conv_tile_xsplit(int tile);                           /* 1: the tile reads a split input map (usot_conv_desc.x_split) */
 int usot_conv_tile_wfrag(int tile);                            /* 1: the tile streams its filters in fragment order; 2: split-fp16 bank + w_scale */
 /* weight-stationary tiles (filters held in registers, k split over the 8 waves of a workgroup) serve ONE K each: returns it
  * (0: the tile takes any K); *kpanel = the multiple Cin must have (128 / 256).  They also need Cout % 32 == 0, ksplit == 1. */

@@ -24,7 +24,7 @@ for spec in sys.argv[2:] or ['54', '53', '55']:          # tile or tile:ksplit
                       KH=k, KW=k, pad=(pad, pad), dil=(dil, dil), act=1, tile=tile, ksplit=ks, ws=ws.data_ptr(),
                       groups=G, x_gs=N * H * W * Cin, w_gs=Cout * k * k * Cin, b_gs=Cout, y_gs=N * H * H * Cout,
                       w_frag=hip.tile_wfrag(tile),       # timing only: random filters are as good in any order
-                      w_scale=b.data_ptr() if hip.tile_wfrag(tile) == 2 else None)
+                      w_scale=b.data_ptr() if hip.tile_wfrag(tile) == 2 else None, x_split=hip.tile_xsplit(tile))
     for _ in range(5):
         hip.check(L.usot_conv2d_f32(hip.stream(), C.byref(d)))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -25,12 +25,12 @@ for tile in [int(v) for v in sys.argv[1:]] or [41, 53]:
     ws = torch.zeros(8 * 64, dtype=torch.int32, device=dev)
     d = hip.conv_desc(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N=N, H=H, W=W, Cin=Cin, OH=H, OW=H, Cout=Cout,
                       KH=k, KW=k, pad=(pad, pad), dil=(dil, dil), act=1, tile=tile, ws=ws.data_ptr(), w_frag=hip.tile_wfrag(tile),
-                      w_scale=b.data_ptr() if hip.tile_wfrag(tile) == 2 else None)      # timing only: random bits are as good as split filters
+                      w_scale=b.data_ptr() if hip.tile_wfrag(tile) == 2 else None, x_split=hip.tile_xsplit(tile))      # timing only: random bits are as good as split filters
     for _ in range(2):
         hip.check(L.usot_conv2d_f32(hip.stream(), C.byref(d)))
     torch.cuda.synchronize()
     t = (ws.cpu().numpy().astype(np.int64) & 0xffffffff).reshape(64, 8)[2:34]
     med = lambda a: int(np.median(a))
-    print('%-44s k-step %5d | consumer: MFMA phase %4d, barrier wait %4d | producer: LDS stores %4d, loads %4d, barrier wait %4d' % (
+    print('%-44s k-step %5d | consumer: MFMA phase %4d, barrier wait %4d | producer: wait for loads %4d, convert + LDS stores %4d, loads %4d, barrier wait %4d' % (
         hip.tile_name(tile), med(np.diff(t[:, 0])), med(t[:, 1] - t[:, 0]), med(t[:, 2] - t[:, 1]),
-        med(t[:, 5] - t[:, 4]), med(t[:, 6] - t[:, 5]), med(t[:, 7] - t[:, 6])))
+        med(t[:, 3] - t[:, 4]), med(t[:, 5] - t[:, 3]), med(t[:, 6] - t[:, 5]), med(t[:, 7] - t[:, 6])))

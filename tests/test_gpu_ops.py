@@ -117,6 +117,34 @@ def test_split_fp16_tiles_range_contract(tile):
     assert not torch.isfinite(y).all()
 
 
+@pytest.mark.parametrize('tile2', [116, 117])
+def test_split_maps_chain_two_convolutions_without_an_fp32_map(tile2):
+    """usot_conv_desc.y_split / x_split: a split-fp16 tile writes its result as a split map (per pixel and 64-channel block the hi
+    halves then the lo halves of 8 x value) and an all-DMA tile (PF = 6: both operands by LDS-DMA, no producer waves) reads it.
+    Both levels against float64; the launcher refuses a split input on a tile that stages fp32 and an fp32 input on an all-DMA tile."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(21)
+    N, Cc, H, W = 2, 128, 14, 17
+    x = torch.randn(N, Cc, H, W, generator=g).abs()
+    w1 = torch.randn(Cc, Cc, 3, 3, generator=g) / np.sqrt(9 * Cc); b1 = torch.randn(Cc, generator=g)
+    w2 = torch.randn(2 * Cc, Cc, 3, 3, generator=g) / np.sqrt(9 * Cc); b2 = torch.randn(2 * Cc, generator=g)
+    r1 = F.relu(F.conv2d(x.double(), w1.double(), b1.double(), 1, 2, 2))
+    r2 = F.conv2d(r1, w2.double(), b2.double(), 1, 1).float()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y1 = hip.conv2d(xd, pack_w(w1).to(DEV), b1.to(DEV), KH=3, KW=3, pad=(2, 2), dil=(2, 2), act=hip.ACT_RELU, tile=106, y_split=True)
+    assert rel_err(hip.unsplit_map(y1).permute(0, 3, 1, 2).cpu().numpy(), r1.float().numpy()) < 2e-5
+    w2p, sc = hip.split16_pack(pack_w(w2).to(DEV))
+    b2d = b2.to(DEV)
+    y2 = torch.empty(N, H, W, 2 * Cc, device=DEV)
+    mk = lambda tile, xs: hip.conv_desc(y1.data_ptr(), w2p.data_ptr(), b2d.data_ptr(), y2.data_ptr(), N=N, H=H, W=W, Cin=Cc, OH=H, OW=W,
+                                        Cout=2 * Cc, KH=3, KW=3, pad=(1, 1), tile=tile, w_frag=2, w_scale=sc.data_ptr(), x_split=xs)
+    hip.check(hip.lib().usot_conv2d_f32(hip.stream(), C.byref(mk(tile2, 1))), 'usot_conv2d_f32')
+    torch.cuda.synchronize()
+    assert rel_err(y2.permute(0, 3, 1, 2).cpu().numpy(), r2.numpy()) < 2e-5
+    assert hip.lib().usot_conv2d_f32(hip.stream(), C.byref(mk(tile2, 0))) != 0          # an all-DMA tile reads split maps only
+    assert hip.lib().usot_conv2d_f32(hip.stream(), C.byref(mk(106, 1))) != 0            # ... and nobody else reads them
+
+
 @pytest.mark.parametrize('ksplit', _tuned_ksplits())
 def test_conv_splitk(ksplit):
     g = torch.Generator().manual_seed(5)

@@ -51,6 +51,8 @@ struct ConvK {
     int vec_store;
     int pr;                             // weight-stationary tiles: pixel ranges per (group, 32-channel block)
     const float *wscale;                // split-fp16 tiles (PF = 4): 1 / (filter row scale x activation scale) per output channel
+    const float *zero;                  // PF = 6: 16 zero bytes, the source of padding taps for the activation DMA
+    int x_split, y_split;               // the input map arrives / the result leaves in the split-fp16 layout (usot_conv_desc)
 };
 
 // Up to four convolutions of DIFFERENT geometry in one launch (same tile shape): the shortcut
@@ -171,6 +173,7 @@ __device__ __forceinline__ int xcd_remap(int b, int total)
 }
 
 constexpr int LDK = 36;   // padded k-extent of an LDS row (floats)
+__device__ __attribute__((aligned(16))) uint32_t g_zero16_f32[4] = {0u, 0u, 0u, 0u};     // source of padding taps (activation DMA, PF = 6)
 
 // Blocked accumulation.  v_mfma_f32_16x16x4_f32 adds its four products to C one after the other, so a plain k-loop is ONE
 // sequential float32 chain of K additions per output: on a K = 4608 reduction its rounding error is 4x (rms) that of a
@@ -736,7 +739,7 @@ template <int BM, int BN, int WM, int WN, int BK, int D = 1, int NPW = 4, int PF
 #ifdef USOT_V3_SWZ
 __global__ __launch_bounds__(64 * WM * WN + 64 * NPW, (BM * BN <= 32 * 64) ? (4 + NPW) / 2 : 1) void conv_igemm_f32_v3(const ConvBatch bt)
 #else
-__global__ __launch_bounds__(64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void conv_igemm_f32_v3(const ConvBatch bt)
+__global__ __launch_bounds__(PF == 6 ? 64 * WM * WN + 768 : 64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void conv_igemm_f32_v3(const ConvBatch bt)
 #endif
 {
     int pi = 0;
@@ -756,7 +759,7 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 consumer wavefronts");
     constexpr int CT = 64 * WM * WN;              // consumer threads; the producers follow
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr bool H16 = PF == 4 || PF == 5;      // split-fp16 arithmetic (above)
+    constexpr bool H16 = PF == 4 || PF == 5 || PF == 6;      // split-fp16 arithmetic (above)
     static_assert(!H16 || BK == 64, "split-fp16 rows are 64 hi + 64 lo halves");
     // PF = 5: split-fp16 with the FILTER tile moved by LDS-DMA.  The pre-split filter rows are copied to LDS unchanged, and the
     // producers' ds_write_b128 of them were two thirds of the 24 KB a k-step pushes through the VGPR -> LDS store path (~79 B/clk
@@ -766,9 +769,14 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void
     // wait with a counted s_waitcnt vmcnt until the pieces of tile t + 2 have landed, and join the k-step's barrier.  A stage is
     // the same padded row image as before (17 chunks of 16 bytes per row: linear chunk c = 17 row + chunk, the 17th a pad that
     // receives a dummy load), so the consumers' fragment addresses do not change; 1 KiB pieces are c = 64 piece + lane.
-    constexpr bool WDMA = PF == 5;
-    constexpr int NDW = WDMA ? 4 : 0;             // filter-DMA wavefronts
-    constexpr int NSW = WDMA ? (D >= 4 ? 6 : 5) : 3;   // filter stages (six on the tiles whose activation producers run four k-tiles deep)
+    // PF = 6: BOTH operands by LDS-DMA.  The input map arrives ALREADY split (usot_conv_desc.x_split: per pixel and 64-channel block the
+    // 64 hi halves then the 64 lo halves of 8 x value - the 256 bytes of the fp32 block, written by the producing kernel's epilogue,
+    // y_split), so an activation row of a k-tile is as ready-made as a filter row: the four DMA wavefronts fetch both tiles (a padding
+    // tap fetches 16 zero bytes), five stages each, and the producer wavefronts with their loads, conversions and ds_writes are gone.
+    constexpr bool XDMA = PF == 6;
+    constexpr bool WDMA = PF == 5 || PF == 6;
+    constexpr int NDW = XDMA ? 12 : (WDMA ? 4 : 0);  // DMA wavefronts (a piece costs its wave ~200 cycles of issue - traced: 26 pieces per k-tile over twelve waves)
+    constexpr int NSW = WDMA ? ((D >= 4 || PF == 6) ? 6 : 5) : 3;   // filter stages (six on the all-DMA tiles and those whose activation producers run four k-tiles deep)
     constexpr int LA = NSW - 1;                   // the DMA runs LA k-tiles ahead
     // LDS rows.  BK = 64: a row is 256 B = one bank row, UNPADDED, 16-byte chunk c of tile row `row` stored at chunk
     // c ^ (row & 15).  ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md
@@ -789,13 +797,15 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void
     constexpr int NR = BK / 16;
     constexpr int STAGE = (BM + BN) * LD;
     // LDS: without the filter DMA three stages of [activation rows | filter rows]; with it three activation stages, then NSW filter stages
+    constexpr int NSX = XDMA ? NSW : 3;                        // activation stages
     constexpr int XSTRIDE = WDMA ? BM * LD : STAGE;            // floats between activation stages
-    constexpr int WBASE = WDMA ? 3 * BM * LD : BM * LD;        // first filter stage
+    constexpr int WBASE = WDMA ? NSX * BM * LD : BM * LD;      // first filter stage
     constexpr int WSTRIDE = WDMA ? BN * LD : STAGE;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const bool producer = threadIdx.x >= CT;
     const int tid = producer ? (int)threadIdx.x - CT : (int)threadIdx.x;
+    constexpr int NPTL = XDMA ? 0 : NPT;          // producer threads actually launched (none when the activations come by DMA)
     const int tiles = p.MT * p.NT;
     const int total = tiles * p.groups * p.ksplit;
     const int b = xcd_remap(bid0, total);
@@ -809,13 +819,16 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void
     const int nt = kt1 - kt0;
 
     if constexpr (WDMA) {
-        if ((int)threadIdx.x >= CT + NPT) {
-            // ---------------- filter-DMA wavefronts (PF = 5)
-            const int dt = (int)threadIdx.x - CT - NPT;
+        if ((int)threadIdx.x >= CT + NPTL) {
+            // ---------------- DMA wavefronts: the filter tile (PF = 5, 6) and, with PF = 6, the activation tile too
+            const int dt = (int)threadIdx.x - CT - NPTL;
             const int dwv = __builtin_amdgcn_readfirstlane(dt >> 6), lane = dt & 63;
             constexpr int NCH = BN * 17;                       // 16-byte chunks of a filter stage: 16 data + 1 pad per row
             constexpr int NPIECE = (NCH + 63) / 64;            // 1 KiB pieces (64 lanes x 16 bytes)
             constexpr int MAXP = (NPIECE + NDW - 1) / NDW;
+            constexpr int NCHX = BM * 17;                      // the activation stage likewise (PF = 6)
+            constexpr int NPX = XDMA ? (NCHX + 63) / 64 : 0;
+            constexpr int MAXPX = XDMA ? (NPX + NDW - 1) / NDW : 1;
             const float *__restrict__ wg = p.w + (long)g * p.w_gs + (long)kt0 * BK;
             const float *src[MAXP];
             bool live[MAXP];
@@ -829,39 +842,97 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void
                 src[q] = wg + (ok ? (long)co * p.K + ch * 4 : 0L);      // pad chunks and rows past Cout fetch the bank's first bytes
                 mine += piece < NPIECE ? 1 : 0;
             }
+            // activation pieces: lane -> (pixel row of the tile, 16-byte chunk of its 64-channel block); the tap moves per k-tile
+            const float *__restrict__ xg = p.x + (long)g * p.x_gs;
+            int xih0[MAXPX], xiw0[MAXPX], xch[MAXPX];
+            long xnb[MAXPX];
+            bool xlive[MAXPX], xrow[MAXPX];
+            if constexpr (XDMA) {
+#pragma unroll
+                for (int q = 0; q < MAXPX; ++q) {
+                    const int piece = dwv + q * NDW, c = 64 * piece + lane;
+                    xlive[q] = piece < NPX && c < NCHX;
+                    const int row = c / 17, ch = c - row * 17, m = bm0 + row;
+                    xrow[q] = xlive[q] && ch < 16 && m < p.M;          // a real pixel and a data chunk (else: zeros)
+                    const int mm = xrow[q] ? m : 0;
+                    const int n = mm / p.P, pix = mm - n * p.P;
+                    const int oh = pix / p.OW, ow = pix - oh * p.OW;
+                    xih0[q] = oh * p.stride - p.pad_h;
+                    xiw0[q] = ow * p.stride - p.pad_w;
+                    xnb[q] = (long)n * p.H * p.W * p.Cin;
+                    xch[q] = ch * 4;
+                    mine += piece < NPX ? 1 : 0;
+                }
+            }
             const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(smem + WBASE);
+            const uint32_t ldsx = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
+            auto dma = [&](const float *sp, uint32_t dst) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(sp), "s"(dst) : "memory");
+            };
             auto issue = [&](int tile) {                       // k-tile `tile` of this workgroup's range -> stage tile % NSW
                 const uint32_t stg = lds0 + (uint32_t)((tile % NSW) * BN * LD * 4);
 #pragma unroll
                 for (int q = 0; q < MAXP; ++q) {
                     const int piece = dwv + q * NDW;
-                    if (piece < NPIECE && live[q]) {
-                        const uint32_t dst = __builtin_amdgcn_readfirstlane(stg + (uint32_t)(piece * 1024));
-                        const float *sp = src[q] + (long)tile * BK;
-                        unsigned keep;
-                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep) : "v"(sp), "s"(dst) : "memory");
+                    if (piece < NPIECE && live[q])
+                        dma(src[q] + (long)tile * BK, __builtin_amdgcn_readfirstlane(stg + (uint32_t)(piece * 1024)));
+                }
+                if constexpr (XDMA) {
+                    const int kt = kt0 + tile, tap = kt / cch, cc = kt - tap * cch;
+                    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+                    const uint32_t stx = ldsx + (uint32_t)((tile % NSX) * BM * LD * 4);
+#pragma unroll
+                    for (int q = 0; q < MAXPX; ++q) {
+                        const int piece = dwv + q * NDW;
+                        if (piece < NPX && xlive[q]) {
+                            const int ih = xih0[q] + kh * p.dil_h, iw = xiw0[q] + kw * p.dil_w;
+                            const bool in = xrow[q] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                            const float *sp = in ? xg + xnb[q] + ((long)ih * p.W + iw) * p.Cin + cc * BK + xch[q] : p.zero;
+                            dma(sp, __builtin_amdgcn_readfirstlane(stx + (uint32_t)(piece * 1024)));
+                        }
                     }
                 }
             };
             // at most the pieces of the LA - 2 newest k-tiles may stay in flight (drain = true: none - the tail, where fewer exist)
             auto land = [&](bool drain) {
-                if (drain || mine < 1 || mine > 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (mine == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * (LA - 2)) : "memory");
-                else if (mine == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (LA - 2)) : "memory");
-                else if (mine == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (LA - 2)) : "memory");
-                else if (mine == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (LA - 2)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * (LA - 2)) : "memory");
+                if (drain) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+                switch (mine) {
+                case 1: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * (LA - 2)) : "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (LA - 2)) : "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (LA - 2)) : "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (LA - 2)) : "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * (LA - 2)) : "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * (LA - 2)) : "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(7 * (LA - 2)) : "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (LA - 2)) : "memory"); break;
+                case 9: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(9 * (LA - 2)) : "memory"); break;
+                case 10: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(10 * (LA - 2)) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                }
             };
             for (int j = 0; j < LA && j < nt; ++j) issue(j);
             land(nt < LA);                                     // k-tiles 0 and 1 are in LDS before the first barrier
             asm volatile("s_barrier" ::: "memory");
+#ifdef USOT_TRACE
+            unsigned *trd = (XDMA && p.ksplit == 1 && p.ws && bid0 == 0 && dt == 0) ? (unsigned *)p.ws : nullptr;
+#define USOT_DSTAMP(slot, t) if (trd && (t) < 64) trd[(t) * 8 + (slot)] = (unsigned)__builtin_readcyclecounter()
+#else
+#define USOT_DSTAMP(slot, t)
+#endif
             for (int t = 0; t < nt; ++t) {
                 const bool more = t + LA < nt;
+                USOT_DSTAMP(4, t);
                 if (more) issue(t + LA);
+                USOT_DSTAMP(3, t);
+                USOT_DSTAMP(5, t);
                 land(!more);                                   // k-tile t + 2 has landed when the consumers pass this step's barrier
+                USOT_DSTAMP(6, t);
                 asm volatile("s_barrier" ::: "memory");
+                USOT_DSTAMP(7, t);
             }
+#undef USOT_DSTAMP
             return;
         }
     }
@@ -1022,6 +1093,13 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void
             USOT_STAMP(4, t);
 #ifdef USOT_V3_STAGGER
             for (int q = 0; q < pw * USOT_V3_STAGGER / 4; ++q) __builtin_amdgcn_s_sleep(1);
+#endif
+#ifdef USOT_TRACE
+            {   // the wait for the oldest register buffer's loads, apart from the conversion / store instructions behind it
+                constexpr int d_ = decltype(dc)::value;
+                asm volatile("" :: "v"(xr[d_][XI - 1]));
+                USOT_STAMP(3, t);
+            }
 #endif
             if (t + 2 < nt) store_tile(dc, st2);
             USOT_STAMP(5, t);
@@ -1200,10 +1278,11 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void
             // fragments are fetched as soon as a slot pair is free
             const bool more = t + 1 < nt;
             const int stw1 = stw == NSW - 1 ? 0 : stw + 1;
+            const int sx1 = XDMA ? stw1 : st1;            // (PF = 6: the activation ring is as deep as the filter ring)
             mma_h(acc, acc2, fw[0], fw[2], fx[0], fx[2], true);
-            if (more) { read_frags(st1, 0, 0, stw1); read_frags(st1, 2, 2, stw1); }
+            if (more) { read_frags(sx1, 0, 0, stw1); read_frags(sx1, 2, 2, stw1); }
             mma_h(acc, acc2, fw[1], fw[3], fx[1], fx[3], false);
-            if (more) { read_frags(st1, 1, 1, stw1); read_frags(st1, 3, 3, stw1); }
+            if (more) { read_frags(sx1, 1, 1, stw1); read_frags(sx1, 3, 3, stw1); }
             st = st1;
             stw = stw1;
             USOT_STAMP(1, t);
@@ -1314,6 +1393,21 @@ __global__ __launch_bounds__(64 * WM * WN + 64 * NPW + (PF == 5 ? 256 : 0)) void
                 if (a != USOT_ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a);
+                }
+                if constexpr (H16) {
+                    if (p.y_split) {
+                        // the result leaves split (usot_conv_desc.y_split): per pixel and 64-channel block 64 hi halves then 64 lo halves of
+                        // 8 x value - what a PF = 6 consumer's DMA copies into its LDS rows unchanged
+                        const f32x4 w8 = v * 8.0f;
+                        const uint32_t hi0 = usot_pack2_lp<true>(w8[0], w8[1]), hi1 = usot_pack2_lp<true>(w8[2], w8[3]);
+                        const usot_f16x2 h0 = __builtin_bit_cast(usot_f16x2, hi0), h1 = __builtin_bit_cast(usot_f16x2, hi1);
+                        const uint32_t lo0 = usot_pack2_lp<true>(w8[0] - (float)h0[0], w8[1] - (float)h0[1]);
+                        const uint32_t lo1 = usot_pack2_lp<true>(w8[2] - (float)h1[0], w8[3] - (float)h1[1]);
+                        char *blk = (char *)(yg + (long)m * p.y_cstride + p.y_coff + (co & ~63));
+                        *(u32x2_t *)(blk + (co & 63) * 2) = u32x2_t{hi0, hi1};
+                        *(u32x2_t *)(blk + 128 + (co & 63) * 2) = u32x2_t{lo0, lo1};
+                        continue;
+                    }
                 }
                 *(f32x4 *)(yg + (long)m * p.y_cstride + p.y_coff + co) = v;
             } else {
@@ -2307,6 +2401,7 @@ struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int t
 #define TILE13(bm, bn, wm, wn, bk, d, npw) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d, npw, 3>, 64 * wm * wn + 64 * npw, d, 0, 3 }
 #define TILEH(bm, bn, wm, wn, d, npw) { bm, bn, 64, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, 64, d, npw, 4>, 64 * wm * wn + 64 * npw, d, 2, 4 }
 #define TILEHD(bm, bn, wm, wn, d, npw) { bm, bn, 64, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, 64, d, npw, 5>, 64 * wm * wn + 64 * npw + 256, d, 2, 5 }
+#define TILEHX(bm, bn, wm, wn) { bm, bn, 64, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, 64, 2, 4, 6>, 64 * wm * wn + 768, 2, 2, 6 }
 #define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d, 0, 0 }
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
@@ -2429,6 +2524,8 @@ const TileCfg kTiles[] = {
     TILEHD(32, 64, 2, 2, 4, 4),       // 113: D = 4 and SIX filter stages (the DMA five k-tiles ahead)
     TILEHD(32, 32, 2, 2, 4, 4),       // 114
     TILEHD(32, 64, 2, 2, 4, 8),       // 115
+    TILEHX(32, 64, 2, 2),             // 116: split-fp16, BOTH operands by LDS-DMA (PF = 6): the input map arrives split (usot_conv_desc.x_split), no producer waves
+    TILEHX(32, 32, 2, 2),             // 117
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -2468,6 +2565,7 @@ extern "C" int usot_conv_tile_name(int tile, char *buf, int len)
     const TileCfg &t = kTiles[tile - 1];
     if (t.nst) { snprintf(buf, len, "conv_wstat_f32<NST=%d,RPS=%d>", t.nst, t.rps); return USOT_OK; }
     if (t.skfn) { snprintf(buf, len, "conv_igemm_f32_v3p<%d,%d,BK=%d,D=%d,NPW=%d>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
+    if (t.wfrag == 2 && t.dw == 6) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,PF=6>", t.bm, t.bn, t.bk); return USOT_OK; }
     if (t.wfrag == 2 && t.dw == 5) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=5>", t.bm, t.bn, t.bk, t.depth, (t.threads - 512) / 64); return USOT_OK; }
     if (t.wfrag == 2) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,D=%d,NPW=%d,PF=4>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.wfrag) { snprintf(buf, len, "conv_igemm_f32_ws<%d,%d,D=%d,NPW=%d,DW=%d>", t.bm, t.bn, t.depth, (t.threads - 256) / 64, t.dw); return USOT_OK; }
@@ -2489,6 +2587,8 @@ extern "C" int usot_conv_tile_wfrag(int tile)
     if (tile < 1 || tile > kNumTiles) return 0;
     return kTiles[tile - 1].wfrag;
 }
+
+extern "C" int usot_conv_tile_xsplit(int tile) { return (tile >= 1 && tile <= kNumTiles && kTiles[tile - 1].wfrag == 2 && kTiles[tile - 1].dw == 6) ? 1 : 0; }
 
 /* weight-stationary tiles serve ONE reduction length: K the tile requires (0: any K the other rules allow); their other
  * requirements: Cin % kpanel == 0 (128 or 256, returned through *kpanel), Cout % 32 == 0, ksplit == 1, w_frag == 1 */
@@ -2582,7 +2682,7 @@ int fill_params(const usot_conv_desc *d, ConvK &p)
     p.K = d->KH * d->KW * d->Cin;
     p.cchunks = d->Cin / 32;
     p.KT = d->KH * d->KW * p.cchunks;
-    p.wscale = nullptr;
+    p.wscale = nullptr; p.zero = nullptr; p.x_split = p.y_split = 0;
     p.vec_store = !d->y_nchw && (p.y_cstride % 4 == 0) && (p.y_coff % 4 == 0) &&
                   (!d->res || (p.res_cstride % 4 == 0 && p.res_coff % 4 == 0)) &&
                   ((uintptr_t)d->y % 16 == 0) && (!d->res || (uintptr_t)d->res % 16 == 0) &&
@@ -2738,6 +2838,21 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
         if (d[i].w_frag != tc.wfrag) return USOT_EINVAL;
         if (tc.wfrag == 2 && (!d[i].w_scale || ((uintptr_t)d[i].w_scale & 3))) return USOT_EINVAL;
         p.wscale = d[i].w_scale;
+        // split maps: only the split-fp16 tiles write them (vectorised NHWC epilogue, whole 64-channel blocks, no split-K), only the
+        // all-DMA tiles read them - and those read nothing else
+        p.x_split = d[i].x_split ? 1 : 0;
+        p.y_split = d[i].y_split ? 1 : 0;
+        if (p.x_split != (tc.wfrag == 2 && tc.dw == 6 ? 1 : 0)) return USOT_EINVAL;
+        if (p.y_split && (tc.wfrag != 2 || !p.vec_store || (d[i].Cout & 63) || (p.y_coff & 63) || (p.y_cstride & 63) || p.ksplit > 1 || d[i].res)) return USOT_EINVAL;
+        if (p.x_split) {
+            static const float *zero_page = nullptr;
+            if (!zero_page) {
+                void *zp = nullptr;
+                if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16_f32)) != hipSuccess || !zp) return USOT_ELAUNCH;
+                zero_page = (const float *)zp;
+            }
+            p.zero = zero_page;
+        }
         if (tc.wfrag == 1 && p.groups > 1 && (p.w_gs % ((long)16 * p.K))) return USOT_EINVAL;
         p.MT = (p.M + tc.bm - 1) / tc.bm;
         p.NT = (d[i].Cout + tc.bn - 1) / tc.bn;
@@ -2757,6 +2872,7 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
 #endif
     size_t lds = (size_t)tc.ksw * tc.stages * (tc.bm + (tc.wfrag == 1 ? 0 : tc.bn)) * ld * sizeof(float);
     if (tc.wfrag == 2 && tc.dw == 5) lds = (size_t)(3 * tc.bm + (tc.depth >= 4 ? 6 : 5) * tc.bn) * ld * sizeof(float);      // three activation + five (six) filter stages
+    if (tc.wfrag == 2 && tc.dw == 6) lds = (size_t)(6 * tc.bm + 6 * tc.bn) * ld * sizeof(float);                           // six of each
     if (lds > 64 * 1024) {
         static bool raised[128] = {false};
         if (!raised[tile]) {

@@ -979,7 +979,7 @@ extern "C" int usot_device_guard(void)
     return expect == dev ? USOT_OK : USOT_ESTATE;
 }
 
-extern "C" int usot_abi_version(void) { return 3; }   // 2: usot_conv_desc.w_frag; 3: usot_conv_desc.w_scale
+extern "C" int usot_abi_version(void) { return 4; }   // 2: usot_conv_desc.w_frag; 3: w_scale; 4: x_split / y_split
 
 extern "C" const char *usot_strerror(int code)
 {

@@ -15,7 +15,7 @@ ACT_NONE, ACT_RELU, ACT_EXP, ACT_CONF = 0, 1, 2, 3
 
 EXPORTS = (
     'usot_abi_version', 'usot_device_guard', 'usot_strerror', 'usot_conv2d_f32', 'usot_conv_tile_count',
-    'usot_conv_tile_info', 'usot_conv_tile_name', 'usot_conv_tile_wfrag', 'usot_conv_tile_kreq', 'usot_conv_tile_streamk', 'usot_conv_streamk_ws_floats', 'usot_conv_pack_wfrag_f32', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
+    'usot_conv_tile_info', 'usot_conv_tile_name', 'usot_conv_tile_wfrag', 'usot_conv_tile_xsplit', 'usot_conv_tile_kreq', 'usot_conv_tile_streamk', 'usot_conv_streamk_ws_floats', 'usot_conv_pack_wfrag_f32', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
     'usot_xcorr_depthwise_f32', 'usot_groupdw_f32', 'usot_conf_fusion_reduce_f32',
     'usot_prroi_pool_forward_f32', 'usot_prroi_pool_backward_f32', 'usot_prroi_pool_coor_backward_f32', 'usot_permute4_f32', 'usot_decode_f32',
     'usot_plan_create', 'usot_plan_destroy', 'usot_plan_add_conv', 'usot_plan_add_stem',
@@ -51,7 +51,7 @@ class ConvDesc(C.Structure):
                 ('x_gs', C.c_int64), ('w_gs', C.c_int64), ('b_gs', C.c_int64), ('y_gs', C.c_int64),
                 ('r_gs', C.c_int64),
                 ('ksplit', C.c_int32), ('tile', C.c_int32), ('w_frag', C.c_int32), ('defer', C.c_int32),
-                ('w_scale', C.c_void_p)]
+                ('w_scale', C.c_void_p), ('x_split', C.c_int32), ('y_split', C.c_int32)]
 
 
 class GroupDWDesc(C.Structure):
@@ -250,6 +250,30 @@ def tile_wfrag(tile):
     return int(lib().usot_conv_tile_wfrag(int(tile))) if tile else 0
 
 
+def tile_xsplit(tile):
+    """1 when conv tile id `tile` reads its input map in the split-fp16 layout (descriptor field x_split, split_map)."""
+    return int(lib().usot_conv_tile_xsplit(int(tile))) if tile else 0
+
+
+def split_map(x):
+    """NHWC fp32 map [..., C] (C % 64 == 0) -> the split-fp16 layout of usot_conv_desc.x_split / y_split as a float32-typed tensor of the
+    same shape: per pixel and 64-channel block the 64 hi halves then the 64 lo halves of 8 x value."""
+    c = x.shape[-1]
+    assert c % 64 == 0
+    v = x.float() * SPLIT16_X_SCALE
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    blocks = lambda t: t.reshape(tuple(x.shape[:-1]) + (c // 64, 64))
+    return torch.cat([blocks(hi), blocks(lo)], -1).contiguous().view(torch.float32).reshape(x.shape)
+
+
+def unsplit_map(y):
+    """Inverse of split_map (hi + lo, / 8) - for tests and probes."""
+    c = y.shape[-1]
+    h = y.contiguous().view(torch.float16).reshape(tuple(y.shape[:-1]) + (c // 64, 2, 64)).float()
+    return ((h[..., 0, :] + h[..., 1, :]) / SPLIT16_X_SCALE).reshape(y.shape)
+
+
 def tile_kreq(tile):
     """(K, Cin multiple) a weight-stationary conv tile requires, or (0, 0) for the tiles that take any geometry."""
     if not tile:
@@ -329,7 +353,7 @@ def split16_pack(w):
 def conv_desc(x, w, bias, y, *, N, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, pad=(0, 0), dil=(1, 1),
               res=None, act=ACT_NONE, act2=ACT_NONE, act_split=0, y_cstride=0, y_coff=0,
               res_cstride=0, res_coff=0, y_nchw=0, groups=1, x_gs=0, w_gs=0, b_gs=0, y_gs=0, r_gs=0,
-              ksplit=1, tile=0, ws=None, w_frag=0, defer=0, w_scale=None):
+              ksplit=1, tile=0, ws=None, w_frag=0, defer=0, w_scale=None, x_split=0, y_split=0):
     d = ConvDesc()
     d.x, d.w, d.bias, d.res, d.y, d.ws = (x, w, bias or None, res or None, y, ws or None)
     d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout = N, H, W, Cin, OH, OW, Cout
@@ -341,11 +365,12 @@ def conv_desc(x, w, bias, y, *, N, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, pa
     d.x_gs, d.w_gs, d.b_gs, d.y_gs, d.r_gs = x_gs, w_gs, b_gs, y_gs, r_gs
     d.ksplit, d.tile, d.w_frag, d.defer = ksplit, tile, w_frag, defer
     d.w_scale = w_scale or None
+    d.x_split, d.y_split = int(x_split), int(y_split)
     return d
 
 
 def conv2d(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, act=ACT_NONE,
-           tile=0, ksplit=1, y_nchw=False):
+           tile=0, ksplit=1, y_nchw=False, y_split=False):
     """x NHWC [N,H,W,Cin] dense, w packed [Cout, KH*KW*Cin] -> y NHWC [N,OH,OW,Cout]."""
     _dev(x), _dev(w)
     N, H, W_, Cin = x.shape
@@ -360,6 +385,9 @@ def conv2d(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, ac
                          dtype=torch.float32)
     frag = tile_wfrag(tile)
     wsc = None
+    xs = tile_xsplit(tile)
+    if xs:                  # all-DMA split-fp16 tile: the input map in the split layout (here: converted for the caller)
+        x = split_map(x)
     if frag == 2:           # split-fp16 tile: hi + lo fp16 of every scaled filter row, and the scales
         w, wsc = split16_pack(w)
     elif frag:              # weight-streaming tile: the filter bank in MFMA fragment order
@@ -368,7 +396,7 @@ def conv2d(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, ac
                   N=N, H=H, W=W_, Cin=Cin, OH=OH, OW=OW, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad,
                   dil=dil, res=res.data_ptr() if res is not None else None, act=act, tile=tile,
                   ksplit=ksplit, ws=ws.data_ptr() if ws is not None else None, y_nchw=int(y_nchw), w_frag=frag,
-                  w_scale=wsc.data_ptr() if wsc is not None else None)
+                  w_scale=wsc.data_ptr() if wsc is not None else None, x_split=xs, y_split=int(y_split))
     if tile_streamk(tile):
         keep = streamk_ws([d], tile, x.device)
     check(lib().usot_conv2d_f32(stream(), C.byref(d)), 'usot_conv2d_f32')
