@@ -193,6 +193,16 @@ int usot_pw_panel_pair_lp(void *stream, const usot_pw_pair_desc *d, int dtype);
 int usot_pw_panel_pair_supported(int CM, int CO, int CN);
 int usot_plan_add_pw_panel_pair(void *plan, const usot_pw_pair_desc *d, int dtype);
 
+/* A layer3 bottleneck's conv2 -> conv3 of the batched low-precision backbone in ONE launch (csrc/conv_pw_lp.hip;
+ * modules.py:43-56): y[M][1024] = relu(relu(conv(x; c2->w) + c2->bias) . w3^T + b3 + res[M][1024]).  c2 describes conv2 (x, w
+ * [256][KH*KW*256] in the conv kernels' layout, bias, N, H, W, OH, OW, KH, KW, stride, pad, dil; Cin = Cout = 256, act =
+ * USOT_ACT_RELU; its y is IGNORED: a 256-pixel panel of conv2's output stays in LDS and is consumed there), w3 [1024][256], b3 fp32,
+ * res / y dense; storage type dtype 0 = bf16, 1 = fp16.  Bit-identical to usot_conv2d_lp (tile 32) followed by usot_pw_panel_lp.
+ * Shapes: usot_conv_pw_supported(Cin, CM, CO) (256, 256, 1024). */
+int usot_conv_pw_lp(void *stream, const usot_conv_desc *c2, const void *w3, const float *b3, const void *res, void *y, int dtype);
+int usot_conv_pw_supported(int Cin, int CM, int CO);
+int usot_plan_add_conv_pw(void *plan, const usot_conv_desc *c2, const void *w3, const float *b3, const void *res, void *y, int dtype);
+
 /* 3x3 / stride 1 / pad 1 convolution of the batched low-precision backbone as a direct convolution from an LDS halo tile
  * (csrc/conv3x3_halo.hip; layer1's conv2 + BN + ReLU, modules.py:43-46): x, y NHWC dense [N][H][W][C] and w [Cout][9 Cin]
  * (k = (kh*3 + kw)*Cin + ci, the conv kernels' layout) in the storage type (dtype 0 = bf16, 1 = fp16), bias fp32 or NULL,

@@ -1208,6 +1208,79 @@ def test_pw_panel_pair_equals_the_two_convolutions(cm, co, cn, M, act2, dtype):
     assert hip.lib().usot_pw_panel_pair_supported(cm, co, cn + 32) == 0
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('n,h,pad,dil', [(2, 31, 2, 2), (1, 13, 1, 1), (1, 16, 1, 1), (3, 9, 2, 2)])
+def test_conv_pw_fused_equals_the_two_launches(n, h, pad, dil, dtype):
+    """Layer3's conv2 -> conv3 in one launch (csrc/conv_pw_lp.hip: the 256-pixel T2 panel stays in LDS) vs the two launches it
+    replaces on the same operands - the 256 x 256 implicit-GEMM tile (32), then the pixel-stationary panel kernel: BIT-identical
+    (same products, same k order, T2 rounded once); and against float64 on the rounded operands.  Geometries: layer3's dilated
+    conv2 (b8..b12: pad 2 / dil 2) and b7's (pad 1 / dil 1); pixel counts with full panels + a ragged one, a single ragged panel
+    (169 < 256: waves without any pixel), exactly one panel (256)."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + pad)
+    cin = cm = 256
+    co = 1024
+    M = n * h * h
+    t1 = torch.randn(n, h, h, cin, generator=g).relu().to(dtype)
+    w2 = (torch.randn(cm, 9 * cin, generator=g) / (9 * cin) ** 0.5).to(dtype)       # [Cout][kh][kw][Cin]
+    w3 = (torch.randn(co, cm, generator=g) / cm ** 0.5).to(dtype)
+    b2, b3 = torch.randn(cm, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1
+    res = torch.randn(M, co, generator=g).to(dtype)
+    dt = 1 if dtype == torch.float16 else 0
+    t1d, w2d, w3d, b2d, b3d, resd = (a.to(DEV) for a in (t1, w2, w3, b2, b3, res))
+    assert hip.lib().usot_conv_pw_supported(cin, cm, co) == 1 and hip.lib().usot_conv_pw_supported(cin, 128, co) == 0
+    y = torch.full((M + 2, co), 5.0, dtype=dtype, device=DEV)
+    d = hip.conv_desc(t1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), None, N=n, H=h, W=h, Cin=cin, OH=h, OW=h, Cout=cm, KH=3, KW=3,
+                      pad=(pad, pad), dil=(dil, dil), act=1)
+    hip.check(hip.lib().usot_conv_pw_lp(hip.stream(), C.byref(d), hip.ptr(w3d), hip.ptr(b3d), hip.ptr(resd), hip.ptr(y), dt), 'usot_conv_pw_lp')
+    torch.cuda.synchronize()
+    assert torch.all(y[M:] == 5.0)                                   # nothing written past the last pixel
+    # the two launches
+    t2 = torch.empty(n, h, h, cm, dtype=dtype, device=DEV)
+    d2 = hip.conv_desc(t1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), t2.data_ptr(), N=n, H=h, W=h, Cin=cin, OH=h, OW=h, Cout=cm, KH=3, KW=3,
+                       pad=(pad, pad), dil=(dil, dil), act=1, tile=32)
+    hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d2), dt, 0), 'conv2')
+    y2 = torch.empty(M, co, dtype=dtype, device=DEV)
+    hip.check(hip.lib().usot_pw_panel_lp(hip.stream(), hip.ptr(t2), hip.ptr(w3d), hip.ptr(b3d), hip.ptr(resd), hip.ptr(y2), M, cm, co, 1, dt),
+              'conv3')
+    torch.cuda.synchronize()
+    assert torch.equal(y[:M], y2)
+    # float64 on the rounded operands, T2 rounded to the storage type as both paths do
+    x64 = t1.double().permute(0, 3, 1, 2)
+    w64 = w2.double().view(cm, 3, 3, cin).permute(0, 3, 1, 2)
+    t2r = torch.nn.functional.conv2d(x64, w64, b2.double(), padding=pad, dilation=dil).relu().permute(0, 2, 3, 1).reshape(M, cm)
+    t2r = t2r.to(dtype).double()
+    ref = (t2r @ w3.double().t() + b3.double() + res.double()).relu()
+    got = y[:M].float().cpu().double()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    # a T2 value that sits on a rounding boundary may round the other way in fp32 accumulation: allow its effect on Y
+    assert float(((got - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 4 * ulp
+    # argument checks: unsupported width, conv2 without ReLU, misaligned output
+    bad = hip.conv_desc(t1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), None, N=n, H=h, W=h, Cin=cin, OH=h, OW=h, Cout=cm, KH=3, KW=3,
+                        pad=(pad, pad), dil=(dil, dil), act=0)
+    assert hip.lib().usot_conv_pw_lp(hip.stream(), C.byref(bad), hip.ptr(w3d), hip.ptr(b3d), hip.ptr(resd), hip.ptr(y), dt) != 0
+    assert hip.lib().usot_conv_pw_lp(hip.stream(), C.byref(d), hip.ptr(w3d), hip.ptr(b3d), None, hip.ptr(y), dt) != 0
+
+
+def test_backbone_bf16_conv_pw_option_is_bit_identical():
+    """Engine option 'conv_pw_lp' (layer3's conv2 -> conv3 fused per 256-pixel panel): the batched bf16 backbone's output is
+    bit-identical to the default lowering's at a batch where the fused launch is taken (>= 192 panels)."""
+    from usot_amd import synth
+    from usot_amd.model import USOT
+    outs = []
+    for on in (False, True):
+        m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to(DEV)
+        m.engine.opt['conv_pw_lp'] = on
+        x = torch.from_numpy(synth.crop(3, 52, 255)).to(DEV)
+        xf = m.engine.features_bf16(x)
+        torch.cuda.synchronize()
+        kinds = [k for k, *_ in next(v for kk, v in m.engine._feat.items() if kk[0] == 'bf16')['plan'].profile(1)]
+        assert (29 in kinds) == on
+        outs.append(xf.clone())
+        del m
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_bw_probe_kernels_move_the_right_bytes():
     """The HBM ceiling probes bench.py quotes GroupDW against (csrc/bw_probe.hip): copy copies, the 4:1 mix sums the four
     adjacent 1 KiB rows of each 64-element group, bad arguments are refused."""

@@ -672,6 +672,23 @@ class Builder:
         self.lp_bytes.append(2 * (m * (c3.cin + 2 * c3.cout + nxt.cout) + c3.cout * c3.cin + nxt.cout * c3.cout))
         return y, t
 
+    def conv_pw(self, name, c2, c3, t1, res, n, h, dtype):
+        """A layer3 bottleneck's conv2 (3x3) + BN + ReLU -> conv3 (1x1) + BN + residual + ReLU in ONE launch (csrc/conv_pw_lp.hip):
+        conv2's output panel never leaves LDS.  Returns y [n,oh,ow,c3.cout] and the output size."""
+        oh, ow = c2.out_hw(h, h)
+        m = n * oh * ow
+        y = self.buf(n, oh, ow, c3.cout, dtype=dtype)
+        w2, w3 = c2.w_lp(dtype), c3.w_lp(dtype)
+        d = hip.conv_desc(t1.data_ptr(), w2.data_ptr(), c2.b.data_ptr(), None, N=n, H=h, W=h, Cin=c2.cin, OH=oh, OW=ow, Cout=c2.cout,
+                          KH=c2.kh, KW=c2.kw, stride=c2.stride, pad=c2.pad, dil=c2.dil, act=ACT_RELU)
+        hip.check(hip.lib().usot_plan_add_conv_pw(self.plan.h, C.byref(d), hip.ptr(w3), hip.ptr(c3.b), hip.ptr(res), hip.ptr(y),
+                                                  1 if dtype == torch.float16 else 0), 'plan_add_conv_pw ' + name)
+        self.plan.keep += [t1, res, w2, w3, c2.b, c3.b]
+        k2 = c2.kh * c2.kw * c2.cin
+        self.log.append((name, m, c3.cout, c3.cin, 1, m * (c2.cout * k2 + c3.cout * c3.cin)))
+        self.lp_bytes.append(2 * (n * h * h * c2.cin + 2 * m * c3.cout + c2.cout * k2 + c3.cout * c3.cin))
+        return y, oh
+
     def bneck_first(self, name, c1, c2, c3, ds, nxt, x, n, h, dtype):
         """Layer1's first bottleneck + the next block's conv1 in ONE launch (csrc/bneck_lp.hip).  Returns (y [n,h,h,256],
         t [n,h,h,64]): the block's output and the next conv1's (both after ReLU)."""
@@ -958,6 +975,14 @@ class Builder:
             if t1 is None:
                 t1, _, _ = self.conv_bf16('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU, dtype=dtype)
                 yield
+            if (fuse and self.opt['conv_pw_lp'] and c2.stride == 1 and c3.kh == 1 and c2.out_hw(h, h) == (h, h)
+                    and hip.lib().usot_conv_pw_supported(c2.cin, c2.cout, c3.cout)
+                    and rs * n * h * h >= self.opt['panel_min_panels'] * 256):
+                # conv2 -> conv3 + residual + ReLU in one launch (the T2 panel stays in LDS); the next 1x1 follows on its own
+                cur, h = self.conv_pw('b%d.conv2+conv3' % bi, c2, c3, t1, sc, n, h, dtype)
+                t1 = None
+                yield
+                continue
             t2, h2, _ = self.conv_bf16('b%d.conv2' % bi, c2, t1, n, h, h, act=ACT_RELU, dtype=dtype)
             yield
             # conv3 + residual + ReLU shares a launch with the NEXT 1x1 conv (the following block's conv1, or the
@@ -1202,6 +1227,9 @@ DEFAULT_OPTIONS = {
     'defer_append': False,
     # layer3 (from block lp_chains_from on) as lp_chains independent batch slices on parallel graph branches, chain i released
     # i * lp_chain_skew launches of chain 0 late (backbone_bf16); 0 = one chain
+    # layer3's conv2 -> conv3 (+ residual + ReLU) of the batched low-precision backbone in ONE launch (csrc/conv_pw_lp.hip: a 256-pixel
+    # panel of conv2's output stays in LDS).  Bit-identical to the two launches; measured in the batch-64 bf16 step
+    'conv_pw_lp': False,
     'lp_chains': 0,
     'lp_chains_from': 7,
     'lp_chain_skew': 2,
