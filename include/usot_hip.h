@@ -193,14 +193,23 @@ int usot_pw_panel_pair_lp(void *stream, const usot_pw_pair_desc *d, int dtype);
 int usot_pw_panel_pair_supported(int CM, int CO, int CN);
 int usot_plan_add_pw_panel_pair(void *plan, const usot_pw_pair_desc *d, int dtype);
 
-/* A layer3 bottleneck's conv2 -> conv3 of the batched low-precision backbone in ONE launch (csrc/conv_pw_lp.hip;
- * modules.py:43-56): y[M][1024] = relu(relu(conv(x; c2->w) + c2->bias) . w3^T + b3 + res[M][1024]).  c2 describes conv2 (x, w
- * [256][KH*KW*256] in the conv kernels' layout, bias, N, H, W, OH, OW, KH, KW, stride, pad, dil; Cin = Cout = 256, act =
- * USOT_ACT_RELU; its y is IGNORED: a 256-pixel panel of conv2's output stays in LDS and is consumed there), w3 [1024][256], b3 fp32,
- * res / y dense; storage type dtype 0 = bf16, 1 = fp16.  Bit-identical to usot_conv2d_lp (tile 32) followed by usot_pw_panel_lp.
- * Shapes: usot_conv_pw_supported(Cin, CM, CO) (256, 256, 1024). */
+/* A bottleneck's conv2 -> conv3 of the batched low-precision backbone in ONE launch (csrc/conv_pw_lp.hip; modules.py:43-56):
+ * y[M][4 CM] = relu(relu(conv(x; c2->w) + c2->bias) . w3^T + b3 + res[M][4 CM]).  c2 describes conv2 (x, w [CM][KH*KW*CM] in the
+ * conv kernels' layout, bias, N, H, W, OH, OW, KH, KW, stride, pad, dil; Cin = Cout = CM, act = USOT_ACT_RELU; its y is IGNORED:
+ * a panel of conv2's output stays in LDS and is consumed there), w3 [4 CM][CM], b3 fp32, res / y dense; storage type dtype 0 =
+ * bf16, 1 = fp16.  Bit-identical to usot_conv2d_lp followed by usot_pw_panel_lp.  Shapes: usot_conv_pw_supported(Cin, CM, CO):
+ * (256, 256, 1024) layer3, (128, 128, 512) layer2.  A workgroup owns a panel of usot_conv_pw_pixels(M) pixels: 256 (16
+ * wavefronts), or 128 (8 wavefronts) when M gives fewer than 192 panels of 256; c2->tile = 1 / 2 forces the 256 / 128 form. */
 int usot_conv_pw_lp(void *stream, const usot_conv_desc *c2, const void *w3, const float *b3, const void *res, void *y, int dtype);
 int usot_conv_pw_supported(int Cin, int CM, int CO);
+int usot_conv_pw_pixels(int64_t M);
+/* ... and the pair form: the NEXT block's conv1 rides along as in usot_pw_panel_pair_lp, T[M][CN] = act2(Y . w1^T + b1) - a whole
+ * bottleneck tail (conv2 -> conv3 + residual + ReLU -> next conv1) per launch.  d as for usot_pw_panel_pair_lp (w3p = w3 [CO][CM],
+ * w1 [CN][CO], natural layouts; M = conv2's output pixels) except that d->t2 is ignored.  Bit-identical to usot_conv2d_lp followed
+ * by usot_pw_panel_pair_lp.  Shapes: usot_conv_pw_pair_supported(CM, CO, CN): (128, 512, 128), layer2. */
+int usot_conv_pw_pair_lp(void *stream, const usot_conv_desc *c2, const usot_pw_pair_desc *d, int dtype);
+int usot_conv_pw_pair_supported(int CM, int CO, int CN);
+int usot_plan_add_conv_pw_pair(void *plan, const usot_conv_desc *c2, const usot_pw_pair_desc *d, int dtype);
 int usot_plan_add_conv_pw(void *plan, const usot_conv_desc *c2, const void *w3, const float *b3, const void *res, void *y, int dtype);
 
 /* 3x3 / stride 1 / pad 1 convolution of the batched low-precision backbone as a direct convolution from an LDS halo tile

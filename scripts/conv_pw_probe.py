@@ -68,11 +68,12 @@ for rep in range(2):
     print('M=%d  conv2 alone %.1f us | two launches %.1f us | fused %.1f us' % (M, timeit(conv2_only), timeit(two), timeit(fused)))
 
 # whole step
-for on in (False, True, False, True):
+for widths, pair in (((), False), ((256,), False), ((256,), True), ((256, 128), True), ((), False), ((256,), True)):
     m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to(DEV)
     m.pr_pool = False
     e = m.engine
-    e.opt['conv_pw_lp'] = on
+    e.opt['conv_pw_lp'] = widths
+    e.opt['conv_pw_pair_lp'] = pair
     x = torch.from_numpy(synth.crop(1, n, 255)).to(DEV)
     for _ in range(3): out = e.features_bf16(x, dtype=dtype)
     p = next(v for k, v in e._feat.items() if k[0] == ('bf16' if a.lp == 'bf16' else 'f16'))
@@ -84,6 +85,6 @@ for on in (False, True, False, True):
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / 100 * 1e6)
     prof = p['plan'].profile(10)
-    fz = [ms * 1e3 for k, *_, ms in prof if k == 29]
-    print('conv_pw_lp=%s: step %.1f us (best of 5 x 100 replays: %.1f); fused launches: %s' % (on, sorted(ts)[2], min(ts), ['%.1f' % v for v in fz]))
+    fz = [ms * 1e3 for k, *_, ms in prof if k in (29, 30)]
+    print('conv_pw_lp=%s conv_pw_pair_lp=%s: step %.1f us (best of 5 x 100 replays: %.1f); fused launches: %s' % (widths, pair, sorted(ts)[2], min(ts), ['%.1f' % v for v in fz]))
     del m, e, p

@@ -24,7 +24,7 @@ convs = iter(p['log'])
 tot = 0.0; fl = 0.0
 for kind, tile, ks, groups, ms in prof:
     tot += ms
-    if kind in (11, 18, 22, 23, 24, 25, 26, 27, 28, 29):
+    if kind in (11, 18, 22, 23, 24, 25, 26, 27, 28, 29, 30):
         name, M, N, K, g, macs = next(convs)
         byts = 2.0 * (M * K / (9 if K % 9 == 0 and K > 1024 else 1) + M * N + N * K) * g  # (fused pairs: first conv only)
         fl += 2 * macs

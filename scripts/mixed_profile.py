@@ -21,7 +21,7 @@ convs = iter(p['log'])
 tot = 0.0
 for kind, tile, ks, groups, ms in prof:
     tot += ms
-    if kind in (0, 11, 18, 22, 23, 24, 25, 26, 27, 28, 29):
+    if kind in (0, 11, 18, 22, 23, 24, 25, 26, 27, 28, 29, 30):
         try:
             name, M, N, K, g, macs = next(convs)
         except StopIteration:

@@ -1209,13 +1209,15 @@ def test_pw_panel_pair_equals_the_two_convolutions(cm, co, cn, M, act2, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('form', [1, 2], ids=['panel256', 'panel128'])
 @pytest.mark.parametrize('n,h,pad,dil', [(2, 31, 2, 2), (1, 13, 1, 1), (1, 16, 1, 1), (3, 9, 2, 2)])
-def test_conv_pw_fused_equals_the_two_launches(n, h, pad, dil, dtype):
+def test_conv_pw_fused_equals_the_two_launches(n, h, pad, dil, dtype, form):
     """Layer3's conv2 -> conv3 in one launch (csrc/conv_pw_lp.hip: the 256-pixel T2 panel stays in LDS) vs the two launches it
     replaces on the same operands - the 256 x 256 implicit-GEMM tile (32), then the pixel-stationary panel kernel: BIT-identical
     (same products, same k order, T2 rounded once); and against float64 on the rounded operands.  Geometries: layer3's dilated
     conv2 (b8..b12: pad 2 / dil 2) and b7's (pad 1 / dil 1); pixel counts with full panels + a ragged one, a single ragged panel
-    (169 < 256: waves without any pixel), exactly one panel (256)."""
+    (169 < 256: waves without any pixel), exactly one panel (256).  form: the 256-pixel panel on 16 wavefronts / the 128-pixel
+    panel on 8 (what the launcher picks below 192 panels of 256: batch 32), forced through c2->tile."""
     import ctypes as C
     g = torch.Generator().manual_seed(n * 1000 + h * 10 + pad)
     cin = cm = 256
@@ -1228,10 +1230,11 @@ def test_conv_pw_fused_equals_the_two_launches(n, h, pad, dil, dtype):
     res = torch.randn(M, co, generator=g).to(dtype)
     dt = 1 if dtype == torch.float16 else 0
     t1d, w2d, w3d, b2d, b3d, resd = (a.to(DEV) for a in (t1, w2, w3, b2, b3, res))
-    assert hip.lib().usot_conv_pw_supported(cin, cm, co) == 1 and hip.lib().usot_conv_pw_supported(cin, 128, co) == 0
+    assert hip.lib().usot_conv_pw_supported(cin, cm, co) == 1 and hip.lib().usot_conv_pw_supported(cin, 64, co) == 0
     y = torch.full((M + 2, co), 5.0, dtype=dtype, device=DEV)
     d = hip.conv_desc(t1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), None, N=n, H=h, W=h, Cin=cin, OH=h, OW=h, Cout=cm, KH=3, KW=3,
-                      pad=(pad, pad), dil=(dil, dil), act=1)
+                      pad=(pad, pad), dil=(dil, dil), act=1, tile=form)
+    assert hip.lib().usot_conv_pw_pixels(M) == 128 and hip.lib().usot_conv_pw_pixels(192 * 256) == 256
     hip.check(hip.lib().usot_conv_pw_lp(hip.stream(), C.byref(d), hip.ptr(w3d), hip.ptr(b3d), hip.ptr(resd), hip.ptr(y), dt), 'usot_conv_pw_lp')
     torch.cuda.synchronize()
     assert torch.all(y[M:] == 5.0)                                   # nothing written past the last pixel
@@ -1262,20 +1265,71 @@ def test_conv_pw_fused_equals_the_two_launches(n, h, pad, dil, dtype):
     assert hip.lib().usot_conv_pw_lp(hip.stream(), C.byref(d), hip.ptr(w3d), hip.ptr(b3d), None, hip.ptr(y), dt) != 0
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('form', [1, 2], ids=['panel256', 'panel128'])
+@pytest.mark.parametrize('n,h,stride,pad,cn', [(2, 31, 1, 1, 128), (1, 33, 2, 0, 128), (1, 16, 1, 1, 128), (2, 31, 1, 1, 0), (1, 12, 1, 1, 0)])
+def test_conv_pw_layer2_forms_equal_the_unfused_launches(n, h, stride, pad, cn, dtype, form):
+    """Layer2's widths on the fused kernel (csrc/conv_pw_lp.hip): conv2 3x3 128 -> 128 (stride 1 / pad 1, and b3's stride 2 / pad 0)
+    -> conv3 128 -> 512 + residual + ReLU, with (cn = 128: pair form) or without the next block's conv1 - bit-identical to the
+    tiled conv2 followed by the pixel-stationary panel kernel (pair form: usot_pw_panel_pair_lp), Y and T alike."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + stride + cn)
+    cm, co = 128, 512
+    oh = (h + 2 * pad - 3) // stride + 1
+    M = n * oh * oh
+    t1 = torch.randn(n, h, h, cm, generator=g).relu().to(dtype)
+    w2 = (torch.randn(cm, 9 * cm, generator=g) / (9 * cm) ** 0.5).to(dtype)
+    w3 = (torch.randn(co, cm, generator=g) / cm ** 0.5).to(dtype)
+    w1 = (torch.randn(max(cn, 64), co, generator=g) / co ** 0.5).to(dtype)
+    b2, b3, b1 = torch.randn(cm, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1, torch.randn(max(cn, 64), generator=g) * 0.1
+    res = torch.randn(M, co, generator=g).to(dtype)
+    dt = 1 if dtype == torch.float16 else 0
+    t1d, w2d, w3d, w1d, b2d, b3d, b1d, resd = (a.to(DEV) for a in (t1, w2, w3, w1, b2, b3, b1, res))
+    geo = dict(N=n, H=h, W=h, Cin=cm, OH=oh, OW=oh, Cout=cm, KH=3, KW=3, stride=stride, pad=(pad, pad), act=1)
+    y = torch.full((M + 2, co), 5.0, dtype=dtype, device=DEV)
+    t = torch.full((M + 2, max(cn, 64)), 5.0, dtype=dtype, device=DEV)
+    d = hip.conv_desc(t1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), None, tile=form, **geo)
+    t2 = torch.empty(n, oh, oh, cm, dtype=dtype, device=DEV)
+    d2 = hip.conv_desc(t1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), t2.data_ptr(), tile=37, **geo)
+    hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d2), dt, 0), 'conv2')
+    y2 = torch.empty(M, co, dtype=dtype, device=DEV)
+    if cn:
+        assert hip.lib().usot_conv_pw_pair_supported(cm, co, cn) == 1 and hip.lib().usot_conv_pw_pair_supported(cm, co, 256) == 0
+        pd = hip.pw_pair_desc(None, w3d.data_ptr(), b3d.data_ptr(), resd.data_ptr(), y.data_ptr(), w1d.data_ptr(), b1d.data_ptr(),
+                              t.data_ptr(), M, cm, co, cn, 1)
+        hip.check(hip.lib().usot_conv_pw_pair_lp(hip.stream(), C.byref(d), C.byref(pd), dt), 'usot_conv_pw_pair_lp')
+        tt = torch.empty(M, cn, dtype=dtype, device=DEV)
+        pd2 = hip.pw_pair_desc(t2.data_ptr(), w3d.data_ptr(), b3d.data_ptr(), resd.data_ptr(), y2.data_ptr(), w1d.data_ptr(),
+                               b1d.data_ptr(), tt.data_ptr(), M, cm, co, cn, 1)
+        hip.check(hip.lib().usot_pw_panel_pair_lp(hip.stream(), C.byref(pd2), dt), 'usot_pw_panel_pair_lp')
+        torch.cuda.synchronize()
+        assert torch.equal(t[:M], tt) and torch.all(t[M:] == 5.0)
+        pd.M = M + 1                                                # the pair's pixel count must be conv2's
+        assert hip.lib().usot_conv_pw_pair_lp(hip.stream(), C.byref(d), C.byref(pd), dt) != 0
+    else:
+        assert hip.lib().usot_conv_pw_supported(cm, cm, co) == 1
+        hip.check(hip.lib().usot_conv_pw_lp(hip.stream(), C.byref(d), hip.ptr(w3d), hip.ptr(b3d), hip.ptr(resd), hip.ptr(y), dt), 'usot_conv_pw_lp')
+        hip.check(hip.lib().usot_pw_panel_lp(hip.stream(), hip.ptr(t2), hip.ptr(w3d), hip.ptr(b3d), hip.ptr(resd), hip.ptr(y2), M, cm, co, 1, dt),
+                  'conv3')
+        torch.cuda.synchronize()
+    assert torch.equal(y[:M], y2) and torch.all(y[M:] == 5.0)
+
+
 def test_backbone_bf16_conv_pw_option_is_bit_identical():
-    """Engine option 'conv_pw_lp' (layer3's conv2 -> conv3 fused per 256-pixel panel): the batched bf16 backbone's output is
-    bit-identical to the default lowering's at a batch where the fused launch is taken (>= 192 panels)."""
+    """Engine options 'conv_pw_lp' / 'conv_pw_pair_lp' (layer3's conv2 -> conv3 and layer2's conv2 -> conv3 -> next conv1 fused per
+    pixel panel): the batched bf16 backbone's output is bit-identical to the unfused lowering's."""
     from usot_amd import synth
     from usot_amd.model import USOT
     outs = []
     for on in (False, True):
         m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to(DEV)
-        m.engine.opt['conv_pw_lp'] = on
+        m.engine.opt['conv_pw_lp'] = (256,) if on else ()
+        m.engine.opt['conv_pw_pair_lp'] = on
         x = torch.from_numpy(synth.crop(3, 52, 255)).to(DEV)
         xf = m.engine.features_bf16(x)
         torch.cuda.synchronize()
         kinds = [k for k, *_ in next(v for kk, v in m.engine._feat.items() if kk[0] == 'bf16')['plan'].profile(1)]
-        assert (29 in kinds) == on
+        assert (29 in kinds) == on and (30 in kinds) == on
         outs.append(xf.clone())
         del m
     assert torch.equal(outs[0], outs[1])

@@ -36,27 +36,49 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct CpK {
-    const uint16_t *x, *w2, *w3, *res, *zero;
-    const float *b2, *b3;
-    uint16_t *y;
+    const uint16_t *x, *w2, *w3, *res, *zero, *w1;
+    const float *b2, *b3, *b1;
+    uint16_t *y, *t;
     int H, W, OW, KW, stride, pad_h, pad_w, dil_h, dil_w;
-    int M, P, KT, npanels;
+    int M, P, KT, npanels, act2;
 };
 
 __device__ __attribute__((aligned(16))) uint32_t cp_zero16[4] = {0u, 0u, 0u, 0u};     // source of padding taps (LDS-DMA)
 
-constexpr int CP_BM = 256, CP_CIN = 256, CP_CM = 256, CP_CO = 1024, CP_NW = 16, CP_NTHR = CP_NW * 64;
 #ifndef CP_WD
 #define CP_WD 2
 #endif
 constexpr int CP_LDC = 8;                                  // 16-byte chunks per staged row (64 elements)
-constexpr int CP_CCH = CP_CIN / 64;                        // channel chunks per tap
-constexpr int CP_CPR = CP_CM / 8;                          // 16-byte chunks per T2 row / per slab row
-constexpr int CP_SLAB = 64 * CP_CPR;                       // chunks of a w3 slab (64 channels x 256 k)
-constexpr int CP_G = CP_CO / 64;                           // channel groups of conv3
-constexpr int CP_KS = CP_CM / 32;                          // MFMA k-steps of conv3
-constexpr int CP_LDS = 2 * (CP_BM + CP_CM) * CP_LDC * 16;  // 128 KB: conv2's two stages = the T2 panel >= slab ring + bias
-static_assert(CP_LDS >= CP_BM * CP_CPR * 16 && CP_LDS >= 3 * CP_SLAB * 16 + CP_CO * 4, "LDS phases");
+
+// NW wavefronts own a panel of 16 NW pixels: 16 (256 pixels) or 8 (128 pixels: batches whose 256-pixel panels would leave CUs
+// idle).  CM = conv2's width (= its input's: 256 in layer3, 128 in layer2), conv3 expands to 4 CM; CN > 0: the pair form -
+// the NEXT block's conv1 (4 CM -> CN) rides along as in csrc/pw_panel.hip (Y's sixteen channels per lane, rounded, are the B
+// fragments of the second GEMM; its bank's k-slice of the group sits in the same slab ring).
+template <int NW, int CM, int CN>
+struct CpCfg {
+    static constexpr int BM = NW * 16, NTHR = NW * 64;
+    static constexpr int CIN = CM, CO = 4 * CM;
+    static constexpr int CCH = CIN / 64;                   // channel chunks per tap
+    static constexpr int CPR = CM / 8;                     // 16-byte chunks per T2 row / per w3 slab row
+    static constexpr int SLAB0 = 64 * CPR;                 // chunks of a w3 slab (64 channels x CM k)
+    static constexpr int SLAB1 = CN * 8;                   // ... of w1's slab (CN channels x this group's 64 k)
+    static constexpr int SLAB = SLAB0 + SLAB1;
+    static constexpr int G = CO / 64;                      // channel groups of conv3
+    static constexpr int KS = CM / 32;                     // MFMA k-steps of conv3
+    static constexpr int NB1 = CN / 16;                    // 16-channel blocks of T
+    static constexpr int TM = 4, TN = CM / 64;             // a wave = 64 pixels x CM / 4 channels of conv2
+    static constexpr int WM = BM / (TM * 16);              // waves along the pixels (4 | 2); along the channels: 4
+    static constexpr int RPP = NTHR / 8;                   // tile rows one staging pass covers
+    static constexpr int XI = BM / RPP, WI = CM / RPP;     // DMA instructions per lane, k-tile and operand
+    static constexpr int STAGES = 2 * (BM + CM) * CP_LDC * 16, RING = 3 * SLAB * 16 + (CO + CN) * 4;
+    static constexpr int LDS = STAGES > RING ? STAGES : RING;
+    static_assert(NW == 16 || NW == 8, "panels of 256 or 128 pixels");
+    static_assert(CM == 256 || CM == 128, "layer3 / layer2 widths");
+    static_assert(CN % 64 == 0 && WI >= 1 && CM % RPP == 0, "shape");
+    static_assert(STAGES >= BM * CPR * 16, "the T2 panel fits conv2's stages");
+    static_assert(SLAB0 % NTHR == 0 && SLAB1 % NTHR == 0, "whole DMA instructions per slab");
+    static_assert(LDS <= 160 * 1024, "LDS");
+};
 
 template <bool F16> __device__ __forceinline__ f32x4 cp_mfma(u32x4 a, u32x4 b, f32x4 c)
 {
@@ -95,13 +117,13 @@ __device__ __forceinline__ void cp_barrier()
     asm volatile("" ::: "memory");
 }
 
-template <bool F16>
-__global__ __launch_bounds__(CP_NTHR) void conv_pw_kernel(const CpK p)
+template <bool F16, int NW, int CM, int CN>
+__global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
 {
-    constexpr int BM = CP_BM, CM = CP_CM, LDC = CP_LDC, NTHR = CP_NTHR;
-    constexpr int RPP = NTHR / 8;                          // tile rows one staging pass covers (128)
-    constexpr int XI = BM / RPP, WI = CM / RPP;            // DMA instructions per lane, k-tile and operand (2, 2)
-    constexpr int TM = 4, TN = 4;                          // a wave = 64 pixels x 64 channels of conv2
+    using Cf = CpCfg<NW, CM, CN>;
+    constexpr int BM = Cf::BM, LDC = CP_LDC, NTHR = Cf::NTHR, RPP = Cf::RPP, XI = Cf::XI, WI = Cf::WI, TM = Cf::TM, TN = Cf::TN, WM = Cf::WM;
+    constexpr int CP_CIN = Cf::CIN, CP_CCH = Cf::CCH, CP_CPR = Cf::CPR, CP_SLAB = Cf::SLAB, CP_G = Cf::G, CP_KS = Cf::KS, CP_CO = Cf::CO;
+    constexpr int NB1 = Cf::NB1;
     extern __shared__ __attribute__((aligned(16))) u32x4 cp_smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -118,7 +140,7 @@ __global__ __launch_bounds__(CP_NTHR) void conv_pw_kernel(const CpK p)
                      : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
     };
 
-    // ------------------------------------------------------------------ phase 1: conv2, 256 pixels x 256 channels
+    // ------------------------------------------------------------------ phase 1: conv2, BM pixels x CM channels
     f32x4 acc2[TN][TM];
     {
         const int lr = tid >> 3;
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(CP_NTHR) void conv_pw_kernel(const CpK p)
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int wm = wave & 3, wn = wave >> 2;
+        const int wm = wave % WM, wn = wave / WM;
         const u32x4 *sX = cp_smem, *sW = cp_smem + 2 * BM * LDC;
         const int sq = cp_swz(l15);                        // rows differ from l15 by multiples of 16
         const int nt = p.KT;
@@ -235,20 +257,35 @@ __global__ __launch_bounds__(CP_NTHR) void conv_pw_kernel(const CpK p)
 
     // ------------------------------------------------------------------ phase 4: conv3 over the panel (csrc/pw_panel.hip, PB = 1)
     float *sBias = (float *)(cp_smem + 3 * CP_SLAB);
-    sBias[tid] = p.b3[tid];                                // CP_CO == CP_NTHR
-    static_assert(CP_CO == CP_NTHR, "one bias value per thread");
-    // slab of group g -> ring slot: physical chunk c = i * 1024 + tid holds logical chunk pc ^ (row & 15) of slab row `row`,
+    for (int i = tid; i < CP_CO; i += NTHR) sBias[i] = p.b3[i];
+    if constexpr (CN > 0)
+        for (int i = tid; i < CN; i += NTHR) sBias[CP_CO + i] = p.b1[i];
+    // slab of group g -> ring slot: physical chunk c = i * NTHR + tid holds logical chunk pc ^ (row & 15) of slab row `row`,
     // row = MFMA row rho of 16-channel block blk = channel g * 64 + (blk >> 1) * 32 + (rho >> 2) * 8 + (blk & 1) * 4 + (rho & 3)
     auto issue_slab = [&](int g, int slot) {
         const uint32_t base = lds0 + (uint32_t)(slot * CP_SLAB * 16) + (uint32_t)(wave * 64 * 16);
 #pragma unroll
-        for (int i = 0; i < CP_SLAB / NTHR; ++i) {
+        for (int i = 0; i < Cf::SLAB0 / NTHR; ++i) {
             const int c = i * NTHR + tid;
             const int row = c / CP_CPR, pc = c % CP_CPR;
             const int lc = pc ^ (row & 15);
             const int blk = row >> 4, rho = row & 15;
             const int ch = g * 64 + (blk >> 1) * 32 + (rho >> 2) * 8 + (blk & 1) * 4 + (rho & 3);
             dma16u(p.w3 + (long)ch * CM + lc * 8, __builtin_amdgcn_readfirstlane(base + (uint32_t)(i * NTHR * 16)));
+        }
+        if constexpr (CN > 0) {
+            // w1's k-slice of the group: row = T channel (blk >> 2) * 64 + ((blk >> 1) & 1) * 32 + (rho >> 2) * 8 + (blk & 1) * 4 + (rho & 3)
+            // (blk = 16-channel block of T), 8 chunks of 8 k, chunk pc holds logical chunk pc ^ ((row >> 1) & 7)
+#pragma unroll
+            for (int i = 0; i < Cf::SLAB1 / NTHR; ++i) {
+                const int c = i * NTHR + tid;
+                const int row = c / 8, pc = c % 8;
+                const int lc = pc ^ ((row >> 1) & 7);
+                const int blk = row >> 4, rho = row & 15;
+                const int ch = (blk >> 2) * 64 + ((blk >> 1) & 1) * 32 + (rho >> 2) * 8 + (blk & 1) * 4 + (rho & 3);
+                dma16u(p.w1 + (long)ch * CP_CO + g * 64 + lc * 8,
+                       __builtin_amdgcn_readfirstlane(base + (uint32_t)((Cf::SLAB0 + i * NTHR) * 16)));
+            }
         }
     };
     const long pm = (long)bm0 + wave * 16 + l15;           // this lane's pixel
@@ -269,6 +306,9 @@ __global__ __launch_bounds__(CP_NTHR) void conv_pw_kernel(const CpK p)
         };
         load_res(0);
         f32x4 acc[4];
+        f32x4 acct[NB1 ? NB1 : 1];                         // the second GEMM's accumulators live across the groups
+#pragma unroll
+        for (int n = 0; n < (NB1 ? NB1 : 1); ++n) acct[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA is invisible to the compiler's wait counts
         cp_barrier();
 
@@ -276,7 +316,7 @@ __global__ __launch_bounds__(CP_NTHR) void conv_pw_kernel(const CpK p)
             const u32x4 *slab = cp_smem + (g % 3) * CP_SLAB;
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            constexpr int WD = CP_WD;                      // A fragments through a ring of WD k-steps (counted lgkmcnt by the compiler)
+            constexpr int WD = (CN > 0 && NW == 16) ? 1 : CP_WD;   // A fragments through a ring of WD k-steps (the 16-wave pair form has 128 registers)
             u32x4 wf[WD][4];
             auto read_w = [&](int ks, u32x4 (&w)[4]) {
 #pragma unroll
@@ -318,6 +358,17 @@ __global__ __launch_bounds__(CP_NTHR) void conv_pw_kernel(const CpK p)
                 *(u32x4 *)(p.y + pm * CP_CO + c0) = yf[0];
                 *(u32x4 *)(p.y + pm * CP_CO + c0 + 32) = yf[1];
             }
+            // ---- second GEMM, this group's 64 k: the lane's rounded outputs are its B fragments (k-step s = run s)
+            if constexpr (CN > 0) {
+                const u32x4 *slab1 = cp_smem + (g % 3) * CP_SLAB + Cf::SLAB0;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int n = 0; n < NB1; ++n) {
+                        const u32x4 w1f = slab1[(n * 16 + l15) * 8 + ((s2 * 4 + q) ^ ((l15 >> 1) & 7))];
+                        acct[n] = cp_mfma<F16>(w1f, yf[s2], acct[n]);
+                    }
+            }
         };
         // one interval.  Leaders: GEMM(k), epilogue(k), residual of k + 1; trailers: epilogue(k - 1), residual of k, GEMM(k).
         auto interval = [&](int k) {
@@ -341,58 +392,134 @@ __global__ __launch_bounds__(CP_NTHR) void conv_pw_kernel(const CpK p)
 #pragma unroll 1
         for (int k = 0; k < CP_G; ++k) interval(k);
         if constexpr (trail) epilogue(CP_G - 1);
+        // ---- epilogue of the second GEMM: acct[n][r] = T channel (n >> 2) * 64 + ((n >> 1) & 1) * 32 + q * 8 + (n & 1) * 4 + r
+        if constexpr (CN > 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB1 / 4; ++nb) {
+                const int t0 = nb * 64 + q * 8;
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 b1v = *(const f32x4 *)(sBias + CP_CO + t0 + (i >> 1) * 32 + (i & 1) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[i * 4 + r] = acct[nb * 4 + i][r] + b1v[r];
+                        if (p.act2 == USOT_ACT_RELU) v[i * 4 + r] = fmaxf(v[i * 4 + r], 0.0f);
+                    }
+                }
+                if (pm < (long)p.M) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        u32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = usot_pack2_lp<F16>(v[k * 8 + 2 * e], v[k * 8 + 2 * e + 1]);
+                        *(u32x4 *)(p.t + pm * CN + t0 + k * 32) = o;
+                    }
+                }
+            }
+        }
     };
-    // a workgroup's waves are dealt round-robin to the four SIMDs: every SIMD hosts two leaders and two trailers
-    if (wave >= CP_NW / 2) run(std::true_type{});
+    // a workgroup's waves are dealt round-robin to the four SIMDs: every SIMD hosts as many leaders as trailers
+    if (wave >= NW / 2) run(std::true_type{});
     else                   run(std::false_type{});
+}
+
+template <int NW, int CM, int CN>
+int cp_launch(hipStream_t s, const CpK &p, int dtype)
+{
+    using Cf = CpCfg<NW, CM, CN>;
+    static bool raised[2] = {false, false};
+    const void *fn = dtype ? (const void *)conv_pw_kernel<true, NW, CM, CN> : (const void *)conv_pw_kernel<false, NW, CM, CN>;
+    if (!raised[dtype]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) != hipSuccess) return USOT_ELAUNCH;
+        raised[dtype] = true;
+    }
+    if (dtype) hipLaunchKernelGGL((conv_pw_kernel<true, NW, CM, CN>), dim3(p.npanels), dim3(Cf::NTHR), Cf::LDS, s, p);
+    else       hipLaunchKernelGGL((conv_pw_kernel<false, NW, CM, CN>), dim3(p.npanels), dim3(Cf::NTHR), Cf::LDS, s, p);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+// conv2's descriptor -> kernel arguments (everything but the 1x1 banks); returns the panel size, 0 = invalid
+int cp_fill(const usot_conv_desc *c2, int CM, CpK &p)
+{
+    if (!c2 || !c2->x || !c2->w || !c2->bias) return 0;
+    if (c2->Cin != CM || c2->Cout != CM || c2->act != USOT_ACT_RELU || c2->N <= 0) return 0;
+    if (c2->groups > 1 || c2->ksplit > 1 || c2->res || c2->KH <= 0 || c2->KW <= 0 || c2->stride <= 0) return 0;
+    const int oh = (c2->H + 2 * c2->pad_h - c2->dil_h * (c2->KH - 1) - 1) / c2->stride + 1;
+    const int ow = (c2->W + 2 * c2->pad_w - c2->dil_w * (c2->KW - 1) - 1) / c2->stride + 1;
+    if (oh != c2->OH || ow != c2->OW || oh <= 0 || ow <= 0) return 0;
+    if (((uintptr_t)c2->x % 16) || ((uintptr_t)c2->w % 16) || ((uintptr_t)c2->bias % 16)) return 0;
+    const long M = (long)c2->N * oh * ow;
+    if (M > 0x7fffffffL - 256) return 0;
+    static const uint16_t *zero_page = nullptr;
+    if (!zero_page) {
+        void *zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(cp_zero16)) != hipSuccess || !zp) return 0;
+        zero_page = (const uint16_t *)zp;
+    }
+    // fewer than 192 panels of 256 pixels (batch 32 at layer2 / layer3 resolution: 121) would leave half the chip idle: panels of
+    // 128 pixels then (8 wavefronts; c2->tile = 1 / 2 forces the 256- / 128-pixel form: tests)
+    const bool small = c2->tile == 2 || (c2->tile != 1 && (M + 255) / 256 < 192);
+    const int bm = small ? 128 : 256;
+    p.x = (const uint16_t *)c2->x; p.w2 = (const uint16_t *)c2->w; p.zero = zero_page; p.b2 = c2->bias;
+    p.H = c2->H; p.W = c2->W; p.OW = ow; p.KW = c2->KW; p.stride = c2->stride; p.pad_h = c2->pad_h; p.pad_w = c2->pad_w;
+    p.dil_h = c2->dil_h; p.dil_w = c2->dil_w;
+    p.M = (int)M; p.P = oh * ow; p.KT = c2->KH * c2->KW * (CM / 64); p.npanels = (int)((M + bm - 1) / bm);
+    return bm;
 }
 
 }  // namespace
 
 extern "C" int usot_conv_pw_supported(int Cin, int CM, int CO)
 {
-    return Cin == CP_CIN && CM == CP_CM && CO == CP_CO;
+    return Cin == CM && CO == 4 * CM && (CM == 256 || CM == 128);
 }
 
-/* Y = relu(relu(conv(x; c2->w) + c2->bias) . w3^T + b3 + res): conv2 (c2: x, w [256][KH*KW*256], bias, N, H, W, KH, KW, stride,
- * pad, dil; Cin = Cout = 256, act must be USOT_ACT_RELU, c2->y is ignored - T2 never reaches memory) and the 1x1 expansion
- * w3 [1024][256] + b3 + residual res [M][1024] + ReLU into y [M][1024]; storage type dtype 0 = bf16, 1 = fp16. */
+extern "C" int usot_conv_pw_pair_supported(int CM, int CO, int CN)
+{
+    return CM == 128 && CO == 512 && CN == 128;
+}
+
+/* pixels per panel (= per workgroup) the launcher would use for M pixels */
+extern "C" int usot_conv_pw_pixels(int64_t M) { return (M + 255) / 256 < 192 ? 128 : 256; }
+
+/* Y = relu(relu(conv(x; c2->w) + c2->bias) . w3^T + b3 + res): see usot_hip.h */
 extern "C" int usot_conv_pw_lp(void *stream, const usot_conv_desc *c2, const void *w3, const float *b3, const void *res, void *y,
                                int dtype)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
-    if (!c2 || !c2->x || !c2->w || !c2->bias || !w3 || !b3 || !res || !y || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
-    if (!usot_conv_pw_supported(c2->Cin, c2->Cout, CP_CO) || c2->act != USOT_ACT_RELU || c2->N <= 0) return USOT_EINVAL;
-    if (c2->groups > 1 || c2->ksplit > 1 || c2->res || c2->KH <= 0 || c2->KW <= 0 || c2->stride <= 0) return USOT_EINVAL;
-    const int oh = (c2->H + 2 * c2->pad_h - c2->dil_h * (c2->KH - 1) - 1) / c2->stride + 1;
-    const int ow = (c2->W + 2 * c2->pad_w - c2->dil_w * (c2->KW - 1) - 1) / c2->stride + 1;
-    if (oh != c2->OH || ow != c2->OW || oh <= 0 || ow <= 0) return USOT_EINVAL;
-    const void *ptrs[] = {c2->x, c2->w, c2->bias, w3, b3, res, y};
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics: one GPU per process (common.h)
+    if (!c2 || !w3 || !b3 || !res || !y || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
+    if (!usot_conv_pw_supported(c2->Cin, c2->Cout, 4 * c2->Cout)) return USOT_EINVAL;
+    const void *ptrs[] = {w3, b3, res, y};
     for (const void *q : ptrs)
         if ((uintptr_t)q % 16) return USOT_EINVAL;
-    const long M = (long)c2->N * oh * ow;
-    if (M > 0x7fffffffL - CP_BM) return USOT_EINVAL;
-    static const uint16_t *zero_page = nullptr;
-    if (!zero_page) {
-        void *zp = nullptr;
-        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(cp_zero16)) != hipSuccess || !zp) return USOT_ELAUNCH;
-        zero_page = (const uint16_t *)zp;
-    }
-    CpK p;
-    p.x = (const uint16_t *)c2->x; p.w2 = (const uint16_t *)c2->w; p.w3 = (const uint16_t *)w3; p.res = (const uint16_t *)res;
-    p.zero = zero_page; p.b2 = c2->bias; p.b3 = b3; p.y = (uint16_t *)y;
-    p.H = c2->H; p.W = c2->W; p.OW = ow; p.KW = c2->KW; p.stride = c2->stride; p.pad_h = c2->pad_h; p.pad_w = c2->pad_w;
-    p.dil_h = c2->dil_h; p.dil_w = c2->dil_w;
-    p.M = (int)M; p.P = oh * ow; p.KT = c2->KH * c2->KW * CP_CCH; p.npanels = (int)((M + CP_BM - 1) / CP_BM);
-    static bool raised[2] = {false, false};
-    if (!raised[dtype]) {
-        const void *fn = dtype ? (const void *)conv_pw_kernel<true> : (const void *)conv_pw_kernel<false>;
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS) != hipSuccess) return USOT_ELAUNCH;
-        raised[dtype] = true;
-    }
+    CpK p = {};
+    const int bm = cp_fill(c2, c2->Cout, p);
+    if (!bm) return USOT_EINVAL;
+    p.w3 = (const uint16_t *)w3; p.res = (const uint16_t *)res; p.b3 = b3; p.y = (uint16_t *)y;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype) hipLaunchKernelGGL(conv_pw_kernel<true>, dim3(p.npanels), dim3(CP_NTHR), CP_LDS, s, p);
-    else       hipLaunchKernelGGL(conv_pw_kernel<false>, dim3(p.npanels), dim3(CP_NTHR), CP_LDS, s, p);
-    USOT_CHECK_LAUNCH();
-    return USOT_OK;
+    if (c2->Cout == 256) return bm == 128 ? cp_launch<8, 256, 0>(s, p, dtype) : cp_launch<16, 256, 0>(s, p, dtype);
+    return bm == 128 ? cp_launch<8, 128, 0>(s, p, dtype) : cp_launch<16, 128, 0>(s, p, dtype);
+}
+
+/* the pair form: ... and T = act2(Y . w1^T + b1), the NEXT block's conv1, in the same launch.  d: w3p = w3 [CO][CM], b3, res, y,
+ * w1 [CN][CO], b1, t, M (= conv2's output pixels), CM, CO, CN, act2; d->t2 is ignored */
+extern "C" int usot_conv_pw_pair_lp(void *stream, const usot_conv_desc *c2, const usot_pw_pair_desc *d, int dtype)
+{
+    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;
+    if (!c2 || !d || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
+    if (!d->w3p || !d->b3 || !d->res || !d->y || !d->w1 || !d->b1 || !d->t) return USOT_EINVAL;
+    if (d->act2 != USOT_ACT_NONE && d->act2 != USOT_ACT_RELU) return USOT_EINVAL;
+    if (!usot_conv_pw_pair_supported(d->CM, d->CO, d->CN) || c2->Cout != d->CM) return USOT_EINVAL;
+    const void *ptrs[] = {d->w3p, d->b3, d->res, d->y, d->w1, d->b1, d->t};
+    for (const void *q : ptrs)
+        if ((uintptr_t)q % 16) return USOT_EINVAL;
+    CpK p = {};
+    const int bm = cp_fill(c2, d->CM, p);
+    if (!bm || p.M != d->M) return USOT_EINVAL;
+    p.w3 = (const uint16_t *)d->w3p; p.res = (const uint16_t *)d->res; p.b3 = d->b3; p.y = (uint16_t *)d->y;
+    p.w1 = (const uint16_t *)d->w1; p.b1 = d->b1; p.t = (uint16_t *)d->t; p.act2 = d->act2;
+    hipStream_t s = (hipStream_t)stream;
+    return bm == 128 ? cp_launch<8, 128, 128>(s, p, dtype) : cp_launch<16, 128, 128>(s, p, dtype);
 }

@@ -689,6 +689,26 @@ class Builder:
         self.lp_bytes.append(2 * (n * h * h * c2.cin + 2 * m * c3.cout + c2.cout * k2 + c3.cout * c3.cin))
         return y, oh
 
+    def conv_pw_pair(self, name, c2, c3, nxt, t1, res, n, h, act2, dtype):
+        """A whole bottleneck tail of layer2 in ONE launch (csrc/conv_pw_lp.hip, pair form): conv2 (3x3) + BN + ReLU -> conv3 + BN +
+        residual + ReLU -> the next block's conv1 + BN + ReLU.  Returns (y, t, oh)."""
+        oh, ow = c2.out_hw(h, h)
+        m = n * oh * ow
+        y = self.buf(n, oh, ow, c3.cout, dtype=dtype)
+        t = self.buf(n, oh, ow, nxt.cout, dtype=dtype)
+        w2, w3, w1 = c2.w_lp(dtype), c3.w_lp(dtype), nxt.w_lp(dtype)
+        d2 = hip.conv_desc(t1.data_ptr(), w2.data_ptr(), c2.b.data_ptr(), None, N=n, H=h, W=h, Cin=c2.cin, OH=oh, OW=ow, Cout=c2.cout,
+                           KH=c2.kh, KW=c2.kw, stride=c2.stride, pad=c2.pad, dil=c2.dil, act=ACT_RELU)
+        d = hip.pw_pair_desc(None, w3.data_ptr(), c3.b.data_ptr(), res.data_ptr(), y.data_ptr(), w1.data_ptr(), nxt.b.data_ptr(),
+                             t.data_ptr(), m, c3.cin, c3.cout, nxt.cout, act2)
+        hip.check(hip.lib().usot_plan_add_conv_pw_pair(self.plan.h, C.byref(d2), C.byref(d), 1 if dtype == torch.float16 else 0),
+                  'plan_add_conv_pw_pair ' + name)
+        self.plan.keep += [t1, res, w2, w3, w1, c2.b, c3.b, nxt.b]
+        k2 = c2.kh * c2.kw * c2.cin
+        self.log.append((name, m, c3.cout, c3.cin, 1, m * (c2.cout * k2 + c3.cout * c3.cin + nxt.cout * c3.cout)))
+        self.lp_bytes.append(2 * (n * h * h * c2.cin + m * (2 * c3.cout + nxt.cout) + c2.cout * k2 + c3.cout * c3.cin + nxt.cout * c3.cout))
+        return y, t, oh
+
     def bneck_first(self, name, c1, c2, c3, ds, nxt, x, n, h, dtype):
         """Layer1's first bottleneck + the next block's conv1 in ONE launch (csrc/bneck_lp.hip).  Returns (y [n,h,h,256],
         t [n,h,h,64]): the block's output and the next conv1's (both after ReLU)."""
@@ -975,9 +995,17 @@ class Builder:
             if t1 is None:
                 t1, _, _ = self.conv_bf16('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU, dtype=dtype)
                 yield
-            if (fuse and self.opt['conv_pw_lp'] and c2.stride == 1 and c3.kh == 1 and c2.out_hw(h, h) == (h, h)
+            nxp = W.blocks[bi + 1][0] if bi + 1 < nb else None
+            if (fuse and self.opt['conv_pw_pair_lp'] and t1 is not None and nxp is not None and nxp.kh == 1 and nxp.stride == 1
+                    and c3.kh == 1 and c2.cin == c2.cout and hip.lib().usot_conv_pw_pair_supported(c3.cin, c3.cout, nxp.cout)
+                    and rs * n * c2.out_hw(h, h)[0] ** 2 >= self.opt['panel_min_panels'] * 128):
+                # layer2: conv2 -> conv3 + residual + ReLU -> the next block's conv1 in one launch
+                cur, t1, h = self.conv_pw_pair('b%d.conv2+conv3+b%d.conv1' % (bi, bi + 1), c2, c3, nxp, t1, sc, n, h, ACT_RELU, dtype)
+                yield
+                continue
+            if (fuse and c2.cout in (self.opt['conv_pw_lp'] or ()) and c2.stride == 1 and c3.kh == 1 and c2.out_hw(h, h) == (h, h)
                     and hip.lib().usot_conv_pw_supported(c2.cin, c2.cout, c3.cout)
-                    and rs * n * h * h >= self.opt['panel_min_panels'] * 256):
+                    and rs * n * h * h >= self.opt['panel_min_panels'] * 128):
                 # conv2 -> conv3 + residual + ReLU in one launch (the T2 panel stays in LDS); the next 1x1 follows on its own
                 cur, h = self.conv_pw('b%d.conv2+conv3' % bi, c2, c3, t1, sc, n, h, dtype)
                 t1 = None
@@ -1228,8 +1256,11 @@ DEFAULT_OPTIONS = {
     # layer3 (from block lp_chains_from on) as lp_chains independent batch slices on parallel graph branches, chain i released
     # i * lp_chain_skew launches of chain 0 late (backbone_bf16); 0 = one chain
     # layer3's conv2 -> conv3 (+ residual + ReLU) of the batched low-precision backbone in ONE launch (csrc/conv_pw_lp.hip: a 256-pixel
-    # panel of conv2's output stays in LDS).  Bit-identical to the two launches; measured in the batch-64 bf16 step
-    'conv_pw_lp': False,
+    # panel of conv2's output stays in LDS).  Bit-identical to the two launches; measured in the batch-64 bf16 step.
+    # Value: the conv2 widths it is used for ((256,) = layer3; 128 = layer2's last block, whose next conv1 has no pair form)
+    'conv_pw_lp': (256,),
+    # layer2's bottleneck tails the same way, with the next block's conv1 riding along (pair form)
+    'conv_pw_pair_lp': True,
     'lp_chains': 0,
     'lp_chains_from': 7,
     'lp_chain_skew': 2,
