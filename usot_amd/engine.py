@@ -1258,7 +1258,7 @@ DEFAULT_OPTIONS = {
     # layer3's conv2 -> conv3 (+ residual + ReLU) of the batched low-precision backbone in ONE launch (csrc/conv_pw_lp.hip: a 256-pixel
     # panel of conv2's output stays in LDS).  Bit-identical to the two launches; measured in the batch-64 bf16 step.
     # Value: the conv2 widths it is used for ((256,) = layer3; 128 = layer2's last block, whose next conv1 has no pair form)
-    'conv_pw_lp': (256,),
+    'conv_pw_lp': (256, 128),
     # layer2's bottleneck tails the same way, with the next block's conv1 riding along (pair form)
     'conv_pw_pair_lp': True,
     'lp_chains': 0,
@@ -1373,6 +1373,8 @@ ENV_SWITCHES = {      # environment variable -> (option, parser)
     'USOT_STREAM_3X3_SHAPES': ('stream_3x3_shapes', _shapes),
     'USOT_FUSED_F32_SLICED': ('fused_f32_sliced', lambda v: v == '1'),
     'USOT_SPIN_SECONDS': ('spin_seconds', float),
+    'USOT_CONV_PW_LP': ('conv_pw_lp', lambda v: tuple(int(t) for t in v.split(',') if t)),      # '' = off, '256', '256,128'
+    'USOT_CONV_PW_PAIR_LP': ('conv_pw_pair_lp', lambda v: v == '1'),
 }
 
 
