@@ -355,6 +355,10 @@ def test_engine_options_are_enumerable_and_checked():
     opt = engine.options_from_env({'USOT_STREAM_1X1': '0', 'USOT_STREAM_3X3_SHAPES': '128x128,256x256', 'USOT_SPIN_SECONDS': '0.01'})
     assert opt['stream_1x1'] is False and opt['stream_3x3_shapes'] == {(128, 128), (256, 256)} and opt['spin_seconds'] == 0.01
     assert engine.options_from_env({}) == engine.DEFAULT_OPTIONS
+    # the fused conv2 -> conv3 (-> next conv1) kernels of the batched low-precision backbone: widths as a list, '' = off
+    opt = engine.options_from_env({'USOT_CONV_PW_LP': '', 'USOT_CONV_PW_PAIR_LP': '0'})
+    assert opt['conv_pw_lp'] == () and opt['conv_pw_pair_lp'] is False
+    assert engine.options_from_env({'USOT_CONV_PW_LP': '256,128'})['conv_pw_lp'] == (256, 128)
     with pytest.raises(hip.HipError):
         engine.merged_options({'no_such_switch': 1})
 
