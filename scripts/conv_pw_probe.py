@@ -43,9 +43,9 @@ def conv2_only(s):
     hip.check(L.usot_conv2d_lp(hip.stream(), C.byref(d2), dt, 0), 'conv2')
 
 
-def fused(s):
+def fused(s, tile=4):
     d = hip.conv_desc(s['t1'].data_ptr(), w2.data_ptr(), b2.data_ptr(), None, N=n, H=h, W=h, Cin=cin, OH=h, OW=h, Cout=cm,
-                      KH=3, KW=3, pad=(2, 2), dil=(2, 2), act=1)
+                      KH=3, KW=3, pad=(2, 2), dil=(2, 2), act=1, tile=tile)
     hip.check(L.usot_conv_pw_lp(hip.stream(), C.byref(d), hip.ptr(w3), hip.ptr(b3), hip.ptr(s['res']), hip.ptr(s['y']), dt), 'fused')
 
 
@@ -65,15 +65,16 @@ for s in sets:
 torch.cuda.synchronize()
 print('bit-identical:', all(torch.equal(s['y'], s['y2']) for s in sets))
 for rep in range(2):
-    print('M=%d  conv2 alone %.1f us | two launches %.1f us | fused %.1f us' % (M, timeit(conv2_only), timeit(two), timeit(fused)))
+    print('M=%d  conv2 alone %.1f us | two launches %.1f us | fused %.1f us | fused, row-shared k-loop %.1f us' % (M, timeit(conv2_only), timeit(two), timeit(fused), timeit(lambda s: fused(s, 0))))
 
 # whole step
-for widths, pair in (((), False), ((256,), False), ((256,), True), ((256, 128), True), ((), False), ((256,), True)):
+for widths, pair, rs in (((), False, False), ((256,), False, False), ((256, 128), True, False), ((256, 128), True, True), ((256, 128), True, False), ((256, 128), True, True)):
     m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to(DEV)
     m.pr_pool = False
     e = m.engine
     e.opt['conv_pw_lp'] = widths
     e.opt['conv_pw_pair_lp'] = pair
+    e.opt['conv_pw_rs'] = rs
     x = torch.from_numpy(synth.crop(1, n, 255)).to(DEV)
     for _ in range(3): out = e.features_bf16(x, dtype=dtype)
     p = next(v for k, v in e._feat.items() if k[0] == ('bf16' if a.lp == 'bf16' else 'f16'))
@@ -86,5 +87,5 @@ for widths, pair in (((), False), ((256,), False), ((256,), True), ((256, 128), 
         ts.append((time.perf_counter() - t0) / 100 * 1e6)
     prof = p['plan'].profile(10)
     fz = [ms * 1e3 for k, *_, ms in prof if k in (29, 30)]
-    print('conv_pw_lp=%s conv_pw_pair_lp=%s: step %.1f us (best of 5 x 100 replays: %.1f); fused launches: %s' % (widths, pair, sorted(ts)[2], min(ts), ['%.1f' % v for v in fz]))
+    print('conv_pw_lp=%s conv_pw_pair_lp=%s conv_pw_rs=%s: step %.1f us (best of 5 x 100 replays: %.1f); fused launches: %s' % (widths, pair, rs, sorted(ts)[2], min(ts), ['%.1f' % v for v in fz]))
     del m, e, p

@@ -41,6 +41,7 @@ struct CpK {
     uint16_t *y, *t;
     int H, W, OW, KW, stride, pad_h, pad_w, dil_h, dil_w;
     int M, P, KT, npanels, act2;
+    int rs;                        // phase 1 on the row-shared k-loop (3 x 3, stride 1, pad = dil <= 4)
 };
 
 __device__ __attribute__((aligned(16))) uint32_t cp_zero16[4] = {0u, 0u, 0u, 0u};     // source of padding taps (LDS-DMA)
@@ -70,8 +71,12 @@ struct CpCfg {
     static constexpr int WM = BM / (TM * 16);              // waves along the pixels (4 | 2); along the channels: 4
     static constexpr int RPP = NTHR / 8;                   // tile rows one staging pass covers
     static constexpr int XI = BM / RPP, WI = CM / RPP;     // DMA instructions per lane, k-tile and operand
-    static constexpr int STAGES = 2 * (BM + CM) * CP_LDC * 16, RING = 3 * SLAB * 16 + (CO + CN) * 4;
+    // row-shared form of phase 1 (below): an activation stage holds XROWS = BM + 2 x 4 halo rows and serves the three kw taps of a
+    // (kh, channel chunk) group; + one row of zeros for taps outside the image
+    static constexpr int XROWS = BM + 8, NBLK = XROWS / 8, PERK = (NBLK + 2) / 3;
+    static constexpr int STAGES = 2 * (XROWS + CM) * CP_LDC * 16 + 128, RING = 3 * SLAB * 16 + (CO + CN) * 4;
     static constexpr int LDS = STAGES > RING ? STAGES : RING;
+    static_assert(PERK <= NW, "a k-tile's share of the next activation stage: at most one DMA instruction per wave");
     static_assert(NW == 16 || NW == 8, "panels of 256 or 128 pixels");
     static_assert(CM == 256 || CM == 128, "layer3 / layer2 widths");
     static_assert(CN % 64 == 0 && WI >= 1 && CM % RPP == 0, "shape");
@@ -117,7 +122,7 @@ __device__ __forceinline__ void cp_barrier()
     asm volatile("" ::: "memory");
 }
 
-template <bool F16, int NW, int CM, int CN>
+template <bool F16, int NW, int CM, int CN, bool RS>
 __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
 {
     using Cf = CpCfg<NW, CM, CN>;
@@ -142,7 +147,119 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
 
     // ------------------------------------------------------------------ phase 1: conv2, BM pixels x CM channels
     f32x4 acc2[TN][TM];
-    {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wm = wave % WM, wn = wave / WM;
+    if constexpr (RS) {
+        // ---- ROW-SHARED k-loop (3 x 3, stride 1, "same" padding: pad = dil <= 4, OW = W).  In the flattened pixel index the
+        // tap (kh, kw) of output pixel m is the tap (kh, centre) of pixel m + (kw - 1) dil whenever that pixel is in the same
+        // image row - so ONE staged tile per (kh, channel chunk), BM + 8 rows (pixels bm0 - 4 ... bm0 + BM + 3 at their kh row),
+        // serves the three kw k-tiles: a lane reads its B fragments (kw - 1) dil rows up or down, or from a row of zeros when the
+        // tap leaves the image row.  43 instead of 64 LDS-DMA instructions per k-tile and CU at 256 x 256 (a k-tile's DMA issue is
+        // ~ 13 cycles per instruction next to its 2 048 MFMA cycles, csrc/conv_bf16.hip).  k order: (kh, chunk, kw).
+        constexpr int XROWS = Cf::XROWS, NBLK = Cf::NBLK, PERK = Cf::PERK, XST = XROWS * LDC;
+        const u32x4 *sW = cp_smem + 2 * XST;
+        const int zchunk = 2 * XST + 2 * CM * LDC;         // the row of zeros, in 16-byte chunks from cp_smem
+        if (tid < 8) cp_smem[zchunk + tid] = u32x4{0u, 0u, 0u, 0u};
+        // this lane's rows of an activation stage: block kw * PERK + wave (8 rows) in the k-tile kw of a group
+        // (32-bit element offsets: the launcher checks the map has fewer than 2^31 elements; a row that does not exist is marked
+        //  by an oh far outside the image so that every kh fails the range check)
+        uint32_t xs_off[3];
+        int xs_oh[3];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int row = (kw * PERK + wave) * 8 + (lane >> 3);
+            const int v = bm0 - 4 + row;
+            const bool ok = wave < PERK && kw * PERK + wave < NBLK && v >= 0 && v < p.M;
+            const int vv = ok ? v : 0;
+            const int n = vv / p.P, pix = vv - n * p.P;
+            const int oh = pix / p.OW, ow = pix - oh * p.OW;
+            xs_oh[kw] = ok ? oh - p.pad_h : -(1 << 20);
+            xs_off[kw] = (uint32_t)((n * p.H * p.W + ow) * CP_CIN + ((lane & 7) ^ cp_swz(row)) * 8);
+        }
+        auto issue_x = [&](auto kwc, int g, int stage) {
+            constexpr int kw = decltype(kwc)::value;
+            if (wave < PERK && kw * PERK + wave < NBLK) {             // wave-uniform
+                const int kh = g / CP_CCH, cc = g - kh * CP_CCH;
+                const int ih = xs_oh[kw] + kh * p.dil_h;
+                const bool ok = (unsigned)ih < (unsigned)p.H;
+                dma16u(ok ? p.x + (xs_off[kw] + (uint32_t)(ih * p.W * CP_CIN + cc * 64)) : p.zero,
+                       __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((stage * XST + (kw * PERK + wave) * 64) * 16)));
+            }
+        };
+        const int lr = tid >> 3;
+        const uint32_t K2 = (uint32_t)p.KT * 64u;
+        const uint32_t wbase = (uint32_t)lr * K2 + (uint32_t)(((tid & 7) ^ cp_swz(lr)) * 8);     // swz(lr + RPP i) = swz(lr)
+        const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((2 * XST + wave * 8 * LDC) * 16));
+        auto issue_w = [&](int g, int kw, int buf) {
+            const int kh = g / CP_CCH, cc = g - kh * CP_CCH;
+            const uint32_t koff = (uint32_t)(((kh * 3 + kw) * CP_CCH + cc) * 64);
+#pragma unroll
+            for (int i = 0; i < WI; ++i)
+                dma16u(p.w2 + (wbase + koff + (uint32_t)(RPP * i) * K2), ldsw + (uint32_t)((buf * CM + RPP * i) * LDC * 16));
+        };
+        // this lane's pixels (one per 16-pixel block of the wave): may the left / right tap be read (same image row)?  bit j: left
+        // tap of block j, bit 4 + j: right tap
+        uint32_t tapmask = 0;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int ow = (bm0 + wm * TM * 16 + j * 16 + l15) % p.OW;
+            tapmask |= (ow - p.dil_w >= 0 ? 1u : 0u) << j;
+            tapmask |= (ow + p.dil_w < p.W ? 1u : 0u) << (4 + j);
+        }
+        const int row0 = 4 + wm * TM * 16 + l15;
+        const int ng = 3 * CP_CCH;
+        using K0 = std::integral_constant<int, 0>;
+        using K1 = std::integral_constant<int, 1>;
+        using K2c = std::integral_constant<int, 2>;
+        issue_x(K0{}, 0, 0); issue_x(K1{}, 0, 0); issue_x(K2c{}, 0, 0);
+        issue_w(0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        auto ktile = [&](auto kwc, int g) {
+            constexpr int kw = decltype(kwc)::value;
+            const int t = g * 3 + kw;
+            // the next k-tile's filters, this k-tile's share of the next group's activation stage
+            if (kw < 2) issue_w(g, kw + 1, (t + 1) & 1);
+            else if (g + 1 < ng) issue_w(g + 1, 0, (t + 1) & 1);
+            if (g + 1 < ng) issue_x(kwc, g + 1, (g + 1) & 1);
+            int sh = (kw - 1) * p.dil_w;
+            asm volatile("" : "+s"(sh));                 // recomputed per k-tile: hoisted, the 12 (kw, block) fragment addresses of
+                                                           // both stages would live in registers across the loop (and spill)
+            int a0[TM];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int row = row0 + j * 16 + sh;
+                const bool in = kw == 1 || ((tapmask >> ((kw == 0 ? 0 : 4) + j)) & 1u);
+                a0[j] = in ? (g & 1) * XST + row * LDC + (quad ^ cp_swz(row)) : zchunk + quad;
+            }
+            const u32x4 *cW = sW + ((t & 1) * CM + wn * TN * 16 + l15) * LDC;
+            const int sq = cp_swz(l15);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 wf[TN], xf[TM];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) wf[i] = cW[i * 16 * LDC + ((ks * 4 + quad) ^ sq)];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) xf[j] = cp_smem[a0[j] ^ (ks * 4)];      // chunk (4 ks + quad) ^ swz = first ^ 4 ks
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc2[i][j] = cp_mfma<F16>(wf[i], xf[j], acc2[i][j]);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        for (int g = 0; g < ng; ++g) {
+            ktile(K0{}, g);
+            ktile(K1{}, g);
+            ktile(K2c{}, g);
+        }
+    } else {
         const int lr = tid >> 3;
         const int kc = (tid & 7) ^ cp_swz(lr);             // the swizzle sits on the SOURCE address (the DMA's LDS position is fixed)
         int x_ih0[XI], x_iw0[XI];
@@ -192,11 +309,6 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
                 set_tap(++cur_tap);
             }
         };
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int wm = wave % WM, wn = wave / WM;
         const u32x4 *sX = cp_smem, *sW = cp_smem + 2 * BM * LDC;
         const int sq = cp_swz(l15);                        // rows differ from l15 by multiples of 16
         const int nt = p.KT;
@@ -225,7 +337,8 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-
+    }
+    {
         // -------------------------------------------------------------- phase 2: T2 = relu(acc + b2) -> LDS, storage type
         // row r of the panel = CP_CPR chunks of 8 channels, chunk c at position c ^ (r & 15): a wave's fragment reads below
         // (16 rows x 4 consecutive chunks per instruction) then fall into 16 distinct 16-byte slots per lane group
@@ -424,20 +537,26 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
     else                   run(std::false_type{});
 }
 
-template <int NW, int CM, int CN>
-int cp_launch(hipStream_t s, const CpK &p, int dtype)
+template <int NW, int CM, int CN, bool RS>
+int cp_launch_rs(hipStream_t s, const CpK &p, int dtype)
 {
     using Cf = CpCfg<NW, CM, CN>;
     static bool raised[2] = {false, false};
-    const void *fn = dtype ? (const void *)conv_pw_kernel<true, NW, CM, CN> : (const void *)conv_pw_kernel<false, NW, CM, CN>;
+    const void *fn = dtype ? (const void *)conv_pw_kernel<true, NW, CM, CN, RS> : (const void *)conv_pw_kernel<false, NW, CM, CN, RS>;
     if (!raised[dtype]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) != hipSuccess) return USOT_ELAUNCH;
         raised[dtype] = true;
     }
-    if (dtype) hipLaunchKernelGGL((conv_pw_kernel<true, NW, CM, CN>), dim3(p.npanels), dim3(Cf::NTHR), Cf::LDS, s, p);
-    else       hipLaunchKernelGGL((conv_pw_kernel<false, NW, CM, CN>), dim3(p.npanels), dim3(Cf::NTHR), Cf::LDS, s, p);
+    if (dtype) hipLaunchKernelGGL((conv_pw_kernel<true, NW, CM, CN, RS>), dim3(p.npanels), dim3(Cf::NTHR), Cf::LDS, s, p);
+    else       hipLaunchKernelGGL((conv_pw_kernel<false, NW, CM, CN, RS>), dim3(p.npanels), dim3(Cf::NTHR), Cf::LDS, s, p);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
+}
+
+template <int NW, int CM, int CN>
+int cp_launch(hipStream_t s, const CpK &p, int dtype)
+{
+    return p.rs ? cp_launch_rs<NW, CM, CN, true>(s, p, dtype) : cp_launch_rs<NW, CM, CN, false>(s, p, dtype);
 }
 
 // conv2's descriptor -> kernel arguments (everything but the 1x1 banks); returns the panel size, 0 = invalid
@@ -459,8 +578,13 @@ int cp_fill(const usot_conv_desc *c2, int CM, CpK &p)
         zero_page = (const uint16_t *)zp;
     }
     // fewer than 192 panels of 256 pixels (batch 32 at layer2 / layer3 resolution: 121) would leave half the chip idle: panels of
-    // 128 pixels then (8 wavefronts; c2->tile = 1 / 2 forces the 256- / 128-pixel form: tests)
-    const bool small = c2->tile == 2 || (c2->tile != 1 && (M + 255) / 256 < 192);
+    // 128 pixels then (8 wavefronts; c2->tile & 3 = 1 / 2 forces the 256- / 128-pixel form: tests)
+    const int force = c2->tile & 3;
+    const bool small = force == 2 || (force != 1 && (M + 255) / 256 < 192);
+    // the row-shared k-loop of phase 1 where the geometry allows it (c2->tile & 4: the per-tap loop anyway: tests, A/B)
+    p.rs = !(c2->tile & 4) && c2->KH == 3 && c2->KW == 3 && c2->stride == 1 && c2->pad_h == c2->dil_h && c2->pad_w == c2->dil_w &&
+           c2->dil_w >= 1 && c2->dil_w <= 4 && ow == c2->W && oh == c2->H &&
+           (long)c2->N * c2->H * c2->W * CM < 0x7fffffffL;      // 32-bit element offsets in that loop
     const int bm = small ? 128 : 256;
     p.x = (const uint16_t *)c2->x; p.w2 = (const uint16_t *)c2->w; p.zero = zero_page; p.b2 = c2->bias;
     p.H = c2->H; p.W = c2->W; p.OW = ow; p.KW = c2->KW; p.stride = c2->stride; p.pad_h = c2->pad_h; p.pad_w = c2->pad_w;
