@@ -209,7 +209,9 @@ int usot_conv_pw_pixels(int64_t M);
 /* ... and the pair form: the NEXT block's conv1 rides along as in usot_pw_panel_pair_lp, T[M][CN] = act2(Y . w1^T + b1) - a whole
  * bottleneck tail (conv2 -> conv3 + residual + ReLU -> next conv1) per launch.  d as for usot_pw_panel_pair_lp (w3p = w3 [CO][CM],
  * w1 [CN][CO], natural layouts; M = conv2's output pixels) except that d->t2 is ignored.  Bit-identical to usot_conv2d_lp followed
- * by usot_pw_panel_pair_lp.  Shapes: usot_conv_pw_pair_supported(CM, CO, CN): (128, 512, 128), layer2. */
+ * by usot_pw_panel_pair_lp.  Shapes: usot_conv_pw_pair_supported(CM, CO, CN): (128, 512, 128), layer2 - and (256, 1024, 256), layer3,
+ * where the second convolution runs as a FIFTH phase instead (no registers for the pair form): the workgroup reads its own Y panel
+ * back (L2 / Infinity Cache) and computes T as a 16-k-tile implicit GEMM on the freed LDS - T bit-identical to usot_conv2d_lp on Y. */
 int usot_conv_pw_pair_lp(void *stream, const usot_conv_desc *c2, const usot_pw_pair_desc *d, int dtype);
 int usot_conv_pw_pair_supported(int CM, int CO, int CN);
 int usot_plan_add_conv_pw_pair(void *plan, const usot_conv_desc *c2, const usot_pw_pair_desc *d, int dtype);

@@ -68,13 +68,14 @@ for rep in range(2):
     print('M=%d  conv2 alone %.1f us | two launches %.1f us | fused %.1f us | fused, row-shared k-loop %.1f us' % (M, timeit(conv2_only), timeit(two), timeit(fused), timeit(lambda s: fused(s, 0))))
 
 # whole step
-for widths, pair, rs in (((), False, False), ((256,), False, False), ((256, 128), True, False), ((256, 128), True, True), ((256, 128), True, False), ((256, 128), True, True)):
+for widths, pair, rs, p5 in (((), False, False, False), ((256, 128), True, False, False), ((256, 128), True, True, False), ((256, 128), True, True, True), ((256, 128), True, True, False), ((256, 128), True, True, True), ((256, 128), True, False, True)):
     m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to(DEV)
     m.pr_pool = False
     e = m.engine
     e.opt['conv_pw_lp'] = widths
     e.opt['conv_pw_pair_lp'] = pair
     e.opt['conv_pw_rs'] = rs
+    e.opt['conv_pw_p5_lp'] = p5
     x = torch.from_numpy(synth.crop(1, n, 255)).to(DEV)
     for _ in range(3): out = e.features_bf16(x, dtype=dtype)
     p = next(v for k, v in e._feat.items() if k[0] == ('bf16' if a.lp == 'bf16' else 'f16'))
@@ -87,5 +88,5 @@ for widths, pair, rs in (((), False, False), ((256,), False, False), ((256, 128)
         ts.append((time.perf_counter() - t0) / 100 * 1e6)
     prof = p['plan'].profile(10)
     fz = [ms * 1e3 for k, *_, ms in prof if k in (29, 30)]
-    print('conv_pw_lp=%s conv_pw_pair_lp=%s conv_pw_rs=%s: step %.1f us (best of 5 x 100 replays: %.1f); fused launches: %s' % (widths, pair, rs, sorted(ts)[2], min(ts), ['%.1f' % v for v in fz]))
+    print('conv_pw_lp=%s conv_pw_pair_lp=%s conv_pw_rs=%s conv_pw_p5_lp=%s: step %.1f us (best of 5 x 100 replays: %.1f); fused launches: %s' % (widths, pair, rs, p5, sorted(ts)[2], min(ts), ['%.1f' % v for v in fz]))
     del m, e, p

@@ -1327,6 +1327,52 @@ def test_conv_pw_layer2_forms_equal_the_unfused_launches(n, h, stride, pad, cn, 
     assert (torch.equal(y[:M], y2) if exact else close(y[:M], y2)) and torch.all(y[M:] == 5.0)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('rs', [False, True], ids=['pertap', 'rowshared'])
+@pytest.mark.parametrize('form', [1, 2], ids=['panel256', 'panel128'])
+@pytest.mark.parametrize('n,h,pad,act2', [(2, 31, 2, 1), (1, 13, 1, 0), (1, 16, 1, 1)])
+def test_conv_pw_layer3_with_the_next_conv1_as_fifth_phase(n, h, pad, act2, dtype, form, rs):
+    """Layer3's fused block with the next block's conv1 (or the neck: act2 = 0) as phase 5 of the launch (csrc/conv_pw_lp.hip: the
+    workgroup reads its own Y panel back and runs the 1024 -> 256 convolution on the freed LDS): Y as the four-phase kernel's, T
+    bit-identical to the tiled convolution on that Y (same k order) - also on the ragged last panel and with waves without pixels."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(n * 100 + h + act2)
+    cm, co, cn = 256, 1024, 256
+    M = n * h * h
+    t1 = torch.randn(n, h, h, cm, generator=g).relu().to(dtype)
+    w2 = (torch.randn(cm, 9 * cm, generator=g) / (9 * cm) ** 0.5).to(dtype)
+    w3 = (torch.randn(co, cm, generator=g) / cm ** 0.5).to(dtype)
+    w1 = (torch.randn(cn, co, generator=g) / co ** 0.5).to(dtype)
+    b2, b3, b1 = torch.randn(cm, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1, torch.randn(cn, generator=g) * 0.1
+    res = torch.randn(M, co, generator=g).to(dtype)
+    dt = 1 if dtype == torch.float16 else 0
+    t1d, w2d, w3d, w1d, b2d, b3d, b1d, resd = (a.to(DEV) for a in (t1, w2, w3, w1, b2, b3, b1, res))
+    geo = dict(N=n, H=h, W=h, Cin=cm, OH=h, OW=h, Cout=cm, KH=3, KW=3, pad=(pad, pad), dil=(pad, pad), act=1)
+    tile = form | (0 if rs else 4)
+    y = torch.full((M + 2, co), 5.0, dtype=dtype, device=DEV)
+    t = torch.full((M + 2, cn), 5.0, dtype=dtype, device=DEV)
+    d = hip.conv_desc(t1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), None, tile=tile, **geo)
+    assert hip.lib().usot_conv_pw_pair_supported(cm, co, cn) == 1
+    pd = hip.pw_pair_desc(None, w3d.data_ptr(), b3d.data_ptr(), resd.data_ptr(), y.data_ptr(), w1d.data_ptr(), b1d.data_ptr(),
+                          t.data_ptr(), M, cm, co, cn, act2)
+    hip.check(hip.lib().usot_conv_pw_pair_lp(hip.stream(), C.byref(d), C.byref(pd), dt), 'usot_conv_pw_pair_lp')
+    # the four-phase kernel with the same k-loop, then the tiled conv1 on ITS Y
+    y2 = torch.empty(M, co, dtype=dtype, device=DEV)
+    hip.check(hip.lib().usot_conv_pw_lp(hip.stream(), C.byref(d), hip.ptr(w3d), hip.ptr(b3d), hip.ptr(resd), hip.ptr(y2), dt), 'usot_conv_pw_lp')
+    tt = torch.empty(M, cn, dtype=dtype, device=DEV)
+    d1 = hip.conv_desc(y2.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), tt.data_ptr(), N=1, H=M, W=1, Cin=co, OH=M, OW=1, Cout=cn, KH=1, KW=1,
+                       act=act2, tile=32)
+    hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d1), dt, 0), 'conv1')
+    torch.cuda.synchronize()
+    assert torch.equal(y[:M], y2) and torch.all(y[M:] == 5.0)
+    assert torch.equal(t[:M], tt) and torch.all(t[M:] == 5.0)
+    ref = y2.double() @ w1d.double().t() + b1d.double()
+    if act2:
+        ref = ref.relu()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert float(((t[:M].double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= ulp * 1.01
+
+
 def test_backbone_bf16_conv_pw_option_is_bit_identical():
     """Engine options 'conv_pw_lp' / 'conv_pw_pair_lp' (layer3's conv2 -> conv3 and layer2's conv2 -> conv3 -> next conv1 fused per
     pixel panel): the batched bf16 backbone's output is bit-identical to the unfused lowering's with the per-tap k-loop, and within
@@ -1337,13 +1383,13 @@ def test_backbone_bf16_conv_pw_option_is_bit_identical():
     for on in (False, True, 'rs'):
         m = USOT(); m.load_state_dict(synth.torch_state_dict(m)); m.eval(); m = m.to(DEV)
         m.engine.opt['conv_pw_lp'] = (256,) if on else ()
-        m.engine.opt['conv_pw_pair_lp'] = bool(on)
+        m.engine.opt['conv_pw_pair_lp'] = m.engine.opt['conv_pw_p5_lp'] = bool(on)
         m.engine.opt['conv_pw_rs'] = on == 'rs'
         x = torch.from_numpy(synth.crop(3, 52, 255)).to(DEV)
         xf = m.engine.features_bf16(x)
         torch.cuda.synchronize()
         kinds = [k for k, *_ in next(v for kk, v in m.engine._feat.items() if kk[0] == 'bf16')['plan'].profile(1)]
-        assert (29 in kinds) == bool(on) and (30 in kinds) == bool(on)
+        assert (30 in kinds) == bool(on)
         outs.append(xf.clone())
         del m
     assert torch.equal(outs[0], outs[1])

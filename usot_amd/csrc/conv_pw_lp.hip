@@ -62,11 +62,16 @@ struct CpCfg {
     static constexpr int CCH = CIN / 64;                   // channel chunks per tap
     static constexpr int CPR = CM / 8;                     // 16-byte chunks per T2 row / per w3 slab row
     static constexpr int SLAB0 = 64 * CPR;                 // chunks of a w3 slab (64 channels x CM k)
-    static constexpr int SLAB1 = CN * 8;                   // ... of w1's slab (CN channels x this group's 64 k)
+    // layer3's next conv1 (1024 -> 256) has no register pair form (64 more accumulators than a 16-wave workgroup has): CM = 256 with
+    // CN > 0 is the PHASE-5 form instead - after conv3 the workgroup reads its own Y panel back (L2 / Infinity Cache: it has just
+    // written it) and runs conv1 as a 16-k-tile implicit GEMM on the freed LDS
+    static constexpr bool P5 = CM == 256 && CN > 0;
+    static constexpr int CNR = P5 ? 0 : CN;                // width of the pair form's second GEMM
+    static constexpr int SLAB1 = CNR * 8;                  // ... of w1's slab (CN channels x this group's 64 k)
     static constexpr int SLAB = SLAB0 + SLAB1;
     static constexpr int G = CO / 64;                      // channel groups of conv3
     static constexpr int KS = CM / 32;                     // MFMA k-steps of conv3
-    static constexpr int NB1 = CN / 16;                    // 16-channel blocks of T
+    static constexpr int NB1 = CNR / 16;                   // 16-channel blocks of T (pair form)
     static constexpr int TM = 4, TN = CM / 64;             // a wave = 64 pixels x CM / 4 channels of conv2
     static constexpr int WM = BM / (TM * 16);              // waves along the pixels (4 | 2); along the channels: 4
     static constexpr int RPP = NTHR / 8;                   // tile rows one staging pass covers
@@ -75,11 +80,12 @@ struct CpCfg {
     // (kh, channel chunk) group; + one row of zeros for taps outside the image
     static constexpr int XROWS = BM + 8, NBLK = XROWS / 8, PERK = (NBLK + 2) / 3;
     static constexpr int STAGES = 2 * (XROWS + CM) * CP_LDC * 16 + 128, RING = 3 * SLAB * 16 + (CO + CN) * 4;
-    static constexpr int LDS = STAGES > RING ? STAGES : RING;
+    static constexpr int STAGES5 = P5 ? (3 * BM + 2 * CN) * CP_LDC * 16 : 0;       // phase 5: three Y stages + two filter stages
+    static constexpr int LDS = STAGES5 > (STAGES > RING ? STAGES : RING) ? STAGES5 : (STAGES > RING ? STAGES : RING);
     static_assert(PERK <= NW, "a k-tile's share of the next activation stage: at most one DMA instruction per wave");
     static_assert(NW == 16 || NW == 8, "panels of 256 or 128 pixels");
     static_assert(CM == 256 || CM == 128, "layer3 / layer2 widths");
-    static_assert(CN % 64 == 0 && WI >= 1 && CM % RPP == 0, "shape");
+    static_assert(CN % 64 == 0 && WI >= 1 && CM % RPP == 0 && (!P5 || CN == CM), "shape");
     static_assert(STAGES >= BM * CPR * 16, "the T2 panel fits conv2's stages");
     static_assert(SLAB0 % NTHR == 0 && SLAB1 % NTHR == 0, "whole DMA instructions per slab");
     static_assert(LDS <= 160 * 1024, "LDS");
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
     // ------------------------------------------------------------------ phase 4: conv3 over the panel (csrc/pw_panel.hip, PB = 1)
     float *sBias = (float *)(cp_smem + 3 * CP_SLAB);
     for (int i = tid; i < CP_CO; i += NTHR) sBias[i] = p.b3[i];
-    if constexpr (CN > 0)
+    if constexpr (NB1 > 0)
         for (int i = tid; i < CN; i += NTHR) sBias[CP_CO + i] = p.b1[i];
     // slab of group g -> ring slot: physical chunk c = i * NTHR + tid holds logical chunk pc ^ (row & 15) of slab row `row`,
     // row = MFMA row rho of 16-channel block blk = channel g * 64 + (blk >> 1) * 32 + (rho >> 2) * 8 + (blk & 1) * 4 + (rho & 3)
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
             const int ch = g * 64 + (blk >> 1) * 32 + (rho >> 2) * 8 + (blk & 1) * 4 + (rho & 3);
             dma16u(p.w3 + (long)ch * CM + lc * 8, __builtin_amdgcn_readfirstlane(base + (uint32_t)(i * NTHR * 16)));
         }
-        if constexpr (CN > 0) {
+        if constexpr (NB1 > 0) {
             // w1's k-slice of the group: row = T channel (blk >> 2) * 64 + ((blk >> 1) & 1) * 32 + (rho >> 2) * 8 + (blk & 1) * 4 + (rho & 3)
             // (blk = 16-channel block of T), 8 chunks of 8 k, chunk pc holds logical chunk pc ^ ((row >> 1) & 7)
 #pragma unroll
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
                 *(u32x4 *)(p.y + pm * CP_CO + c0 + 32) = yf[1];
             }
             // ---- second GEMM, this group's 64 k: the lane's rounded outputs are its B fragments (k-step s = run s)
-            if constexpr (CN > 0) {
+            if constexpr (NB1 > 0) {
                 const u32x4 *slab1 = cp_smem + (g % 3) * CP_SLAB + Cf::SLAB0;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
         for (int k = 0; k < CP_G; ++k) interval(k);
         if constexpr (trail) epilogue(CP_G - 1);
         // ---- epilogue of the second GEMM: acct[n][r] = T channel (n >> 2) * 64 + ((n >> 1) & 1) * 32 + q * 8 + (n & 1) * 4 + r
-        if constexpr (CN > 0) {
+        if constexpr (NB1 > 0) {
 #pragma unroll
             for (int nb = 0; nb < NB1 / 4; ++nb) {
                 const int t0 = nb * 64 + q * 8;
@@ -535,6 +541,113 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
     // a workgroup's waves are dealt round-robin to the four SIMDs: every SIMD hosts as many leaders as trailers
     if (wave >= NW / 2) run(std::true_type{});
     else                   run(std::false_type{});
+
+    // ------------------------------------------------------------------ phase 5 (CM = 256, CN = 256): the NEXT block's conv1 on this panel
+    // T[BM][CN] = act2(Y . w1^T + b1), K = 4 CM.  The panel's Y rows were stored by this workgroup's own waves a moment ago: after
+    // vmcnt(0) + a barrier they are in L2 (write-through L1; no line of Y was ever loaded by this CU), the k-loop streams them back
+    // by LDS-DMA - the standalone conv1 launch (a cold single-round kernel: 42 us for 157 MB) and its read of Y from HBM disappear.
+    // Same k order as the tiled kernels: bit-identical to usot_conv2d_lp on Y.
+    if constexpr (Cf::P5) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x4 acc5[TN][TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc5[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int lr = tid >> 3;
+        const int kc = (tid & 7) ^ cp_swz(lr);
+        const uint16_t *yp[XI];
+        bool yok[XI];
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const long m = (long)bm0 + lr + RPP * i;
+            yok[i] = m < (long)p.M;
+            yp[i] = p.y + (yok[i] ? m : 0) * CP_CO + kc * 8;
+        }
+        const uint16_t *w1p[WI];
+#pragma unroll
+        for (int i = 0; i < WI; ++i) w1p[i] = p.w1 + (long)(lr + RPP * i) * CP_CO + kc * 8;
+        // THREE activation stages, two filter stages (all of the LDS, as tile 36 of csrc/conv_bf16.hip): Y comes back from the
+        // Infinity Cache / HBM (an XCD's 32 panels = 16 MB have long left its 4 MB L2), so its DMA runs two k-tiles ahead with a
+        // counted vmcnt; the filters are L2-resident and run one ahead.  (Two stages + vmcnt(0) per k-tile: 2.5 us per k-tile.)
+        const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(wave * 8 * LDC * 16));
+        auto issue_x5 = [&](int t, int slot) {
+            const uint32_t bx = ldsw + (uint32_t)(slot * BM * LDC * 16);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) dma16u(yok[i] ? yp[i] + t * 64 : p.zero, bx + (uint32_t)(RPP * i * LDC * 16));
+        };
+        auto issue_w5 = [&](int t, int buf) {
+            const uint32_t bw = ldsw + (uint32_t)((3 * BM + buf * CN) * LDC * 16);
+#pragma unroll
+            for (int i = 0; i < WI; ++i) dma16u(w1p[i] + t * 64, bw + (uint32_t)(RPP * i * LDC * 16));
+        };
+        const u32x4 *sX = cp_smem, *sW = cp_smem + 3 * BM * LDC;
+        const int sq = cp_swz(l15);
+        constexpr int NT5 = CP_CO / 64;
+        static_assert(NT5 >= 3, "three-stage loop");
+        issue_x5(0, 0);
+        issue_w5(0, 0);
+        issue_x5(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(XI) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int xs = 0;
+        for (int t = 0; t < NT5; ++t) {
+            const int xs2 = xs == 0 ? 2 : xs - 1;           // (t + 2) % 3
+            // issue order: W(t + 1), then X(t + 2) - the wait below leaves only X(t + 2) outstanding (in-order retirement)
+            if (t + 1 < NT5) issue_w5(t + 1, (t & 1) ^ 1);
+            if (t + 2 < NT5) issue_x5(t + 2, xs2);
+            const u32x4 *cX = sX + (xs * BM + wm * TM * 16 + l15) * LDC;
+            const u32x4 *cW = sW + ((t & 1) * CN + wn * TN * 16 + l15) * LDC;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 wf[TN], xq[TM];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) wf[i] = cW[i * 16 * LDC + ((ks * 4 + quad) ^ sq)];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) xq[j] = cX[j * 16 * LDC + ((ks * 4 + quad) ^ sq)];
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc5[i][j] = cp_mfma<F16>(wf[i], xq[j], acc5[i][j]);
+            }
+            if (t + 2 < NT5) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(XI) : "memory");
+            else             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            xs = xs == 2 ? 0 : xs + 1;
+        }
+        // T tile -> LDS in the storage type (rows of CN / 8 chunks, chunk c of row r at c ^ (r & 15)), then out in whole rows
+        char *sT = (char *)cp_smem;
+        constexpr int TCPR = CN / 8;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int ch = wn * TN * 16 + i * 16 + quad * 4;
+            const f32x4 b = *(const f32x4 *)(p.b1 + ch);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int row = wm * TM * 16 + j * 16 + l15;
+                f32x4 v = acc5[i][j] + b;
+                if (p.act2 == USOT_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                }
+                u32x2 o;
+                o[0] = usot_pack2_lp<F16>(v[0], v[1]);
+                o[1] = usot_pack2_lp<F16>(v[2], v[3]);
+                *(u32x2 *)(sT + ((row * TCPR + ((ch >> 3) ^ (row & 15))) * 16 + ((ch >> 2) & 1) * 8)) = o;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < BM * TCPR / NTHR; ++it) {
+            const int idx = it * NTHR + tid;
+            const int row = idx / TCPR, pc = idx % TCPR;
+            const long m = (long)bm0 + row;
+            if (m < (long)p.M) *(u32x4 *)(p.t + m * CN + (pc ^ (row & 15)) * 8) = cp_smem[idx];
+        }
+    }
 }
 
 template <int NW, int CM, int CN, bool RS>
@@ -602,7 +715,7 @@ extern "C" int usot_conv_pw_supported(int Cin, int CM, int CO)
 
 extern "C" int usot_conv_pw_pair_supported(int CM, int CO, int CN)
 {
-    return CM == 128 && CO == 512 && CN == 128;
+    return (CM == 128 && CO == 512 && CN == 128) || (CM == 256 && CO == 1024 && CN == 256);
 }
 
 /* pixels per panel (= per workgroup) the launcher would use for M pixels */
@@ -645,5 +758,6 @@ extern "C" int usot_conv_pw_pair_lp(void *stream, const usot_conv_desc *c2, cons
     p.w3 = (const uint16_t *)d->w3p; p.res = (const uint16_t *)d->res; p.b3 = d->b3; p.y = (uint16_t *)d->y;
     p.w1 = (const uint16_t *)d->w1; p.b1 = d->b1; p.t = (uint16_t *)d->t; p.act2 = d->act2;
     hipStream_t s = (hipStream_t)stream;
+    if (d->CM == 256) return bm == 128 ? cp_launch<8, 256, 256>(s, p, dtype) : cp_launch<16, 256, 256>(s, p, dtype);
     return bm == 128 ? cp_launch<8, 128, 128>(s, p, dtype) : cp_launch<16, 128, 128>(s, p, dtype);
 }

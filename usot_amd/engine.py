@@ -997,12 +997,15 @@ class Builder:
             if t1 is None:
                 t1, _, _ = self.conv_bf16('b%d.conv1' % bi, c1, cur, n, h, h, act=ACT_RELU, dtype=dtype)
                 yield
-            nxp = W.blocks[bi + 1][0] if bi + 1 < nb else None
-            if (fuse and self.opt['conv_pw_pair_lp'] and t1 is not None and nxp is not None and nxp.kh == 1 and nxp.stride == 1
+            lastb = bi + 1 == nb
+            nxp = (W.neck if not neck_f32 else None) if lastb else W.blocks[bi + 1][0]
+            if (fuse and t1 is not None and nxp is not None and nxp.kh == 1 and nxp.stride == 1
                     and c3.kh == 1 and c2.cin == c2.cout and hip.lib().usot_conv_pw_pair_supported(c3.cin, c3.cout, nxp.cout)
+                    and self.opt['conv_pw_pair_lp' if c3.cin == 128 else 'conv_pw_p5_lp']
                     and rs * n * c2.out_hw(h, h)[0] ** 2 >= self.opt['panel_min_panels'] * 128):
-                # layer2: conv2 -> conv3 + residual + ReLU -> the next block's conv1 in one launch
-                cur, t1, h = self.conv_pw_pair('b%d.conv2+conv3+b%d.conv1' % (bi, bi + 1), c2, c3, nxp, t1, sc, n, h, ACT_RELU, dtype)
+                # conv2 -> conv3 + residual + ReLU -> the next block's conv1 (or the neck) in one launch
+                cur, t1, h = self.conv_pw_pair('b%d.conv2+conv3+%s' % (bi, 'neck' if lastb else 'b%d.conv1' % (bi + 1)), c2, c3, nxp,
+                                               t1, sc, n, h, ACT_NONE if lastb else ACT_RELU, dtype)
                 yield
                 continue
             if (fuse and c2.cout in (self.opt['conv_pw_lp'] or ()) and c2.stride == 1 and c3.kh == 1 and c2.out_hw(h, h) == (h, h)
@@ -1263,6 +1266,9 @@ DEFAULT_OPTIONS = {
     'conv_pw_lp': (256, 128),
     # layer2's bottleneck tails the same way, with the next block's conv1 riding along (pair form)
     'conv_pw_pair_lp': True,
+    # layer3's blocks likewise, the next block's conv1 (or the neck) as a FIFTH phase of the launch: the workgroup reads its own Y
+    # panel back (csrc/conv_pw_lp.hip) - the standalone 1024 -> 256 launch disappears
+    'conv_pw_p5_lp': True,
     # phase 1 of those kernels on the ROW-SHARED k-loop where the geometry allows it (3 x 3, stride 1, pad = dil: one staged activation
     # tile per (kh, channel chunk) serves the three kw taps - a third fewer LDS-DMA instructions per k-tile; k order (kh, chunk, kw), so
     # results differ from the per-tap loop's by fp32 summation order).  False: the per-tap loop, bit-identical to the unfused launches
@@ -1382,6 +1388,7 @@ ENV_SWITCHES = {      # environment variable -> (option, parser)
     'USOT_CONV_PW_LP': ('conv_pw_lp', lambda v: tuple(int(t) for t in v.split(',') if t)),      # '' = off, '256', '256,128'
     'USOT_CONV_PW_PAIR_LP': ('conv_pw_pair_lp', lambda v: v == '1'),
     'USOT_CONV_PW_RS': ('conv_pw_rs', lambda v: v == '1'),
+    'USOT_CONV_PW_P5_LP': ('conv_pw_p5_lp', lambda v: v == '1'),
 }
 
 
