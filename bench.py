@@ -461,9 +461,13 @@ def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, 
                      'traffic': traffic, 'traffic_source': tsrc,
                      'algorithmic_bytes_per_step': int(alg_bytes),
                      'traffic_to_algorithmic': round(traffic / alg_bytes, 3) if traffic else None,
+                     # the fused layer3 blocks read their own Y panel back for the next conv1 (phase 5 of csrc/conv_pw_lp.hip): real
+                     # HBM / Infinity-Cache traffic that the unfused decomposition counted as conv1's algorithmic input
+                     'fused_readback_bytes_per_step': int(sum(p.get('lp_readback', []))),
+                     'traffic_to_algorithmic_plus_readback': round(traffic / (alg_bytes + sum(p.get('lp_readback', []))), 3) if traffic else None,
                      'hbm_gbs_at_algorithmic_bytes': round(alg_bytes / (dt / n) / 1e9, 1),
                      'traffic_per_launch_top_kernels': by_kernel,
-                     'kernel': 'conv_igemm_bf16 / pw_panel family (all %d conv launches)' % len(rows),
+                     'kernel': 'conv_igemm_bf16 / conv_pw / bneck family (all %d conv launches; a fused bottleneck launch counts once)' % len(rows),
                      'algorithmic_gflop_per_step': round(fl_conv / 1e9, 1), 'conv_ms_per_step': round(ms_conv, 3),
                      'all_ops_ms_per_step': round(ms_all, 3),
                      'end_to_end_tflops': round(batch * (BACKBONE_GFLOP + 0.504) * n / dt / 1e3, 1),

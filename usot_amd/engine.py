@@ -267,6 +267,7 @@ class Builder:
         self.default_batch_tile = 15      # v2 32x64 BK64 when the lead shape has no tuned entry
         self.log = []           # (name, M, N, K, groups, macs) per conv, for benchmarks
         self.lp_bytes = []      # algorithmic HBM bytes of every low-precision conv launch (operands + result, once each)
+        self.lp_readback = []   # bytes a fused launch reads back of its OWN output (phase 5 of csrc/conv_pw_lp.hip): not algorithmic
         self.f32_bytes = []     # the same for every fp32 entry of `log` (parallel list): bench.py's roofline.algorithmic_bytes_per_launch
         self.geoms = []         # full geometry per conv, for the tuner
 
@@ -709,6 +710,8 @@ class Builder:
         k2 = c2.kh * c2.kw * c2.cin
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c2.cout * k2 + c3.cout * c3.cin + nxt.cout * c3.cout)))
         self.lp_bytes.append(2 * (n * h * h * c2.cin + m * (2 * c3.cout + nxt.cout) + c2.cout * k2 + c3.cout * c3.cin + nxt.cout * c3.cout))
+        if c3.cin == 256:                               # phase-5 form: the Y panel is read back for the second convolution
+            self.lp_readback.append(2 * m * c3.cout)
         return y, t, oh
 
     def bneck_first(self, name, c1, c2, c3, ds, nxt, x, n, h, dtype):
@@ -1492,7 +1495,7 @@ class Engine:
             xin = bld.buf(n, 3, s, s)
             xf, h = bld.backbone_bf16(xin, n, s, dtype=dtype, raw_pixels=raw)
             self._finish(bld.plan)
-            self._feat[key] = dict(x=xin, xf=xf, h=h, plan=bld.plan, log=bld.log, p3=bld.p3, lp_bytes=bld.lp_bytes)
+            self._feat[key] = dict(x=xin, xf=xf, h=h, plan=bld.plan, log=bld.log, p3=bld.p3, lp_bytes=bld.lp_bytes, lp_readback=bld.lp_readback)
         p = self._feat[key]
         p['x'].copy_(x)
         p['plan'].run()
@@ -1613,7 +1616,7 @@ class Engine:
                 bbox, cls2, S = bld.heads(xf, b, hf, self._zenc[b]['zk'], mem, m)
             self._finish(bld.plan)
             self._track[key] = dict(x=xin, xf=xf, hf=hf, mem=mem, bbox=bbox, cls2=cls2, S=S, plan=bld.plan, log=bld.log,
-                                    lp_bytes=bld.lp_bytes, f32_bytes=bld.f32_bytes)
+                                    lp_bytes=bld.lp_bytes, f32_bytes=bld.f32_bytes, lp_readback=bld.lp_readback)
         p = self._track[key]
         p['x'].copy_(x)
         p['mem'].copy_(hip.to_nhwc(_as_dev_f32(template_mem, self.device)))
