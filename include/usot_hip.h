@@ -199,7 +199,8 @@ int usot_plan_add_pw_panel_pair(void *plan, const usot_pw_pair_desc *d, int dtyp
  * a panel of conv2's output stays in LDS and is consumed there), w3 [4 CM][CM], b3 fp32, res / y dense; storage type dtype 0 =
  * bf16, 1 = fp16.  Bit-identical to usot_conv2d_lp followed by usot_pw_panel_lp.  Shapes: usot_conv_pw_supported(Cin, CM, CO):
  * (256, 256, 1024) layer3, (128, 128, 512) layer2.  A workgroup owns a panel of usot_conv_pw_pixels(M) pixels: 256 (16
- * wavefronts), or 128 (8 wavefronts) when M gives fewer than 192 panels of 256; c2->tile & 3 = 1 / 2 forces the 256 / 128 form.
+ * wavefronts), or 128 (8 wavefronts) when M gives fewer than 192 panels of 256 or a mostly empty second round of them (CUs < panels
+ * < 1.5 CUs); c2->tile & 3 = 1 / 2 forces the 256 / 128 form.
  * 3 x 3 / stride 1 / pad = dil <= 4 convolutions run their k-loop ROW-SHARED (one staged activation tile per (kh, channel chunk)
  * serves the three kw taps; k order (kh, chunk, kw): same products, another fp32 summation order); c2->tile & 4 keeps the per-tap
  * loop, whose result is bit-identical to the unfused launches. */

@@ -1238,6 +1238,8 @@ def test_conv_pw_fused_equals_the_two_launches(n, h, pad, dil, dtype, form, rs):
     d = hip.conv_desc(t1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), None, N=n, H=h, W=h, Cin=cin, OH=h, OW=h, Cout=cm, KH=3, KW=3,
                       pad=(pad, pad), dil=(dil, dil), act=1, tile=form | (0 if rs else 4))
     assert hip.lib().usot_conv_pw_pixels(M) == 128 and hip.lib().usot_conv_pw_pixels(192 * 256) == 256
+    cus = torch.cuda.get_device_properties(0).multi_processor_count          # a mostly empty second round of 256-pixel panels: 128
+    assert hip.lib().usot_conv_pw_pixels((cus + 17) * 256) == 128 and hip.lib().usot_conv_pw_pixels(2 * cus * 256) == 256
     hip.check(hip.lib().usot_conv_pw_lp(hip.stream(), C.byref(d), hip.ptr(w3d), hip.ptr(b3d), hip.ptr(resd), hip.ptr(y), dt), 'usot_conv_pw_lp')
     torch.cuda.synchronize()
     assert torch.all(y[M:] == 5.0)                                   # nothing written past the last pixel
@@ -1306,7 +1308,7 @@ def test_conv_pw_layer2_forms_equal_the_unfused_launches(n, h, stride, pad, cn, 
     hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d2), dt, 0), 'conv2')
     y2 = torch.empty(M, co, dtype=dtype, device=DEV)
     if cn:
-        assert hip.lib().usot_conv_pw_pair_supported(cm, co, cn) == 1 and hip.lib().usot_conv_pw_pair_supported(cm, co, 256) == 0
+        assert hip.lib().usot_conv_pw_pair_supported(cm, co, cn) == 1 and hip.lib().usot_conv_pw_pair_supported(cm, co, 64) == 0
         pd = hip.pw_pair_desc(None, w3d.data_ptr(), b3d.data_ptr(), resd.data_ptr(), y.data_ptr(), w1d.data_ptr(), b1d.data_ptr(),
                               t.data_ptr(), M, cm, co, cn, 1)
         hip.check(hip.lib().usot_conv_pw_pair_lp(hip.stream(), C.byref(d), C.byref(pd), dt), 'usot_conv_pw_pair_lp')
@@ -1330,14 +1332,15 @@ def test_conv_pw_layer2_forms_equal_the_unfused_launches(n, h, stride, pad, cn, 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 @pytest.mark.parametrize('rs', [False, True], ids=['pertap', 'rowshared'])
 @pytest.mark.parametrize('form', [1, 2], ids=['panel256', 'panel128'])
-@pytest.mark.parametrize('n,h,pad,act2', [(2, 31, 2, 1), (1, 13, 1, 0), (1, 16, 1, 1)])
-def test_conv_pw_layer3_with_the_next_conv1_as_fifth_phase(n, h, pad, act2, dtype, form, rs):
+@pytest.mark.parametrize('n,h,pad,act2,cm', [(2, 31, 2, 1, 256), (1, 13, 1, 0, 256), (1, 16, 1, 1, 256), (2, 31, 1, 1, 128), (1, 12, 1, 1, 128)])
+def test_conv_pw_layer3_with_the_next_conv1_as_fifth_phase(n, h, pad, act2, cm, dtype, form, rs):
     """Layer3's fused block with the next block's conv1 (or the neck: act2 = 0) as phase 5 of the launch (csrc/conv_pw_lp.hip: the
     workgroup reads its own Y panel back and runs the 1024 -> 256 convolution on the freed LDS): Y as the four-phase kernel's, T
-    bit-identical to the tiled convolution on that Y (same k order) - also on the ragged last panel and with waves without pixels."""
+    bit-identical to the tiled convolution on that Y (same k order) - also on the ragged last panel and with waves without pixels.
+    cm = 128: layer2's last block, whose next conv1 is layer3's first (512 -> 256)."""
     import ctypes as C
-    g = torch.Generator().manual_seed(n * 100 + h + act2)
-    cm, co, cn = 256, 1024, 256
+    g = torch.Generator().manual_seed(n * 100 + h + act2 + cm)
+    co, cn = 4 * cm, 256
     M = n * h * h
     t1 = torch.randn(n, h, h, cm, generator=g).relu().to(dtype)
     w2 = (torch.randn(cm, 9 * cm, generator=g) / (9 * cm) ** 0.5).to(dtype)

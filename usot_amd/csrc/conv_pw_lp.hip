@@ -27,6 +27,8 @@
 #include "usot_hip.h"
 #include "common.h"
 
+extern "C" int usot_conv_pw_pixels(int64_t M);
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -65,7 +67,7 @@ struct CpCfg {
     // layer3's next conv1 (1024 -> 256) has no register pair form (64 more accumulators than a 16-wave workgroup has): CM = 256 with
     // CN > 0 is the PHASE-5 form instead - after conv3 the workgroup reads its own Y panel back (L2 / Infinity Cache: it has just
     // written it) and runs conv1 as a 16-k-tile implicit GEMM on the freed LDS
-    static constexpr bool P5 = CM == 256 && CN > 0;
+    static constexpr bool P5 = CN == 256;                  // (layer3: CM = 256; layer2's last block: CM = 128, next conv1 512 -> 256)
     static constexpr int CNR = P5 ? 0 : CN;                // width of the pair form's second GEMM
     static constexpr int SLAB1 = CNR * 8;                  // ... of w1's slab (CN channels x this group's 64 k)
     static constexpr int SLAB = SLAB0 + SLAB1;
@@ -85,7 +87,8 @@ struct CpCfg {
     static_assert(PERK <= NW, "a k-tile's share of the next activation stage: at most one DMA instruction per wave");
     static_assert(NW == 16 || NW == 8, "panels of 256 or 128 pixels");
     static_assert(CM == 256 || CM == 128, "layer3 / layer2 widths");
-    static_assert(CN % 64 == 0 && WI >= 1 && CM % RPP == 0 && (!P5 || CN == CM), "shape");
+    static constexpr int TN5 = CN / 64, WI5 = CN / RPP > 0 ? CN / RPP : 1;      // phase 5: a wave = 64 pixels x CN / 4 channels
+    static_assert(CN % 64 == 0 && WI >= 1 && CM % RPP == 0 && (!P5 || CN % RPP == 0), "shape");
     static_assert(STAGES >= BM * CPR * 16, "the T2 panel fits conv2's stages");
     static_assert(SLAB0 % NTHR == 0 && SLAB1 % NTHR == 0, "whole DMA instructions per slab");
     static_assert(LDS <= 160 * 1024, "LDS");
@@ -550,9 +553,10 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
     if constexpr (Cf::P5) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        f32x4 acc5[TN][TM];
+        constexpr int TN5 = Cf::TN5, WI5 = Cf::WI5;
+        f32x4 acc5[TN5][TM];
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+        for (int i = 0; i < TN5; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc5[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int lr = tid >> 3;
@@ -565,9 +569,9 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
             yok[i] = m < (long)p.M;
             yp[i] = p.y + (yok[i] ? m : 0) * CP_CO + kc * 8;
         }
-        const uint16_t *w1p[WI];
+        const uint16_t *w1p[WI5];
 #pragma unroll
-        for (int i = 0; i < WI; ++i) w1p[i] = p.w1 + (long)(lr + RPP * i) * CP_CO + kc * 8;
+        for (int i = 0; i < WI5; ++i) w1p[i] = p.w1 + (long)(lr + RPP * i) * CP_CO + kc * 8;
         // THREE activation stages, two filter stages (all of the LDS, as tile 36 of csrc/conv_bf16.hip): Y comes back from the
         // Infinity Cache / HBM (an XCD's 32 panels = 16 MB have long left its 4 MB L2), so its DMA runs two k-tiles ahead with a
         // counted vmcnt; the filters are L2-resident and run one ahead.  (Two stages + vmcnt(0) per k-tile: 2.5 us per k-tile.)
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
         auto issue_w5 = [&](int t, int buf) {
             const uint32_t bw = ldsw + (uint32_t)((3 * BM + buf * CN) * LDC * 16);
 #pragma unroll
-            for (int i = 0; i < WI; ++i) dma16u(w1p[i] + t * 64, bw + (uint32_t)(RPP * i * LDC * 16));
+            for (int i = 0; i < WI5; ++i) dma16u(w1p[i] + t * 64, bw + (uint32_t)(RPP * i * LDC * 16));
         };
         const u32x4 *sX = cp_smem, *sW = cp_smem + 3 * BM * LDC;
         const int sq = cp_swz(l15);
@@ -599,16 +603,16 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
             if (t + 1 < NT5) issue_w5(t + 1, (t & 1) ^ 1);
             if (t + 2 < NT5) issue_x5(t + 2, xs2);
             const u32x4 *cX = sX + (xs * BM + wm * TM * 16 + l15) * LDC;
-            const u32x4 *cW = sW + ((t & 1) * CN + wn * TN * 16 + l15) * LDC;
+            const u32x4 *cW = sW + ((t & 1) * CN + wn * TN5 * 16 + l15) * LDC;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                u32x4 wf[TN], xq[TM];
+                u32x4 wf[TN5], xq[TM];
 #pragma unroll
-                for (int i = 0; i < TN; ++i) wf[i] = cW[i * 16 * LDC + ((ks * 4 + quad) ^ sq)];
+                for (int i = 0; i < TN5; ++i) wf[i] = cW[i * 16 * LDC + ((ks * 4 + quad) ^ sq)];
 #pragma unroll
                 for (int j = 0; j < TM; ++j) xq[j] = cX[j * 16 * LDC + ((ks * 4 + quad) ^ sq)];
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
+                for (int i = 0; i < TN5; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j) acc5[i][j] = cp_mfma<F16>(wf[i], xq[j], acc5[i][j]);
             }
@@ -622,8 +626,8 @@ __global__ __launch_bounds__(NW * 64) void conv_pw_kernel(const CpK p)
         char *sT = (char *)cp_smem;
         constexpr int TCPR = CN / 8;
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int ch = wn * TN * 16 + i * 16 + quad * 4;
+        for (int i = 0; i < Cf::TN5; ++i) {
+            const int ch = wn * Cf::TN5 * 16 + i * 16 + quad * 4;
             const f32x4 b = *(const f32x4 *)(p.b1 + ch);
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
@@ -693,7 +697,7 @@ int cp_fill(const usot_conv_desc *c2, int CM, CpK &p)
     // fewer than 192 panels of 256 pixels (batch 32 at layer2 / layer3 resolution: 121) would leave half the chip idle: panels of
     // 128 pixels then (8 wavefronts; c2->tile & 3 = 1 / 2 forces the 256- / 128-pixel form: tests)
     const int force = c2->tile & 3;
-    const bool small = force == 2 || (force != 1 && (M + 255) / 256 < 192);
+    const bool small = force == 2 || (force != 1 && usot_conv_pw_pixels(M) == 128);
     // the row-shared k-loop of phase 1 where the geometry allows it (c2->tile & 4: the per-tap loop anyway: tests, A/B)
     p.rs = !(c2->tile & 4) && c2->KH == 3 && c2->KW == 3 && c2->stride == 1 && c2->pad_h == c2->dil_h && c2->pad_w == c2->dil_w &&
            c2->dil_w >= 1 && c2->dil_w <= 4 && ow == c2->W && oh == c2->H &&
@@ -715,11 +719,24 @@ extern "C" int usot_conv_pw_supported(int Cin, int CM, int CO)
 
 extern "C" int usot_conv_pw_pair_supported(int CM, int CO, int CN)
 {
-    return (CM == 128 && CO == 512 && CN == 128) || (CM == 256 && CO == 1024 && CN == 256);
+    return (CM == 128 && CO == 512 && (CN == 128 || CN == 256)) || (CM == 256 && CO == 1024 && CN == 256);
 }
 
-/* pixels per panel (= per workgroup) the launcher would use for M pixels */
-extern "C" int usot_conv_pw_pixels(int64_t M) { return (M + 255) / 256 < 192 ? 128 : 256; }
+/* pixels per panel (= per workgroup) the launcher would use for M pixels.  A launch is one workgroup per CU: 256-pixel panels when
+ * they fill most of a round (192 ... CUs panels) or many rounds; 128-pixel panels when there are too few (batch 32) or when the
+ * 256-pixel panels would spill into a mostly empty second round (CUs < panels < 1.5 CUs: e.g. 273 at batch 64 of 271 x 271 crops). */
+extern "C" int usot_conv_pw_pixels(int64_t M)
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    const int64_t n256 = (M + 255) / 256;
+    return (n256 < 192 || (n256 > cus && 2 * n256 < 3 * cus)) ? 128 : 256;
+}
 
 /* Y = relu(relu(conv(x; c2->w) + c2->bias) . w3^T + b3 + res): see usot_hip.h */
 extern "C" int usot_conv_pw_lp(void *stream, const usot_conv_desc *c2, const void *w3, const float *b3, const void *res, void *y,
@@ -759,5 +776,6 @@ extern "C" int usot_conv_pw_pair_lp(void *stream, const usot_conv_desc *c2, cons
     p.w1 = (const uint16_t *)d->w1; p.b1 = d->b1; p.t = (uint16_t *)d->t; p.act2 = d->act2;
     hipStream_t s = (hipStream_t)stream;
     if (d->CM == 256) return bm == 128 ? cp_launch<8, 256, 256>(s, p, dtype) : cp_launch<16, 256, 256>(s, p, dtype);
+    if (d->CN == 256) return bm == 128 ? cp_launch<8, 128, 256>(s, p, dtype) : cp_launch<16, 128, 256>(s, p, dtype);
     return bm == 128 ? cp_launch<8, 128, 128>(s, p, dtype) : cp_launch<16, 128, 128>(s, p, dtype);
 }

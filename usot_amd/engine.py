@@ -710,7 +710,7 @@ class Builder:
         k2 = c2.kh * c2.kw * c2.cin
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c2.cout * k2 + c3.cout * c3.cin + nxt.cout * c3.cout)))
         self.lp_bytes.append(2 * (n * h * h * c2.cin + m * (2 * c3.cout + nxt.cout) + c2.cout * k2 + c3.cout * c3.cin + nxt.cout * c3.cout))
-        if c3.cin == 256:                               # phase-5 form: the Y panel is read back for the second convolution
+        if nxt.cout == 256:                             # phase-5 form: the Y panel is read back for the second convolution
             self.lp_readback.append(2 * m * c3.cout)
         return y, t, oh
 
