@@ -424,7 +424,7 @@ def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, 
         e.features_bf16(x)
     p = next(v for k, v in e._feat.items() if k[:3] == ('bf16', batch, size))
     n, dt = _timed(p['plan'].run, min_seconds, steps)
-    prof = p['plan'].profile(frames=3, reps=1)
+    prof = stable_profile(p['plan'], dt / n * 1e3)
     convs = iter(p['log'])
     ms_conv = fl_conv = ms_all = 0.0
     rows = []
@@ -476,6 +476,21 @@ def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, 
     }
 
 
+
+def stable_profile(plan, step_ms, frames=3, tries=4):
+    """Per-op times of a plan (eager, HIP events).  A host hiccup during one of the few eager frames lands in one op's mean (seen: a
+    77 us launch reported as 324 us): keep the pass whose op times sum closest to - and accept the first within 6 % of - the
+    graph-timed step."""
+    best = None
+    for _ in range(tries):
+        prof = plan.profile(frames=frames, reps=1)
+        tot = sum(ms for *_, ms in prof)
+        if best is None or abs(tot - step_ms) < abs(best[0] - step_ms):
+            best = (tot, prof)
+        if abs(tot - step_ms) <= 0.06 * step_ms:
+            break
+    return best[1]
+
 def backbone_bf16(a, device):
     """`--workload backbone_bf16`: configs[2] as its own JSON line."""
     model, _ = build_model(0, 1, device)
@@ -521,7 +536,7 @@ def mixed_roofline(pm, batch, size, n, dt, top=5):
     utilisation of its dominant tile and the step's HBM traffic from the committed counter passes of THIS workload
     (scripts/round_snapshot.sh: `--workload track_mixed`; null when they were measured on another source tree); per-op
     HIP-event spans (plan.profile) for the slowest launches."""
-    prof = pm['plan'].profile(frames=5, reps=1)
+    prof = stable_profile(pm['plan'], dt / n * 1e3, frames=5)
     convs = iter(pm['log'])
     rows, ms_all, ms_conv, fl_conv = [], 0.0, 0.0, 0.0
     for kind, tile, ks, groups, ms in prof:

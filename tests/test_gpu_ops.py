@@ -1376,6 +1376,51 @@ def test_conv_pw_layer3_with_the_next_conv1_as_fifth_phase(n, h, pad, act2, cm, 
     assert float(((t[:M].double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= ulp * 1.01
 
 
+@pytest.mark.parametrize('rs', [False, True], ids=['pertap', 'rowshared'])
+def test_conv_pw_at_the_timed_size_is_deterministic_and_equal_to_the_unfused_chain(rs):
+    """The fused layer3 block (conv2 -> conv3 -> next conv1, csrc/conv_pw_lp.hip) at the TIMED size - batch 64 at 31 x 31: 241
+    workgroups, one per CU, every hand-counted s_waitcnt of the kernel under full load - run eight times on the same inputs: every run
+    bit-identical to the first (a slab or stage read before its DMA landed would show as run-to-run differences), Y and T of the
+    per-tap form bit-identical to the three unfused launches."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(64)
+    n, h, cm, co, cn = 64, 31, 256, 1024, 256
+    M = n * h * h
+    dtype, dt = torch.bfloat16, 0
+    t1 = torch.randn(n, h, h, cm, generator=g).relu().to(dtype).to(DEV)
+    w2 = (torch.randn(cm, 9 * cm, generator=g) / (9 * cm) ** 0.5).to(dtype).to(DEV)
+    w3 = (torch.randn(co, cm, generator=g) / cm ** 0.5).to(dtype).to(DEV)
+    w1 = (torch.randn(cn, co, generator=g) / co ** 0.5).to(dtype).to(DEV)
+    b2, b3, b1 = (torch.randn(c, generator=g).mul(0.1).to(DEV) for c in (cm, co, cn))
+    res = torch.randn(M, co, generator=g).to(dtype).to(DEV)
+    geo = dict(N=n, H=h, W=h, Cin=cm, OH=h, OW=h, Cout=cm, KH=3, KW=3, pad=(2, 2), dil=(2, 2), act=1)
+    d = hip.conv_desc(t1.data_ptr(), w2.data_ptr(), b2.data_ptr(), None, tile=0 if rs else 4, **geo)
+    assert hip.lib().usot_conv_pw_pixels(M) == 256
+    runs = []
+    for _ in range(8):
+        y = torch.zeros(M, co, dtype=dtype, device=DEV)
+        t = torch.zeros(M, cn, dtype=dtype, device=DEV)
+        pd = hip.pw_pair_desc(None, w3.data_ptr(), b3.data_ptr(), res.data_ptr(), y.data_ptr(), w1.data_ptr(), b1.data_ptr(), t.data_ptr(),
+                              M, cm, co, cn, 1)
+        hip.check(hip.lib().usot_conv_pw_pair_lp(hip.stream(), C.byref(d), C.byref(pd), dt), 'usot_conv_pw_pair_lp')
+        torch.cuda.synchronize()
+        runs.append((y, t))
+    for y, t in runs[1:]:
+        assert torch.equal(y, runs[0][0]) and torch.equal(t, runs[0][1])
+    if not rs:
+        t2 = torch.empty(n, h, h, cm, dtype=dtype, device=DEV)
+        d2 = hip.conv_desc(t1.data_ptr(), w2.data_ptr(), b2.data_ptr(), t2.data_ptr(), tile=32, **geo)
+        hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d2), dt, 0), 'conv2')
+        y2 = torch.empty(M, co, dtype=dtype, device=DEV)
+        hip.check(hip.lib().usot_pw_panel_lp(hip.stream(), hip.ptr(t2), hip.ptr(w3), hip.ptr(b3), hip.ptr(res), hip.ptr(y2), M, cm, co, 1, dt), 'conv3')
+        tt = torch.empty(M, cn, dtype=dtype, device=DEV)
+        d1 = hip.conv_desc(y2.data_ptr(), w1.data_ptr(), b1.data_ptr(), tt.data_ptr(), N=1, H=M, W=1, Cin=co, OH=M, OW=1, Cout=cn, KH=1, KW=1,
+                           act=1, tile=32)
+        hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d1), dt, 0), 'conv1')
+        torch.cuda.synchronize()
+        assert torch.equal(runs[0][0], y2) and torch.equal(runs[0][1], tt)
+
+
 def test_backbone_bf16_conv_pw_option_is_bit_identical():
     """Engine options 'conv_pw_lp' / 'conv_pw_pair_lp' (layer3's conv2 -> conv3 and layer2's conv2 -> conv3 -> next conv1 fused per
     pixel panel): the batched bf16 backbone's output is bit-identical to the unfused lowering's with the per-tap k-loop, and within
