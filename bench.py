@@ -394,6 +394,7 @@ def cpu_baseline(budget_s=14.0):
 
 
 LP_DOMINANT_KERNEL = 'conv_igemm_bf16<256, 256, 4, 4, false, 0, 2, 16, 1>'     # as scripts/pmc_busy.py keys it
+LP_FUSED_KERNEL = 'conv_pw_kernel<false, 16, 256, 256, true>'    # a fused layer3 block: the kernel with the most time in the step
 BF16_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF is 2:1 sparse)
 BACKBONE_GFLOP = 28.192642        # one 255^2 crop through stem..layer3
 
@@ -463,6 +464,10 @@ def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, 
                      'traffic_to_algorithmic': round(traffic / alg_bytes, 3) if traffic else None,
                      # the fused layer3 blocks read their own Y panel back for the next conv1 (phase 5 of csrc/conv_pw_lp.hip): real
                      # HBM / Infinity-Cache traffic that the unfused decomposition counted as conv1's algorithmic input
+                     # the fused layer3 block (conv2 -> conv3 -> next conv1, six launches per step): the kernel with the largest share of
+                     # the step; its matrix pipe idles through the HBM phases (phase 4: residual + Y, phase 5: the Y readback)
+                     'fused_block': (lambda b: None if not b else {'kernel': LP_FUSED_KERNEL, **{k: b.get(k) for k in ('clock_ghz', 'mfma_busy', 'stale')
+                                                                                                   if k in b}})(pmc_busy(LP_FUSED_KERNEL, BF16_PEAK_TFLOPS)),
                      'fused_readback_bytes_per_step': int(sum(p.get('lp_readback', []))),
                      'traffic_to_algorithmic_plus_readback': round(traffic / (alg_bytes + sum(p.get('lp_readback', []))), 3) if traffic else None,
                      'hbm_gbs_at_algorithmic_bytes': round(alg_bytes / (dt / n) / 1e9, 1),
