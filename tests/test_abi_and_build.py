@@ -106,3 +106,18 @@ def test_split16_tuning_table_names_split_fp16_tiles(libpath):
         assert L.usot_conv_tile_info(src, ctypes.byref(bm), ctypes.byref(bn)) == 0
         assert L.usot_conv_tile_info(dst, ctypes.byref(bm2), ctypes.byref(bn2)) == 0
         assert (bm.value, bn.value) == (bm2.value, bn2.value), (src, dst)
+
+
+def test_fused_bottleneck_shape_queries_are_host_functions(libpath):
+    """The shape / panel queries of the fused bottleneck kernels (csrc/conv_pw_lp.hip) answer without a GPU: layer3 and layer2 widths,
+    the pair forms, and the panel rule (128-pixel panels below 192 panels of 256 and for a mostly empty second round)."""
+    L = ctypes.CDLL(libpath)
+    L.usot_conv_pw_pixels.argtypes = [ctypes.c_int64]
+    assert L.usot_conv_pw_supported(256, 256, 1024) == 1 and L.usot_conv_pw_supported(128, 128, 512) == 1
+    assert L.usot_conv_pw_supported(64, 64, 256) == 0 and L.usot_conv_pw_supported(256, 256, 512) == 0
+    assert L.usot_conv_pw_pair_supported(128, 512, 128) == 1 and L.usot_conv_pw_pair_supported(128, 512, 256) == 1
+    assert L.usot_conv_pw_pair_supported(256, 1024, 256) == 1 and L.usot_conv_pw_pair_supported(256, 1024, 128) == 0
+    assert L.usot_conv_pw_pixels(32 * 961) == 128           # batch 32 at layer3 resolution: 121 panels of 256
+    assert L.usot_conv_pw_pixels(64 * 961) == 256           # batch 64: 241 panels, one round
+    assert L.usot_conv_pw_pixels(64 * 1089) == 128          # 271 x 271 crops: 273 panels of 256 would leave a second round 7 % full
+    assert L.usot_conv_pw_pixels(192 * 961) == 256          # many rounds
