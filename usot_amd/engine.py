@@ -682,7 +682,7 @@ class Builder:
         w2, w3 = c2.w_lp(dtype), c3.w_lp(dtype)
         d = hip.conv_desc(t1.data_ptr(), w2.data_ptr(), c2.b.data_ptr(), None, N=n, H=h, W=h, Cin=c2.cin, OH=oh, OW=ow, Cout=c2.cout,
                           KH=c2.kh, KW=c2.kw, stride=c2.stride, pad=c2.pad, dil=c2.dil, act=ACT_RELU,
-                          tile=0 if self.opt['conv_pw_rs'] else 4)
+                          tile=(0 if self.opt['conv_pw_rs'] else 4) | int(self.opt['conv_pw_panel']))
         hip.check(hip.lib().usot_plan_add_conv_pw(self.plan.h, C.byref(d), hip.ptr(w3), hip.ptr(c3.b), hip.ptr(res), hip.ptr(y),
                                                   1 if dtype == torch.float16 else 0), 'plan_add_conv_pw ' + name)
         self.plan.keep += [t1, res, w2, w3, c2.b, c3.b]
@@ -701,7 +701,7 @@ class Builder:
         w2, w3, w1 = c2.w_lp(dtype), c3.w_lp(dtype), nxt.w_lp(dtype)
         d2 = hip.conv_desc(t1.data_ptr(), w2.data_ptr(), c2.b.data_ptr(), None, N=n, H=h, W=h, Cin=c2.cin, OH=oh, OW=ow, Cout=c2.cout,
                            KH=c2.kh, KW=c2.kw, stride=c2.stride, pad=c2.pad, dil=c2.dil, act=ACT_RELU,
-                           tile=0 if self.opt['conv_pw_rs'] else 4)
+                           tile=(0 if self.opt['conv_pw_rs'] else 4) | int(self.opt['conv_pw_panel']))
         d = hip.pw_pair_desc(None, w3.data_ptr(), c3.b.data_ptr(), res.data_ptr(), y.data_ptr(), w1.data_ptr(), nxt.b.data_ptr(),
                              t.data_ptr(), m, c3.cin, c3.cout, nxt.cout, act2)
         hip.check(hip.lib().usot_plan_add_conv_pw_pair(self.plan.h, C.byref(d2), C.byref(d), 1 if dtype == torch.float16 else 0),
@@ -1276,6 +1276,8 @@ DEFAULT_OPTIONS = {
     # tile per (kh, channel chunk) serves the three kw taps - a third fewer LDS-DMA instructions per k-tile; k order (kh, chunk, kw), so
     # results differ from the per-tap loop's by fp32 summation order).  False: the per-tap loop, bit-identical to the unfused launches
     'conv_pw_rs': True,
+    # panel size of those kernels: 0 = the launcher's rule (usot_conv_pw_pixels), 1 = 256 pixels / 16 wavefronts, 2 = 128 / 8 (A/B switch)
+    'conv_pw_panel': 0,
     'lp_chains': 0,
     'lp_chains_from': 7,
     'lp_chain_skew': 2,
@@ -1391,6 +1393,7 @@ ENV_SWITCHES = {      # environment variable -> (option, parser)
     'USOT_CONV_PW_LP': ('conv_pw_lp', lambda v: tuple(int(t) for t in v.split(',') if t)),      # '' = off, '256', '256,128'
     'USOT_CONV_PW_PAIR_LP': ('conv_pw_pair_lp', lambda v: v == '1'),
     'USOT_CONV_PW_RS': ('conv_pw_rs', lambda v: v == '1'),
+    'USOT_CONV_PW_PANEL': ('conv_pw_panel', int),
     'USOT_CONV_PW_P5_LP': ('conv_pw_p5_lp', lambda v: v == '1'),
 }
 
