@@ -258,6 +258,7 @@ def xcorr_bandwidth(device, sizes=(2048, 128), iters=20):
     return {'bound': 'hbm', 'kernel': top['kernel'], 'samples': top['samples'], 'ms': top['ms'],
             'achieved': top['achieved'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(top['achieved'] / HBM_PEAK_GBPS, 4),
             'ceiling_probe': probe, 'frac_of_measured_ceiling': round(top['achieved'] / probe['mix_4r_1w'], 4),
+            'frac_of_pattern_emulation': round(top['achieved'] / probe['groupdw_pattern'], 4),
             'algorithmic_bytes': top['bytes'], **xcorr_traffic(top['kernel'], top['samples']), 'by_samples': rows}
 
 
@@ -281,9 +282,28 @@ def hbm_ceiling_probe(device, gib=2, iters=10):
         e1.record()
         torch.cuda.synchronize()
         out[name] = round(moved / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9, 1)
+    # GroupDW's own traffic pattern without its compute (mode 3): what (sample, 64-channel group) blocks streaming 256-byte
+    # granules of three maps + one output map reach on this box - the kernel's structural ceiling (scripts/probes/granule_probe.hip)
+    S = 2048                                                 # the sample count `xcorr_hbm.achieved` is measured at
+    del src, dst
+    src = torch.empty(3 * S * 841 * 256, dtype=torch.float32, device=device).fill_(1.0)
+    dst = torch.empty(S * 625 * 256, dtype=torch.float32, device=device)
+    run = lambda: hip.check(hip.lib().usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), S * 3 * 841 * 1024, 3), 'usot_bw_probe')
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    out['groupdw_pattern'] = round(S * (3 * 841 + 625) * 1024 / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9, 1)
     out['unit'] = 'GB/s'
     out['what'] = ('%d GiB buffers, 16 B per lane; read = 8 non-temporal loads in flight per lane; copy = 32 KiB block spans, non-temporal '
-                   'loads and stores; mix_4r_1w = GroupDW byte mix (one interleaved read stream, non-temporal stores)' % gib)
+                   'loads and stores; mix_4r_1w = GroupDW byte mix (one interleaved read stream, non-temporal stores); groupdw_pattern = '
+                   'an address-level emulation of the GroupDW launch itself (%d samples: its blocks, its 256-byte granules, its 4 : 1 mix, '
+                   'no compute)' % (gib, S))
     return out
 
 

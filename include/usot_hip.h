@@ -38,7 +38,9 @@ int usot_abi_version(void);
  * USOT_OK on that device, USOT_ESTATE on any other.  Every launcher with such state calls it first. */
 int usot_device_guard(void);
 /* HBM ceiling probe of the box (csrc/bw_probe.hip): mode 0 read `bytes`, 1 copy `bytes`, 2 read `bytes` + write bytes / 4
- * (GroupDW's byte mix, one interleaved read stream, non-temporal stores).  bytes % 4096 == 0. */
+ * (GroupDW's byte mix, one interleaved read stream, non-temporal stores), 3 GroupDW's TRAFFIC without its compute - an address-level
+ * emulation of the batched launch for S = bytes / (3 * 841 * 1024) samples: (sample, 64-channel group) blocks reading 256-byte
+ * granules of three maps in src (S * 3 * 841 KiB) and writing S * 625 KiB to dst.  bytes % 4096 == 0 (mode 3: % 1024). */
 int usot_bw_probe(void *stream, const void *src, void *dst, int64_t bytes, int mode);
 const char *usot_strerror(int code);
 

@@ -1467,7 +1467,15 @@ def test_bw_probe_kernels_move_the_right_bytes():
     assert torch.allclose(got, want, rtol=1e-6, atol=1e-6) and float(dst[n // 16:].abs().max()) == 0.0
     hip.check(L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, 0), 'read')
     assert L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n + 16, 1) != 0
-    assert L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, 3) != 0
+    assert L.usot_bw_probe(hip.stream(), hip.ptr(src), hip.ptr(dst), n, 4) != 0
+    # mode 3, GroupDW's traffic pattern: S samples = three 29 x 29 x 256 maps read, one 25 x 25 x 256 map written, nothing beyond
+    S = 3
+    src3 = torch.ones(3 * S * 841 * 256, device=DEV)
+    dst3 = torch.zeros(S * 625 * 256 + 1024, device=DEV)
+    hip.check(L.usot_bw_probe(hip.stream(), hip.ptr(src3), hip.ptr(dst3), 3 * S * 841 * 1024, 3), 'groupdw pattern')
+    torch.cuda.synchronize()
+    assert float(dst3[:S * 625 * 256].min()) > 0.0 and float(dst3[S * 625 * 256:].abs().max()) == 0.0
+    assert L.usot_bw_probe(hip.stream(), hip.ptr(src3), hip.ptr(dst3), 4096, 3) != 0          # less than one sample
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
