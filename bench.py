@@ -50,6 +50,15 @@ def build_model(rank, world, device):
     return m, nbytes
 
 
+def f32_dtype_label(engine):
+    """`dtype` of an fp32-storage workload, from the engine options it actually ran with: 'f32' = exact fp32 products
+    (v_mfma_f32_16x16x4_f32, the reference's arithmetic); the opt-in split-fp16 mode says what it is."""
+    if engine.opt.get('split16_f32'):
+        return ('f32 storage / accumulation, split-fp16 products (operands as hi + lo fp16: 22 significant bits, |x| < 8 188 with automatic '
+                'exact-fp32 fallback) in the K >= %d convs and layer3\'s fused 1x1 pairs' % engine.opt.get('split16_min_k', 0))
+    return 'f32'
+
+
 def open_stream(model, device, seed, size=255):
     """Template + memory seeds for one synthetic video stream; returns (session, crops)."""
     p = USOTConfig()
@@ -456,7 +465,10 @@ def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, 
             ms_conv += ms
             fl_conv += 2.0 * macs
             rows.append((ms, name, M, N, K, 2.0 * macs / ms / 1e9))
-    ach = fl_conv / (ms_conv * 1e-3) / 1e12
+    # `achieved` = SURVEY 8(d)'s algorithmic work of the step (batch x 28.192642 GFLOP: stem .. layer3, the neck's 0.504 GFLOP per crop
+    # not counted) over the STEP time of the graph replay - not over the sum of the conv launches' spans, which is reported beside it
+    ach = batch * BACKBONE_GFLOP * n / dt / 1e3
+    conv_tflops = fl_conv / (ms_conv * 1e-3) / 1e12
     # algorithmic HBM bytes of the step: every conv launch's operands and result once (engine.Builder.lp_bytes) + the stem's
     # fp32 crops in and pooled map out; measured traffic from the committed PMC passes (scripts/pmc_lp_traffic.py)
     ph = ((size - 7) // 2 + 1 - 1) // 2 + 1
@@ -493,7 +505,10 @@ def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, 
                      'hbm_gbs_at_algorithmic_bytes': round(alg_bytes / (dt / n) / 1e9, 1),
                      'traffic_per_launch_top_kernels': by_kernel,
                      'kernel': 'conv_igemm_bf16 / conv_pw / bneck family (all %d conv launches; a fused bottleneck launch counts once)' % len(rows),
-                     'algorithmic_gflop_per_step': round(fl_conv / 1e9, 1), 'conv_ms_per_step': round(ms_conv, 3),
+                     'algorithmic_gflop_per_step': round(batch * BACKBONE_GFLOP, 1),
+                     'conv_launches': {'gflop_per_step': round(fl_conv / 1e9, 1), 'ms_per_step': round(ms_conv, 3), 'tflops': round(conv_tflops, 1),
+                                       'what': 'every conv launch behind the stem incl. the neck (HIP-event spans, plan.profile); the stem is its own launch'},
+                     'conv_ms_per_step': round(ms_conv, 3),
                      'all_ops_ms_per_step': round(ms_all, 3),
                      'end_to_end_tflops': round(batch * (BACKBONE_GFLOP + 0.504) * n / dt / 1e3, 1),
                      'slowest': [{'op': nm, 'M': M, 'N': N, 'K': K, 'ms': round(ms, 3), 'tflops': round(tf, 1)}
@@ -633,7 +648,7 @@ def measure_lockstep_f32(model, device, batch=4, size=255, steps=0, min_seconds=
     return {'workload': 'fp32 lock-step: %d streams in one fp32 plan (backbone + heads, N_q=7), hipGraph replay, inputs '
                         'resident' % batch,
             'value': round(batch * n / dt, 1), 'unit': 'frames/s', 'batch': batch, 'steps': n,
-            'ms_per_step': round(dt / n * 1e3, 4), 'dtype': 'f32'}
+            'ms_per_step': round(dt / n * 1e3, 4), 'dtype': f32_dtype_label(e)}
 
 
 def measure_track_271(model, device, warmup=30, min_seconds=1.0):
@@ -644,8 +659,28 @@ def measure_track_271(model, device, warmup=30, min_seconds=1.0):
     run_frames(sess, crops, p, conf, warmup)
     n, dt = _timed(lambda: run_frames(sess, crops, p, conf, 1), min_seconds)
     return {'workload': 'configs[1] at instance size 271: batch=1 fp32 frame (backbone + heads N_q=7 + decode + PrRoIPool), 27x27 response',
-            'value': round(n / dt, 1), 'unit': 'frames/s', 'steps': n, 'ms_per_step': round(dt / n * 1e3, 4), 'dtype': 'f32',
+            'value': round(n / dt, 1), 'unit': 'frames/s', 'steps': n, 'ms_per_step': round(dt / n * 1e3, 4), 'dtype': f32_dtype_label(model.engine),
             'search': 271}
+
+
+def measure_track_split16(model, device, size=255, warmup=30, min_seconds=1.5):
+    """The headline frame on the OPT-IN split-fp16 products (engine option split16_f32: the K >= 1152 convolutions and layer3's
+    fused 1x1 pairs form every product from hi + lo fp16 halves of the fp32 operands, fp32 accumulation; same 1e-4 parity bar, narrower
+    operands than the reference's fp32 - hence a labelled extra, never `value`).  Same loop as `value`, own engine on the same weights."""
+    from usot_amd.engine import Engine
+    eng = Engine(model, device, **dict({k: v for k, v in model.engine_options.items() if v is not None and k != 'options'},
+                                       options=dict(model.engine_options.get('options') or {}, split16_f32=True)))
+    keep, model._engine = model._engine, eng
+    try:
+        sess, crops, p = open_stream(model, device, seed=0, size=size)
+    finally:
+        model._engine = keep
+    conf = Confidences()
+    run_frames(sess, crops, p, conf, warmup)
+    n, dt = _timed(lambda: run_frames(sess, crops, p, conf, 1), min_seconds)
+    return {'workload': 'configs[1] with split-fp16 products (opt-in engine option split16_f32): batch=1 frame, same loop as `value`',
+            'value': round(n / dt, 1), 'unit': 'frames/s', 'steps': n, 'ms_per_step': round(dt / n * 1e3, 4), 'dtype': f32_dtype_label(eng),
+            'range_fallbacks': getattr(eng, 'range_fallbacks', 0), 'roofline': roofline(sess, frames=10)}
 
 
 def track_mixed(a, rank, world, device):
@@ -709,6 +744,41 @@ def self_launch(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def plumbing_only(a):
+    """`--plumbing-only`: the N-rank control flow of the default workload with the frames left out - what an 8-GPU node would do
+    around the timed region, runnable on CPU ranks over gloo: torchrun environment -> streams.init -> the model on rank 0 only ->
+    ONE flat broadcast -> stream s on rank s mod N -> barrier / timed no-op / barrier -> max over ranks -> rank 0 prints one line.
+    `value` is null: nothing was measured."""
+    rank, local, world = streams.env_world()
+    if world != a.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    os.environ.setdefault('USOT_ALLOW_GLOO_ON_GPUS', '1')
+    streams.init(backend='gloo')
+    torch.set_num_threads(min(host_threads(), streams.host_thread_cap(world)))
+    model, wbytes = build_model(rank, world, torch.device('cpu'))
+    S = max(1, a.streams_per_gpu)
+    mine = streams.shard(range(world * S), rank, world)          # the videos this rank would track
+    # every rank's model must now hold rank 0's weights: one checksum per rank, gathered through the same max-over-ranks path
+    ck = float(sum(float(v.double().sum()) for v in model.state_dict().values() if v.is_floating_point()))
+    spread = streams.max_over_ranks(ck) + streams.max_over_ranks(-ck)        # max - min over ranks: 0 when all equal
+    streams.barrier()
+    t0 = time.perf_counter()
+    streams.barrier()
+    dt = streams.max_over_ranks(time.perf_counter() - t0)
+    counts = [len(streams.shard(range(world * S), r, world)) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'tracker FPS (255x255 search, ResNet-50)', 'value': None, 'unit': 'frames/s', 'n_gpus': world, 'steps': 0,
+            'warmup': 0, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic', 'plumbing_only': True,
+            'config': {'workload': 'PLUMBING ONLY - no frames run, nothing measured: rendezvous, weight broadcast, sharding, barriers',
+                       'streams': world * S, 'streams_per_gpu': S, 'shards': counts, 'rank0_streams': mine,
+                       'weights': 'synthetic seed 0 (calibrated BN), %s' % streams.broadcast_summary(), 'weight_bytes': wbytes,
+                       'weight_checksum_spread_over_ranks': spread, 'host_threads_per_rank': torch.get_num_threads(),
+                       'barrier_seconds': round(dt, 6)}}))
+    streams.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -726,10 +796,15 @@ def main():
     ap.add_argument('--heads-f32', action='store_true', help='track_mixed: keep every head conv in fp32')
     ap.add_argument('--streams-per-gpu', type=int, default=1,
                     help='independent videos per GPU on separate HIP streams (default 1 = BASELINE configs[1])')
+    ap.add_argument('--plumbing-only', action='store_true',
+                    help='NO frames are run and nothing is measured: the N-rank control flow only (rendezvous, one flat weight broadcast, stream '
+                         'sharding, barriers, max-over-ranks, rank 0 prints one line) - runs without a GPU over gloo (tests/test_distributed_cpu.py)')
     a = ap.parse_args()
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(a)
+    if a.plumbing_only:
+        return plumbing_only(a)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
     ndev = torch.cuda.device_count()
@@ -779,11 +854,9 @@ def main():
             'n_gpus': world, 'steps': steps, 'steps_requested': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            # fp32 storage and accumulation everywhere; the K >= 1152 convolutions and layer3's fused 1x1 pairs form their products from
-            # fp16 hi + lo splits of the fp32 operands (22 significant bits, engine option split16_f32; False = exact fp32 MFMA) -
-            # same 1e-4 parity bar
-            'dtype': ('f32 (split-fp16 products with fp32 accumulation in the K>=1152 convs and layer3\'s fused 1x1 pairs)'
-                      if model.engine.opt.get('split16_f32') else 'f32'),
+            # the engine's default: exact fp32 products (v_mfma_f32_16x16x4_f32), fp32 storage and accumulation - the reference's
+            # arithmetic; the opt-in split-fp16 mode is timed as the labelled extra `track_split16` below
+            'dtype': f32_dtype_label(model.engine),
             'data': 'synthetic',
             'config': {'workload': 'configs[1]: batch=1 ResNet-50(layer3)+neck, fused depthwise xcorr, cls/reg/'
                                    'memory heads (N_q=7), decode + PrRoIPool, fp32, 1 stream per GPU',
@@ -810,6 +883,7 @@ def main():
                             'lock step, N_q=7, one hipGraph', 'value': round(32 * n / t, 1), 'unit': 'frames/s',
                 'steps': n, 'ms_per_step': round(t / n * 1e3, 3), 'dtype': 'fp16+f32',
                 'roofline': mixed_roofline(pm, 32, a.size, n, t)}
+            line['track_split16'] = measure_track_split16(model, device, a.size)
             line['lockstep_f32_b4'] = measure_lockstep_f32(model, device, 4, a.size)
             if a.size != 271:
                 line['track_271'] = measure_track_271(model, device)

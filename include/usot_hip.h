@@ -26,6 +26,7 @@ extern "C" {
 #define USOT_ELAUNCH      -2   /* hipGetLastError() after launch   */
 #define USOT_ENOMEM       -3
 #define USOT_ESTATE       -4   /* plan used in the wrong state     */
+#define USOT_ENOTBUILT    -5   /* a conv tile id that exists only in the -DUSOT_EXPERIMENTS build (usot_conv_tile_built) */
 
 /* activation codes of the conv epilogue */
 #define USOT_ACT_NONE      0
@@ -90,6 +91,10 @@ typedef struct usot_conv_desc {
                        * all-DMA split-fp16 tiles (usot_conv_tile_xsplit(tile) == 1): both operands then reach LDS by LDS-DMA */
     int32_t y_split;  /* 1: the result is written as a split map (split-fp16 tiles only; dense NHWC, Cout % 64 == 0, no residual, no
                        * split-K).  Its only readers are launches with x_split = 1 */
+    int32_t *ovf;     /* split-fp16 tiles: NULL, or a device word the launch sets to 1 (sticky: it never clears it) when one of its finished
+                       * sums is not finite - what an activation beyond the fp16 window (|x| >= 8 188: hi = inf, lo = -inf) or a non-finite
+                       * input turns every sum it enters into - BEFORE bias / activation / split-K slabs see the sum (a ReLU would turn the
+                       * NaN into a finite 0).  The caller re-runs the work on the exact-fp32 tiles (usot_amd/engine.py: Session, Engine.track) */
 } usot_conv_desc;
 
 int usot_conv2d_f32(void *stream, const usot_conv_desc *d);
@@ -107,6 +112,8 @@ int usot_thin_conv3x3_f32(void *stream, const usot_conv_desc *d, int n);
 int usot_plan_add_thin_conv(void *plan, const usot_conv_desc *d, int n);
 int usot_conv_tile_count(void);
 int usot_conv_tile_info(int tile, int *bm, int *bn);           /* tile ids are 1..count */
+int usot_conv_tile_built(int tile);                            /* 1: compiled into this library (the routed tiles; every id with -DUSOT_EXPERIMENTS) */
+int usot_experiments_built(void);                              /* 1: the library was built with -DUSOT_EXPERIMENTS */
 int usot_conv_tile_name(int tile, char *buf, int len);         /* kernel symbol of the tile */
 int usot_conv_tile_xsplit(int tile);                           /* 1: the tile reads a split input map (usot_conv_desc.x_split) */
 int usot_conv_tile_wfrag(int tile);                            /* 1: the tile streams its filters in fragment order; 2: split-fp16 bank + w_scale */
@@ -134,6 +141,7 @@ int usot_conv2d_bf16(void *stream, const usot_conv_desc *d);
  * w_gs, b_gs, y_gs (y_gs in OUTPUT elements; no residual with groups).  Not supported: ksplit,
  * y_nchw, channel-offset outputs.  tile: 0 = heuristic, 1..usot_conv_bf16_tile_count().           */
 int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, int out_f32);
+int usot_conv_bf16_tile_built(int tile);                       /* 1: the low-precision tile id is compiled into this library (cf. usot_conv_tile_built) */
 int usot_cvt_f32_to_lp(void *stream, const float *src, void *dst, int64_t n, int dtype);
 int usot_maxpool3x3s2_lp(void *stream, const void *x, void *y, int N, int H, int W, int C, int OH, int OW, int dtype);
 int usot_conv_bf16_tile_count(void);
@@ -170,6 +178,7 @@ typedef struct usot_pw_pair_desc {
     /* fp32 form only: res given as res_parts > 1 partial sums [res_parts][M][CO] of the shortcut convolution (defer); the kernel
      * adds (sum of the parts in order + res_bias) as the residual - no activation: the downsample branch has none */
     const float *res_bias;
+    int32_t *ovf;         /* usot_pw_pair_f32s only: NULL or the sticky not-finite word of usot_conv_desc.ovf (checked on both GEMMs' sums) */
 } usot_pw_pair_desc;
 int usot_pw_pair_lp(void *stream, const usot_pw_pair_desc *d, int dtype);
 int usot_pw_pair_layout(int CM, int CO, int CN, int which, int32_t *row, int32_t *k0);   /* which: 0 = w3, 1 = w1 */
@@ -453,7 +462,9 @@ int usot_decode_f32(void *stream, const float *cls, const float *cls_mem, const 
  * roi_out[5] = (0, x1, y1, x2, y2) in feature coordinates: no host round trip between
  * decode and memory-feature pooling.  tsz_dev[6] is a caller-chosen frame tag that is copied
  * to out[8] AFTER the results (system-scope fence in between), so `out` needs 9 doubles and a
- * host may poll out[8] in pinned memory instead of synchronising the stream.             */
+ * host may poll out[8] in pinned memory instead of synchronising the stream.
+ * tsz_dev[3], read as a 64-bit integer: 0, or the device address of the frame's sticky split-fp16 range word
+ * (usot_conv_desc.ovf); its value is then published as out[9] (10 doubles) with the results and the word is cleared. */
 int usot_decode_dev_f32(void *stream, const float *cls, const float *cls_mem, const float *bbox,
                         const double *window, double *out, int S, int instance_size, int stride,
                         float ratio, double penalty_k, double window_influence,

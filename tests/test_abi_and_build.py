@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(libpath):
     # the reference's own native symbols (prroi_pooling_gpu_impl.cuh:20-54)
     assert {'PrRoIPoolingForwardGpu', 'PrRoIPoolingBackwardGpu', 'PrRoIPoolingCoorBackwardGpu'} <= set(syms)
     L.usot_abi_version.restype = ctypes.c_int
-    assert L.usot_abi_version() == 4
+    assert L.usot_abi_version() == 5
     L.usot_strerror.restype = ctypes.c_char_p
     assert b'invalid' in L.usot_strerror(-1)
 
@@ -121,3 +121,34 @@ def test_fused_bottleneck_shape_queries_are_host_functions(libpath):
     assert L.usot_conv_pw_pixels(64 * 961) == 256           # batch 64: 241 panels, one round
     assert L.usot_conv_pw_pixels(64 * 1089) == 128          # 271 x 271 crops: 273 panels of 256 would leave a second round 7 % full
     assert L.usot_conv_pw_pixels(192 * 961) == 256          # many rounds
+
+
+def test_default_library_holds_exactly_the_routed_conv_tiles(libpath):
+    """the product library compiles the conv tiles something can SELECT - the tuning tables
+    (usot_amd/data/tuning_gfx950.json, tuning_split16_gfx950.json, tuning_lp_gfx950.json), engine.SPLIT16_TILES' twins of tuned tiles,
+    the engine's deferred-launch options and default batch tile, and the launchers' own heuristics - and nothing else; every other
+    tile id of the tables is an experiment that exists only in a USOT_EXPERIMENTS=1 build (parity tests: `-m experiments`)."""
+    import json
+    from usot_amd import engine
+    L = ctypes.CDLL(libpath)
+    if L.usot_experiments_built():
+        pytest.skip('experiments build: every tile id is compiled')
+    data = os.path.join(ROOT, 'usot_amd', 'data')
+    with open(os.path.join(data, 'tuning_gfx950.json')) as f:
+        f32 = {int(v[0]) for k, v in json.load(f).items() if not k.startswith('_')}
+    with open(os.path.join(data, 'tuning_split16_gfx950.json')) as f:
+        s16 = {int(v[0]) for v in json.load(f).values()}
+    with open(os.path.join(data, 'tuning_lp_gfx950.json')) as f:
+        lp = {int(v) for v in json.load(f).values()}
+    opt = engine.DEFAULT_OPTIONS
+    routed = set(f32) | s16 | {1, 2, 4, 5, 7, 8}                     # pick_tile() in csrc/conv_igemm.hip
+    routed |= {15}                                                   # Builder.default_batch_tile
+    routed |= {engine.SPLIT16_TILES[t] for t in f32 if t in engine.SPLIT16_TILES}
+    for key in ('defer_split_f32', 'defer_split_s16', 'defer_split_res_f32', 'batch_ds_conv2'):
+        routed |= {int(v[0]) for v in opt[key].values()}
+    built = {t for t in range(1, L.usot_conv_tile_count() + 1) if L.usot_conv_tile_built(t)}
+    assert built == routed, (sorted(built - routed), sorted(routed - built))
+    lp_routed = lp | {1, 4, 5} | {21}                                # heuristic of usot_conv2d_lp; 21 = the plain form of tile 32's loop
+    lp_built = {t for t in range(1, L.usot_conv_bf16_tile_count() + 1) if L.usot_conv_bf16_tile_built(t)}
+    assert lp_built == lp_routed, (sorted(lp_built - lp_routed), sorted(lp_routed - lp_built))
+    assert os.path.getsize(libpath) < 4 * 1024 * 1024                # 8.5 MB with the experiments

@@ -19,7 +19,8 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      USOT_ALLOW_GLOO_ON_GPUS='1')      # this test asks for gloo explicitly, also on a box with >= 2 GPUs
     from usot_amd import streams, synth
     from usot_amd.model import USOT
     r, _, w = streams.init(backend='gloo')
@@ -91,3 +92,29 @@ def test_init_refuses_gloo_when_every_rank_has_its_own_gpu(monkeypatch):
     monkeypatch.setattr(torch.distributed, 'get_backend', lambda: 'gloo')
     streams.init(backend='gloo')
     assert called and called[0]['backend'] == 'gloo'
+
+
+def test_bench_gpus_8_control_flow_over_gloo():
+    """`python bench.py --gpus 8` on CPU ranks (the reference's fan-out is scripts/test_epochs_usot.py:19-49): the
+    self-launch under torch.distributed.run, eight ranks over gloo, ONE flat broadcast of rank 0's weights (every parameter + float
+    BN buffer, fp32), stream s on rank s mod 8, barriers, max-over-ranks, exactly one JSON line from rank 0.  `--plumbing-only`:
+    no frame is run and the line says so (`value` null) - the GPU work of the same command is covered by tests/test_gpu_bench.py."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, USOT_ALLOW_GLOO_ON_GPUS='1', OMP_NUM_THREADS='1', CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--plumbing-only'], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors='replace')[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    c = j['config']
+    assert j['n_gpus'] == 8 and j['plumbing_only'] is True and j['value'] is None and j['scaling'] == 'weak'
+    assert c['streams'] == 8 and c['shards'] == [1] * 8 and c['rank0_streams'] == [0]
+    assert c['weight_bytes'] == (29414993 + 44486 - 70) * 4 == 117837636
+    assert 'broadcast 117837636 B in ' in c['weights'] and 'backend gloo, 8 ranks' in c['weights'], c['weights']
+    assert c['weight_checksum_spread_over_ranks'] == 0.0          # every rank ended up with rank 0's weights

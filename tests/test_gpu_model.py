@@ -21,13 +21,17 @@ def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-@pytest.fixture(scope='module', params=[True, False], ids=['graph', 'eager'])
+@pytest.fixture(scope='module', params=['graph', 'eager', 'graph_split16'])
 def net(request):
+    """graph / eager: the default engine (exact fp32 products); graph_split16: the opt-in split-fp16 products (engine option
+    split16_f32) - every golden below holds on both arithmetic modes."""
     m = USOT()
     m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True), strict=True)
     m.eval()
     m = m.to(DEV)
-    m.engine_options['graphs'] = request.param
+    m.engine_options['graphs'] = request.param != 'eager'
+    if request.param == 'graph_split16':
+        m.engine_options['options'] = {'split16_f32': True}
     return m
 
 
@@ -317,9 +321,10 @@ OPTION_VARIANTS = [{'fused_f32_sliced': False}, {'conf_tail_split': None}, {'con
                    {'defer_split_res_f32': {(961, 512, 2304): (56, 2), (1089, 512, 2304): (56, 2)}},
                    {'defer_split_f32': {}}, {'defer_split_f32': {(961, 256, 2304): (57, 4), (1089, 256, 2304): (57, 4)}},
                    {'defer_split_f32': {(961, 256, 2304): (55, 2), (1089, 256, 2304): (55, 3)}},
-                   # split-fp16 arithmetic of the K >= 1152 convolutions: off (exact-fp32 MFMA everywhere), on for every K >= 256 tile
-                   # conv too, without the filter-DMA tiles of the deferred launches
-                   {'split16_f32': False}, {'split16_min_k': 256, 'split16_min_m': 0}, {'defer_split_s16': {}}, {'split16_pairs': set()}]
+                   # the opt-in split-fp16 arithmetic of the K >= 1152 convolutions: on, on for every K >= 256 tile conv too, without the
+                   # filter-DMA tiles of the deferred launches, without the split pairs
+                   {'split16_f32': True}, {'split16_f32': True, 'split16_min_k': 256, 'split16_min_m': 0}, {'split16_f32': True, 'defer_split_s16': {}},
+                   {'split16_f32': True, 'split16_pairs': set()}]
 
 
 @pytest.mark.parametrize('variant', OPTION_VARIANTS, ids=lambda v: ','.join('%s=%s' % (k, str(v[k])[:40].replace(' ', '')) for k in sorted(v)))
@@ -347,6 +352,55 @@ def test_engine_option_variants_keep_parity(variant, capsys):
         if family == 'zero_dc':
             for name, _, _, h32 in rows:
                 assert h32[0] < TOL, (variant, name, h32)
+
+
+def _finite_or_same(a, b):
+    a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+    np.testing.assert_array_equal(a, b)                       # (NaN == NaN, inf == inf)
+
+
+def test_split16_out_of_range_activation_falls_back_to_exact_fp32():
+    """models.py:179-198 returns the fp32 result for ANY finite fp32 input; the opt-in split-fp16 products hold |x| < 8 188 only.
+    A crop that drives activations beyond the window must not come back as finite garbage (the ReLU / exp(clamp) epilogues turn the
+    NaN of inf - inf into 0 / 1) nor raise: the launches report it (usot_conv_desc.ovf), the engine re-plans on the exact-fp32 tiles
+    and runs the call again - the results are BIT-EQUAL to an engine that was exact from the start, for this call and every later one."""
+    def make(split):
+        m = USOT()
+        m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True), strict=True)
+        m.eval()
+        m = m.to(DEV)
+        m.pr_pool = False
+        if split:
+            m.engine_options['options'] = {'split16_f32': True}
+        return m
+    ms, me = make(True), make(False)
+    z, x = t(synth.crop(0, 1, 127)).to(DEV), t(synth.crop(1, 1, 255)).to(DEV)
+    mem, sm = t(synth.memory_kernels(7, 7)).to(DEV), torch.full((1, 7), 0.9, device=DEV)
+    for m in (ms, me):
+        m.template(z)
+    a = ms.track(x, template_mem=mem, score_mem=sm)
+    b = me.track(x, template_mem=mem, score_mem=sm)
+    assert ms.engine.opt['split16_f32'] and getattr(ms.engine, 'range_fallbacks', 0) == 0      # in range: the split tiles ran
+    for u, v in zip(a, b):
+        assert rel(npy(u), npy(v)) < TOL
+    assert not all(torch.equal(u, v) for u, v in zip(a, b))
+    # in-range maps, activations far beyond the window from a crop 2000 x brighter
+    big = x * 2000.0
+    with pytest.warns(RuntimeWarning, match='split-fp16'):
+        a = ms.track(big, template_mem=mem, score_mem=sm)
+    b = me.track(big, template_mem=mem, score_mem=sm)
+    assert ms.engine.range_fallbacks == 1 and ms.engine.opt['split16_f32'] is False
+    for u, v in zip(a, b):
+        _finite_or_same(u, v)
+    a = ms.track(x, template_mem=mem, score_mem=sm)           # and it stays on the exact tiles
+    b = me.track(x, template_mem=mem, score_mem=sm)
+    for u, v in zip(a, b):
+        _finite_or_same(u, v)
+    # the feature API likewise
+    ms2 = make(True)
+    f = ms2.engine.features(big)
+    assert ms2.engine.range_fallbacks == 1
+    _finite_or_same(f, me.engine.features(big))
 
 
 def test_engine_options_are_enumerable_and_checked():

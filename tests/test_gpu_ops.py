@@ -51,7 +51,8 @@ def _all_tiles():
     import ctypes
     from usot_amd import build
     n = ctypes.CDLL(build.LIB).usot_conv_tile_count() if os.path.exists(build.LIB) else 60
-    return list(range(0, n + 1))
+    from conftest import tile_params
+    return tile_params(range(0, n + 1))         # ids outside the routed set: `experiments` marker (skipped on the default library)
 
 
 def _tuned_ksplits():
@@ -115,8 +116,27 @@ def test_split_fp16_tiles_range_contract(tile):
     xo[0, 2, 3, 9] = 9.0e3                                   # beyond fp16 / 8: must be visible
     y = hip.conv2d(xo, wd, bd, KH=k, KW=k, pad=(1, 1), tile=tile)
     assert not torch.isfinite(y).all()
+    # ... and REPORTED where an activation would hide it: with a ReLU (or Conf_Fusion's exp(clamp(relu))) the NaN of inf - inf
+    # leaves the epilogue as a finite 0 / 1 (fmaxf(NaN, 0) = 0) - the sticky word of usot_conv_desc.ovf says so before that, for
+    # the plain epilogue, the in-launch split-K combine and the split-K slabs alike; in range it stays 0
+    for act in (hip.ACT_RELU, hip.ACT_CONF):
+        for ks in (1, 3):
+            ovf = torch.zeros(1, dtype=torch.int32, device=DEV)
+            hip.conv2d(xd, wd, bd, KH=k, KW=k, pad=(1, 1), tile=tile, ksplit=ks, act=act, ovf=ovf)
+            assert int(ovf.item()) == 0, (act, ks)
+            y = hip.conv2d(xo, wd, bd, KH=k, KW=k, pad=(1, 1), tile=tile, ksplit=ks, act=act, ovf=ovf)
+            assert int(ovf.item()) == 1, (act, ks)
+            assert torch.isfinite(y).all()                   # the hazard the word exists for: finite garbage
+            hip.conv2d(xd, wd, bd, KH=k, KW=k, pad=(1, 1), tile=tile, ksplit=ks, act=act, ovf=ovf)
+            assert int(ovf.item()) == 1                      # sticky: only the reader clears it
+    xi = xd.clone()
+    xi[0, 5, 5, 3] = float('inf')                            # a non-finite INPUT is reported too
+    ovf = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.conv2d(xi, wd, bd, KH=k, KW=k, pad=(1, 1), tile=tile, act=hip.ACT_RELU, ovf=ovf)
+    assert int(ovf.item()) == 1
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize('tile2', [116, 117])
 def test_split_maps_chain_two_convolutions_without_an_fp32_map(tile2):
     """usot_conv_desc.y_split / x_split: a split-fp16 tile writes its result as a split map (per pixel and 64-channel block the hi
@@ -157,7 +177,7 @@ def test_conv_splitk(ksplit):
     assert rel_err(y.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 2e-5
 
 
-@pytest.mark.parametrize('tile,ks', [(57, 4), (55, 2), (53, 3), (38, 4)])
+@pytest.mark.parametrize('tile,ks', [(57, 4), (55, 2), (53, 3), pytest.param(38, 4, marks=pytest.mark.experiments)])
 def test_conv_deferred_reduction_feeds_the_fused_pair(tile, ks):
     """usot_conv_desc.defer: a split-K convolution that writes its partial tiles and stops (no bias, no activation, no
     combine), and the fused fp32 pointwise pair that sums them - in part order, + bias, ReLU - while it stages its pixel tile
@@ -220,6 +240,7 @@ def test_conv_deferred_reduction_feeds_the_fused_pair(tile, ks):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize('tile', [72, 73, 76])
 def test_conv_streamk_batch_of_problems(tile):
     """Persistent stream-K tiles (conv_igemm_f32_v3p): several problems of different geometry in ONE launch whose workgroups share
@@ -509,8 +530,19 @@ def test_pw_pair_f32_split_fp16_operands(M):
     t2w = t2.clone(); t2w[:, ::7] *= 1e-4; t2w[:, 3::11] *= 300.0
     y64 = F.relu(t2w.double() @ w3.double().t() + b3.double() + res.double())
     t64 = F.relu(y64 @ w1.double().t() + b1.double())
-    y, t = hip.pw_pair_f32(d(t2w).reshape(1, 1, M, cm), *args[1:], split16=True)
+    ovf = torch.zeros(1, dtype=torch.int32, device=DEV)
+    y, t = hip.pw_pair_f32(d(t2w).reshape(1, 1, M, cm), *args[1:], split16=True, ovf=ovf)
     assert rel_err(y.reshape(M, co).cpu().numpy(), y64.numpy()) < 1e-5 and rel_err(t.reshape(M, cn).cpu().numpy(), t64.numpy()) < 1e-5
+    assert int(ovf.item()) == 0
+    # range contract (usot_pw_pair_desc.ovf): one staged value beyond the fp16 window - in the pixel tile (GEMM1's operand) or
+    # produced INTO the Y tile (GEMM2's operand) - is reported in the sticky word although both ReLUs return finite numbers
+    t2o = t2.clone(); t2o[M // 2, 17] = 9.0e3
+    y, t = hip.pw_pair_f32(d(t2o).reshape(1, 1, M, cm), *args[1:], split16=True, ovf=ovf)
+    assert int(ovf.item()) == 1 and torch.isfinite(y).all() and torch.isfinite(t).all()
+    ovf.zero_()
+    reso = res.clone(); reso[M // 3, 5] = 9.5e3              # Y = relu(.. + res) lands beyond the window: GEMM2 sees it
+    hip.pw_pair_f32(args[0], args[1], args[2], d(reso).reshape(1, 1, M, co), args[4], args[5], split16=True, ovf=ovf)
+    assert int(ovf.item()) == 1
 
 
 @pytest.mark.parametrize('K,N,M,res', [(256, 1024, 961, True), (128, 512, 961, True), (1024, 256, 961, False), (512, 128, 1089, False),
@@ -804,7 +836,7 @@ def test_conv_fp16_and_f32_out(case):
 
 
 @pytest.mark.parametrize('case', BF16_CASES)
-@pytest.mark.parametrize("tile", list(range(0, 38)))
+@pytest.mark.parametrize("tile", __import__('conftest').tile_params(range(0, 38), lp=True))
 def test_conv_bf16(case, tile):
     """bf16 MFMA conv vs an fp32 conv on the SAME bf16-rounded operands: the only differences
     are fp32 summation order and the final bf16 rounding (2^-8 relative)."""
@@ -1159,7 +1191,7 @@ def test_pw_panel_lp_expansion_conv(K, N, M, res, act, dtype):
     # the tiled kernel on the same operands (NHWC with H = M, W = 1)
     y2 = torch.empty(M, N, dtype=dtype, device=DEV)
     d = hip.conv_desc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y2.data_ptr(), N=1, H=M, W=1, Cin=K, OH=M, OW=1, Cout=N, KH=1, KW=1,
-                      res=rd.data_ptr() if res else None, act=act, tile=10)
+                      res=rd.data_ptr() if res else None, act=act, tile=11)
     hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d), 1 if dtype == torch.float16 else 0, 0), 'usot_conv2d_lp')
     assert torch.equal(y2, y[:M])
     assert hip.lib().usot_pw_panel_lp(hip.stream(), hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), None, hip.ptr(y), M, K, N + 64, act, 0) != 0
@@ -1191,11 +1223,11 @@ def test_pw_panel_pair_equals_the_two_convolutions(cm, co, cn, M, act2, dtype):
     assert torch.all(y[M:] == 3.0) and torch.all(t[M:] == 3.0)
     y2 = torch.empty(M, co, dtype=dtype, device=DEV)
     d1 = hip.conv_desc(t2d.data_ptr(), w3d.data_ptr(), b3d.data_ptr(), y2.data_ptr(), N=1, H=M, W=1, Cin=cm, OH=M, OW=1, Cout=co, KH=1, KW=1,
-                       res=resd.data_ptr(), act=1, tile=10)
+                       res=resd.data_ptr(), act=1, tile=11)
     hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d1), dt, 0), 'conv3')
     tt = torch.empty(M, cn, dtype=dtype, device=DEV)
     d2 = hip.conv_desc(y2.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), tt.data_ptr(), N=1, H=M, W=1, Cin=co, OH=M, OW=1, Cout=cn, KH=1, KW=1,
-                       act=act2, tile=10)
+                       act=act2, tile=11)
     hip.check(hip.lib().usot_conv2d_lp(hip.stream(), C.byref(d2), dt, 0), 'conv1')
     assert torch.equal(y[:M], y2)
     ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10

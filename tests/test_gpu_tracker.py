@@ -25,11 +25,15 @@ class Info:
     version = 'v1'
 
 
-@pytest.fixture(scope='module')
-def net():
+@pytest.fixture(scope='module', params=['exact_f32', 'split16'])
+def net(request):
+    """exact_f32: the default engine (exact fp32 products); split16: the opt-in split-fp16 products (engine option split16_f32) -
+    every reference trajectory below is tracked on both arithmetic modes."""
     m = USOT()
     m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True), strict=True)
     m.eval()
+    if request.param == 'split16':
+        m.engine_options['options'] = {'split16_f32': True}
     return m.cuda()
 
 
@@ -233,6 +237,60 @@ def test_sessions_on_separate_streams_overlap_safely(net):
         np.testing.assert_array_equal(np.array(got[k]), np.array(want[k]))
 
 
+def _fresh(split):
+    m = USOT()
+    m.load_state_dict(synth.torch_state_dict(m, seed=0, calibrated=True), strict=True)
+    m.eval()
+    if split:
+        m.engine_options['options'] = {'split16_f32': True}
+    return m.cuda()
+
+
+def test_session_frame_beyond_the_split16_window_reruns_on_exact_fp32():
+    """A drop-in run must not die (or track on garbage) when a checkpoint drives ONE frame's activations beyond the fp16 window of
+    the opt-in split-fp16 products: the frame graph's launches report it (usot_conv_desc.ovf -> decode's out[9]), the session rebuilds
+    its graph on the exact-fp32 tiles and runs the SAME frame again.  (a) template, bank and memory encodings prepared by an exact
+    engine, only the frame graph on split tiles: the out-of-range frame and every later one are BIT-EQUAL to an exact-fp32 session;
+    (b) a session that lived on split tiles from the start tracks on through such a frame within the tracker's tolerance."""
+    picks = [[0, 0, 0, 0, 0], [0, 1, 0, 1, 0], [2, 1, 0, 2, 1], [1, 2, 3, 1, 0]]
+    ne = _fresh(False)
+    se, crops = _open(ne, 5)
+    # (a)
+    na = _fresh(False)
+    sa, _ = _open(na, 5)
+    na.engine.opt['split16_f32'] = True
+    sa._build()                                       # the frame graph, rebuilt on the split-fp16 tiles
+    assert sa._ovf is not None and se._ovf is None
+    frames = [crops[0] * 2000.0, crops[1], crops[2], crops[3]]
+    for i, x in enumerate(frames):
+        if i == 0:
+            with pytest.warns(RuntimeWarning, match='split-fp16'):
+                a = sa.frame(x, picks[i], (63.5, 63.5))
+        else:
+            a = sa.frame(x, picks[i], (63.5, 63.5))
+        b = se.frame(x, picks[i], (63.5, 63.5))
+        np.testing.assert_array_equal(a, b)
+    assert na.engine.range_fallbacks == 1 and na.engine.opt['split16_f32'] is False and sa._ovf is None
+    assert sa.n == se.n == 5
+    torch.cuda.synchronize()
+    assert torch.equal(sa.bank[:2 + sa.n], se.bank[:2 + se.n])
+    for g in range(3):
+        assert torch.equal(sa.bank_enc[g][:2 + sa.n], se.bank_enc[g][:2 + se.n])
+    # (b)
+    nb = _fresh(True)
+    sb, _ = _open(nb, 5)
+    se2, _ = _open(ne, 5)
+    frames = [crops[0], crops[1], crops[2] * 2000.0, crops[3]]
+    for i, x in enumerate(frames):
+        a = sb.frame(x, picks[i], (63.5, 63.5))
+        b = se2.frame(x, picks[i], (63.5, 63.5))
+        fin = np.isfinite(b)
+        assert (np.isfinite(a) == fin).all()
+        np.testing.assert_allclose(a[fin], b[fin], atol=2e-3, rtol=1e-3)
+        assert (nb.engine.range_fallbacks if hasattr(nb.engine, 'range_fallbacks') else 0) == (1 if i >= 2 else 0)
+    assert sb.n == 5
+
+
 def test_session_cached_encodings_equal_reencoding(net):
     """The session encodes a memory feature once, when it is appended; the reference re-encodes the picked
     features every frame (connect.py:251-255).  After a few frames every cached row must equal a fresh
@@ -256,7 +314,7 @@ def test_session_cached_encodings_equal_reencoding(net):
 
 
 def test_deferred_append_equals_the_append_behind_the_tag():
-    """engine option `defer_append` (default on): frame t's bank append (encode the pooled feature, scatter it and its three
+    """engine option `defer_append` (default OFF): frame t's bank append (encode the pooled feature, scatter it and its three
     encodings) runs on a side branch at the start of frame t + 1's graph instead of behind frame t's result tag.  Same kernels,
     same operands: results of a frame sequence whose picks always include the newest row, and the bank itself after flush(),
     must equal the undeferred session's bit for bit — also across a regrow of the bank and an append_feature() from outside."""

@@ -9,6 +9,12 @@ CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(CSRC, 'libusot_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC]
+# USOT_EXPERIMENTS=1 in the environment: compile the experimental conv tiles too (csrc/conv_igemm.hip / conv_bf16.hip: the ids no
+# tuning table routes - lab notebook A.3); the default library holds the routed tiles only.  Part of csrc_tree(): the two builds
+# never share counters or objects silently.
+EXPERIMENTS = os.environ.get('USOT_EXPERIMENTS', '0') == '1'
+if EXPERIMENTS:
+    FLAGS = FLAGS[:4] + ['-DUSOT_EXPERIMENTS'] + FLAGS[4:]
 # per-file flags.  xcorr.hip: hipcc's SLP vectoriser packs the depthwise FMAs into v_pk_fma_f32 pairs, which
 # on gfx950 run at the scalar-FMA rate but need operand pairs in adjacent registers: the LDS-DMA GroupDW
 # kernel goes from 109 VGPRs to 256 + spills with it
@@ -31,6 +37,8 @@ def csrc_tree():
         with open(f, 'rb') as fh:
             h.update(fh.read())
     h.update(repr((FLAGS[:4], sorted(FILE_FLAGS.items()))).encode())     # include paths differ between boxes: the first four flags only
+    if EXPERIMENTS:
+        h.update(b'USOT_EXPERIMENTS')
     return h.hexdigest()[:16]
 
 

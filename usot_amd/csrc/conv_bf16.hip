@@ -727,43 +727,50 @@ struct TileB { int bm, bn; void (*fn)(const ConvB); void (*fn16)(const ConvB); i
 #define TB32(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0, 2, 32>, conv_igemm_bf16<bm, bn, wm, wn, true, 0, 2, 32>, wm * wn * 64, 2 }
 #define TBP(bm, bn, wm, wn, pf) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0, 2, 16, pf>, conv_igemm_bf16<bm, bn, wm, wn, true, 0, 2, 16, pf>, wm * wn * 64, 2, pf }
 #define TB3(bm, bn, wm, wn) { bm, bn, conv_igemm_bf16<bm, bn, wm, wn, false, 0, 3>, conv_igemm_bf16<bm, bn, wm, wn, true, 0, 3>, wm * wn * 64, 3 }
+// As in conv_igemm.hip: the default build compiles the ROUTED tiles (usot_amd/data/tuning_lp_gfx950.json, the launcher's heuristic
+// below, and tile 21 - the plain form of tile 32's loop); the other ids are empty slots unless built with -DUSOT_EXPERIMENTS.
+#ifdef USOT_EXPERIMENTS
+#define XTB(...) __VA_ARGS__
+#else
+#define XTB(...) TileB{0, 0, nullptr, nullptr, 0, 0}
+#endif
 const TileB kTilesB[] = {
     TB(128, 128, 2, 2),   // 1
-    TB(128, 64, 2, 2),    // 2
-    TB(64, 128, 2, 2),    // 3
+    XTB(TB(128, 64, 2, 2)),    // 2
+    XTB(TB(64, 128, 2, 2)),    // 3
     TB(64, 64, 2, 2),     // 4
     TB(32, 64, 2, 2),     // 5
-    TB2(128, 128, 2, 2),  // 6: two k-tiles of loads in flight
-    TB2(128, 64, 2, 2),   // 7
-    TB2(64, 128, 2, 2),   // 8
-    TB2(64, 64, 2, 2),    // 9
-    TB0(128, 128, 2, 2),  // 10: LDS-DMA staging
+    XTB(TB2(128, 128, 2, 2)),  // 6: two k-tiles of loads in flight
+    XTB(TB2(128, 64, 2, 2)),   // 7
+    XTB(TB2(64, 128, 2, 2)),   // 8
+    XTB(TB2(64, 64, 2, 2)),    // 9
+    XTB(TB0(128, 128, 2, 2)),  // 10: LDS-DMA staging
     TB0(128, 64, 2, 2),   // 11
     TB0(64, 128, 2, 2),   // 12
     TB0(64, 64, 2, 2),    // 13
     TB0(32, 64, 2, 2),    // 14
-    TB3(256, 128, 4, 2),  // 15: 8 wavefronts, 3-stage LDS-DMA pipeline
-    TB3(128, 256, 2, 4),  // 16
-    TB3(128, 128, 2, 2),  // 17: 4 wavefronts, 3 stages (one workgroup per CU)
-    TB08(256, 256, 2, 4), // 18: 8 wavefronts x (128 pixels x 64 channels), 2-stage LDS-DMA
-    TB08(256, 128, 4, 2), // 19
-    TB08(128, 256, 2, 4), // 20
+    XTB(TB3(256, 128, 4, 2)),  // 15: 8 wavefronts, 3-stage LDS-DMA pipeline
+    XTB(TB3(128, 256, 2, 4)),  // 16
+    XTB(TB3(128, 128, 2, 2)),  // 17: 4 wavefronts, 3 stages (one workgroup per CU)
+    XTB(TB08(256, 256, 2, 4)), // 18: 8 wavefronts x (128 pixels x 64 channels), 2-stage LDS-DMA
+    XTB(TB08(256, 128, 4, 2)), // 19
+    XTB(TB08(128, 256, 2, 4)), // 20
     TB08(256, 256, 4, 4), // 21: 16 wavefronts x (64 x 64)
-    TB08(256, 256, 4, 2), // 22: 8 wavefronts x (64 pixels x 128 channels)
-    TB08(256, 128, 4, 4), // 23: 16 wavefronts x (64 x 32)
-    TB08(128, 256, 2, 8), // 24: 16 wavefronts x (64 x 32)
+    XTB(TB08(256, 256, 4, 2)), // 22: 8 wavefronts x (64 pixels x 128 channels)
+    XTB(TB08(256, 128, 4, 4)), // 23: 16 wavefronts x (64 x 32)
+    XTB(TB08(128, 256, 2, 8)), // 24: 16 wavefronts x (64 x 32)
     TB08(128, 128, 4, 4), // 25: 16 wavefronts x (32 x 32)
     TB32(256, 256, 4, 4), // 26: as 21 on v_mfma_f32_32x32x16 (2 x 2 tiles of 32 per wave)
-    TB32(256, 256, 4, 2), // 27: 8 wavefronts x (64 pixels x 128 channels), 32x32 MFMA
-    TB32(256, 256, 2, 4), // 28: 8 wavefronts x (128 x 64)
-    TB32(128, 128, 4, 4), // 29: as 25 (one 32x32 tile per wave)
-    TB32(256, 128, 4, 2), // 30: 8 wavefronts x (64 x 64)
-    TB32(128, 256, 2, 4), // 31
+    XTB(TB32(256, 256, 4, 2)), // 27: 8 wavefronts x (64 pixels x 128 channels), 32x32 MFMA
+    XTB(TB32(256, 256, 2, 4)), // 28: 8 wavefronts x (128 x 64)
+    XTB(TB32(128, 128, 4, 4)), // 29: as 25 (one 32x32 tile per wave)
+    XTB(TB32(256, 128, 4, 2)), // 30: 8 wavefronts x (64 x 64)
+    XTB(TB32(128, 256, 2, 4)), // 31
     TBP(256, 256, 4, 4, 1),   // 32: tile 21 with the asm two-stage loop (integer LDS addresses, zero page from the kernel arguments)
-    TBP(256, 256, 4, 4, 3),   // 33: + the filter lines of k-tile t + 3 pulled into L2 by a 4-byte-per-line LDS-DMA (slower: below)
-    TBP(256, 256, 4, 4, 7),   // 34: + the activation lines
-    TBP(256, 256, 4, 4, 9),   // 35: tile 32 with the fragment reads of the k-tile's first half before the DMA issue
-    TBP(256, 256, 4, 4, 17),  // 36: THREE activation stages + two filter stages (all 160 KB): the 1024 -> 256 reductions' HBM stream
+    XTB(TBP(256, 256, 4, 4, 3)),   // 33: + the filter lines of k-tile t + 3 pulled into L2 by a 4-byte-per-line LDS-DMA (slower: below)
+    XTB(TBP(256, 256, 4, 4, 7)),   // 34: + the activation lines
+    XTB(TBP(256, 256, 4, 4, 9)),   // 35: tile 32 with the fragment reads of the k-tile's first half before the DMA issue
+    XTB(TBP(256, 256, 4, 4, 17)),  // 36: THREE activation stages + two filter stages (all 160 KB): the 1024 -> 256 reductions' HBM stream
     TBP(128, 128, 4, 4, 1),   // 37: tile 25 on the asm loop (layer2's 3x3 convs, N = 128: 27.0 -> 25.9 us isolated; 256 x 128 forms 25.4 / 28.4)
     // (Round 4, isolated on layer3's shortcut conv / its conv2 / layer2's shortcut conv, us per launch: tile 21 439 / 60.8 / 120;
     //  32: 427 / 60.4 / 119; 33: 468 / 65.7 / 134; 34: 504 / 69.0 / 140; 35: 424 / 59.5 / 120.  The prefetch variants test the
@@ -1037,6 +1044,7 @@ __global__ __launch_bounds__(256, USOT_STEM_MINW) void stem_pool_lp_kernel(
 }  // namespace
 
 extern "C" int usot_conv_bf16_tile_count(void) { return kNumTilesB; }
+extern "C" int usot_conv_bf16_tile_built(int tile) { return (tile >= 1 && tile <= kNumTilesB && kTilesB[tile - 1].fn) ? 1 : 0; }
 
 /* bf16|fp16 NHWC conv: x/w/res/y in the storage type (uint16), bias fp32.  Uses the fields N..dil_w,
  * act/act2/act_split, groups (+ x_gs, w_gs, b_gs, y_gs), tile of usot_conv_desc; y dense NHWC
@@ -1073,6 +1081,7 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     }
     if (tile < 1 || tile > kNumTilesB) return USOT_EINVAL;
     const TileB &tc = kTilesB[tile - 1];
+    if (!tc.fn) return USOT_ENOTBUILT;
     p.MT = (p.M + tc.bm - 1) / tc.bm;
     p.NT = (d->Cout + tc.bn - 1) / tc.bn;
     p.nfast = 1;

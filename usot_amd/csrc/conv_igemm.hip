@@ -53,6 +53,7 @@ struct ConvK {
     const float *wscale;                // split-fp16 tiles (PF = 4): 1 / (filter row scale x activation scale) per output channel
     const float *zero;                  // PF = 6: 16 zero bytes, the source of padding taps for the activation DMA
     int x_split, y_split;               // the input map arrives / the result leaves in the split-fp16 layout (usot_conv_desc)
+    int *ovf;                           // split-fp16 tiles: sticky "a finished sum was not finite" word (usot_conv_desc.ovf) or nullptr
 };
 
 // Up to four convolutions of DIFFERENT geometry in one launch (same tile shape): the shortcut
@@ -1215,7 +1216,7 @@ __global__ __launch_bounds__(PF == 6 ? 64 * WM * WN + 768 : 64 * WM * WN + 64 * 
         pb[i] = (cok && p.bias) ? *(const f32x4 *)(p.bias + (long)g * p.b_gs + co) : f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (H16) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) psc[i][e] = co + e < p.Cout ? p.wscale[(long)g * p.Cout + co + e] : 0.f;
+            for (int e = 0; e < 4; ++e) psc[i][e] = co + e < p.Cout ? p.wscale[(long)g * p.b_gs + co + e] : 0.f;      // (the bias' group stride: rows of the bank per group)
         }
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
@@ -1353,6 +1354,20 @@ __global__ __launch_bounds__(PF == 6 ? 64 * WM * WN + 768 : 64 * WM * WN + 64 * 
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc[i][j] *= psc[i];
+        // Range contract, enforced: an activation beyond the fp16 window was staged as hi = inf, lo = -inf and every sum it entered is
+        // NaN (inf - inf) by now; the epilogues below would turn that into a FINITE number (fmaxf(NaN, 0) = 0, exp(0) = 1).  Say so in
+        // the caller's sticky word before bias / activation / the split-K slabs see the sums: the engine re-runs the frame on the
+        // exact-fp32 tiles.  One class test per accumulator register, once per launch - nothing in the k-loop.
+        if (p.ovf) {
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bad |= !(__builtin_fabsf(acc[i][j][e]) <= 3.4028234664e38f);
+            if (bad) __hip_atomic_store(p.ovf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 
     if (p.ksplit > 1) {
@@ -2403,129 +2418,139 @@ struct TileCfg { int bm, bn, bk, stages, ksw; void (*fn)(const ConvBatch); int t
 #define TILEHD(bm, bn, wm, wn, d, npw) { bm, bn, 64, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, 64, d, npw, 5>, 64 * wm * wn + 64 * npw + 256, d, 2, 5 }
 #define TILEHX(bm, bn, wm, wn) { bm, bn, 64, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, 64, 2, 4, 6>, 64 * wm * wn + 768, 2, 2, 6 }
 #define TILE5(bm, bn, wm, wn, bk, d) { bm, bn, bk, 3, 1, conv_igemm_f32_v3<bm, bn, wm, wn, bk, d>, 512, d, 0, 0 }
+// The DEFAULT build compiles the ROUTED tiles only: the ids the tuning tables (usot_amd/data/tuning_gfx950.json, tuning_split16_gfx950.json),
+// engine.SPLIT16_TILES, the engine's deferred-launch options and pick_tile() below can select (tests/test_abi_and_build.py asserts the
+// two sets are equal).  Every other id - the experiments the lab notebook records as "parity-green, measured slower, not routed" - keeps
+// its NUMBER but is an empty slot unless the library is built with -DUSOT_EXPERIMENTS (usot_amd/build.py: USOT_EXPERIMENTS=1); the
+// launcher answers USOT_ENOTBUILT for it and usot_conv_tile_built() says so up front.
+#ifdef USOT_EXPERIMENTS
+#define XT(...) __VA_ARGS__
+#else
+#define XT(...) TileCfg{0, 0, 0, 0, 0, nullptr, 0, 0, 0, 0}
+#endif
 const TileCfg kTiles[] = {
     TILE(128, 128, 2, 2),   // 1: batched backbone
     TILE(128, 64, 2, 2),    // 2
-    TILE(64, 128, 2, 2),    // 3
+    XT(TILE(64, 128, 2, 2)),    // 3
     TILE(64, 64, 2, 2),     // 4
     TILE(32, 64, 2, 2),     // 5
-    TILE(64, 32, 2, 2),     // 6
+    XT(TILE(64, 32, 2, 2)),     // 6
     TILE(32, 32, 2, 2),     // 7
     TILE(16, 64, 1, 4),     // 8: tiny M (template-side encoders)
-    TILE(16, 128, 1, 4),    // 9
-    TILE(32, 128, 2, 2),    // 10
-    TILE2(128, 128, 2, 2, 32),  // 11: v2 (3-stage, mid-tile barrier)
-    TILE2(64, 64, 2, 2, 32),    // 12
-    TILE2(64, 64, 2, 2, 64),    // 13
+    XT(TILE(16, 128, 1, 4)),    // 9
+    XT(TILE(32, 128, 2, 2)),    // 10
+    XT(TILE2(128, 128, 2, 2, 32)),  // 11: v2 (3-stage, mid-tile barrier)
+    XT(TILE2(64, 64, 2, 2, 32)),    // 12
+    XT(TILE2(64, 64, 2, 2, 64)),    // 13
     TILE2(32, 64, 2, 2, 32),    // 14
     TILE2(32, 64, 2, 2, 64),    // 15
     TILE2(32, 32, 2, 2, 64),    // 16
-    TILE2(64, 128, 2, 2, 32),   // 17
-    TILE2(128, 64, 2, 2, 32),   // 18
-    TILE2(32, 128, 2, 2, 32),   // 19
+    XT(TILE2(64, 128, 2, 2, 32)),   // 17
+    XT(TILE2(128, 64, 2, 2, 32)),   // 18
+    XT(TILE2(32, 128, 2, 2, 32)),   // 19
     TILE2(16, 64, 1, 4, 64),    // 20
-    TILE2(64, 32, 2, 2, 64),    // 21
-    TILE3(32, 64, 2, 2, 64, 2), // 22: in-workgroup k-split, 8 waves
-    TILE3(32, 32, 2, 2, 64, 2), // 23
-    TILE3(32, 32, 2, 2, 32, 4), // 24: 16 waves
-    TILE3(64, 64, 2, 2, 32, 2), // 25
+    XT(TILE2(64, 32, 2, 2, 64)),    // 21
+    XT(TILE3(32, 64, 2, 2, 64, 2)), // 22: in-workgroup k-split, 8 waves
+    XT(TILE3(32, 32, 2, 2, 64, 2)), // 23
+    XT(TILE3(32, 32, 2, 2, 32, 4)), // 24: 16 waves
+    XT(TILE3(64, 64, 2, 2, 32, 2)), // 25
     TILE3(16, 64, 1, 4, 64, 2), // 26
-    TILE3(32, 64, 2, 2, 32, 2), // 27
-    TILE3(16, 64, 1, 4, 32, 4), // 28
+    XT(TILE3(32, 64, 2, 2, 32, 2)), // 27
+    XT(TILE3(16, 64, 1, 4, 32, 4)), // 28
     TILE4(64, 64, 2, 2, 32),    // 29: v3 producer/consumer waves
-    TILE4(64, 64, 2, 2, 64),    // 30
+    XT(TILE4(64, 64, 2, 2, 64)),    // 30
     TILE4(32, 64, 2, 2, 64),    // 31
-    TILE4(128, 128, 2, 2, 32),  // 32
+    XT(TILE4(128, 128, 2, 2, 32)),  // 32
     TILE4(32, 32, 2, 2, 64),    // 33
-    TILE4(64, 128, 2, 2, 32),   // 34
-    TILE4(128, 64, 2, 2, 32),   // 35
-    TILE4(32, 128, 2, 2, 64),   // 36
-    TILE5(64, 64, 2, 2, 32, 2),    // 37: v3, two k-tiles of loads in flight per producer
-    TILE5(64, 64, 2, 2, 64, 2),    // 38
+    XT(TILE4(64, 128, 2, 2, 32)),   // 34
+    XT(TILE4(128, 64, 2, 2, 32)),   // 35
+    XT(TILE4(32, 128, 2, 2, 64)),   // 36
+    XT(TILE5(64, 64, 2, 2, 32, 2)),    // 37: v3, two k-tiles of loads in flight per producer
+    XT(TILE5(64, 64, 2, 2, 64, 2)),    // 38
     TILE5(32, 64, 2, 2, 64, 2),    // 39
-    TILE5(128, 128, 2, 2, 32, 2),  // 40
+    XT(TILE5(128, 128, 2, 2, 32, 2)),  // 40
     TILE5(32, 32, 2, 2, 64, 2),    // 41
-    TILE5(64, 128, 2, 2, 32, 2),   // 42
-    TILE5(128, 64, 2, 2, 32, 2),   // 43
-    TILE5(32, 128, 2, 2, 64, 2),   // 44
-    TILE5(64, 64, 2, 2, 32, 3),    // 45: three in flight
-    TILE5(64, 64, 2, 2, 64, 3),    // 46
-    TILE5(32, 64, 2, 2, 64, 3),    // 47
-    TILE5(128, 128, 2, 2, 32, 3),  // 48
+    XT(TILE5(64, 128, 2, 2, 32, 2)),   // 42
+    XT(TILE5(128, 64, 2, 2, 32, 2)),   // 43
+    XT(TILE5(32, 128, 2, 2, 64, 2)),   // 44
+    XT(TILE5(64, 64, 2, 2, 32, 3)),    // 45: three in flight
+    XT(TILE5(64, 64, 2, 2, 64, 3)),    // 46
+    XT(TILE5(32, 64, 2, 2, 64, 3)),    // 47
+    XT(TILE5(128, 128, 2, 2, 32, 3)),  // 48
     TILE5(32, 32, 2, 2, 64, 3),    // 49
-    TILE5(64, 128, 2, 2, 32, 3),   // 50
-    TILE5(128, 64, 2, 2, 32, 3),   // 51
-    TILE5(32, 128, 2, 2, 64, 3),   // 52
+    XT(TILE5(64, 128, 2, 2, 32, 3)),   // 50
+    XT(TILE5(128, 64, 2, 2, 32, 3)),   // 51
+    XT(TILE5(32, 128, 2, 2, 64, 3)),   // 52
     TILE10(32, 32, 2, 2, 64, 2, 8),   // 53: eight producer waves
     TILE10(32, 32, 2, 2, 64, 3, 8),   // 54
     TILE10(32, 64, 2, 2, 64, 2, 8),   // 55
     TILE10(32, 64, 2, 2, 64, 3, 8),   // 56
     TILE10(64, 64, 2, 2, 64, 2, 8),   // 57
-    TILE10(64, 64, 2, 2, 32, 2, 8),   // 58
-    TILE10(32, 128, 2, 2, 64, 2, 8),  // 59
-    TILE10(64, 32, 2, 2, 64, 2, 8),   // 60
-    TILEW(32, 64, 2, 4, 3),           // 61: weight-streaming consumers (filters in fragment order, usot_conv_pack_wfrag_f32); 1 x 4 waves
-    TILEW(32, 64, 2, 4, 2),           // 62
-    TILEW(64, 64, 2, 4, 3),           // 63
-    TILEW2(32, 64, 2, 4, 2),          // 64: the same, consumer waves 2 x 2 (a wave pair shares its filter fragments through L1)
-    TILEW2(64, 64, 2, 4, 2),          // 65
-    TILE11(32, 64, 2, 2, 64, 2, 4),   // 66: v3 with fragment reads two rounds ahead (PF = 2)
-    TILE11(32, 32, 2, 2, 64, 2, 8),   // 67
-    TILES(18, 1),                     // 68: weight-stationary, K = 2304 (3 x 3 x 256)
-    TILES(9, 1),                      // 69: K = 1152 (3 x 3 x 128)
-    TILESB(18, 1),                    // 70: K = 2304, blocked accumulation (64-product blocks + running total)
-    TILES(8, 1),                      // 71: K = 1024
-    TILEP(64, 64, 2, 2, 2, 8),        // 72: v3 as a persistent stream-K launch (whole-chip rounds)
-    TILEP(32, 64, 2, 2, 2, 8),        // 73
-    TILEP(64, 64, 2, 2, 3, 8),        // 74
-    TILEP(64, 64, 2, 2, 2, 4),        // 75
-    TILEP(32, 32, 2, 2, 3, 8),        // 76
-    TILEP32(64, 64, 2, 2, 2, 8),      // 77: k-tiles of 32
-    TILEP32(128, 64, 2, 2, 2, 4),     // 78
+    XT(TILE10(64, 64, 2, 2, 32, 2, 8)),   // 58
+    XT(TILE10(32, 128, 2, 2, 64, 2, 8)),  // 59
+    XT(TILE10(64, 32, 2, 2, 64, 2, 8)),   // 60
+    XT(TILEW(32, 64, 2, 4, 3)),           // 61: weight-streaming consumers (filters in fragment order, usot_conv_pack_wfrag_f32); 1 x 4 waves
+    XT(TILEW(32, 64, 2, 4, 2)),           // 62
+    XT(TILEW(64, 64, 2, 4, 3)),           // 63
+    XT(TILEW2(32, 64, 2, 4, 2)),          // 64: the same, consumer waves 2 x 2 (a wave pair shares its filter fragments through L1)
+    XT(TILEW2(64, 64, 2, 4, 2)),          // 65
+    XT(TILE11(32, 64, 2, 2, 64, 2, 4)),   // 66: v3 with fragment reads two rounds ahead (PF = 2)
+    XT(TILE11(32, 32, 2, 2, 64, 2, 8)),   // 67
+    XT(TILES(18, 1)),                     // 68: weight-stationary, K = 2304 (3 x 3 x 256)
+    XT(TILES(9, 1)),                      // 69: K = 1152 (3 x 3 x 128)
+    XT(TILESB(18, 1)),                    // 70: K = 2304, blocked accumulation (64-product blocks + running total)
+    XT(TILES(8, 1)),                      // 71: K = 1024
+    XT(TILEP(64, 64, 2, 2, 2, 8)),        // 72: v3 as a persistent stream-K launch (whole-chip rounds)
+    XT(TILEP(32, 64, 2, 2, 2, 8)),        // 73
+    XT(TILEP(64, 64, 2, 2, 3, 8)),        // 74
+    XT(TILEP(64, 64, 2, 2, 2, 4)),        // 75
+    XT(TILEP(32, 32, 2, 2, 3, 8)),        // 76
+    XT(TILEP32(64, 64, 2, 2, 2, 8)),      // 77: k-tiles of 32
+    XT(TILEP32(128, 64, 2, 2, 2, 4)),     // 78
     // (72-78, round 5: parity-green; Conf_Fusion's conv isolated 120 (v3 32 x 64) -> 111 us on tile 74 - 64 x 64 tiles without the
     //  three-round quantisation - but INSIDE the frame 111.6 -> 119.5 us and the graph +13 us; the three search encoders 74.6 -> 71.1
     //  per op, graph +10; shortcut conv + conv1 97 -> 132.  128 x 64 / 64 x 128 / 128 x 128 shapes spill at 768 threads.  Not in
     //  the tuning table)
     // (61-67: parity-green, none faster than v3 - DESIGN.md section 3.1 "what a k-step waits for")
-    TILE12(32, 64, 2, 4, 64, 2, 8),   // 79: v3 with EIGHT consumer waves (two per SIMD) on the same tile: 16 x 16 wave tiles
-    TILE12(32, 64, 2, 4, 64, 3, 8),   // 80
-    TILE12(64, 64, 2, 4, 64, 2, 8),   // 81: 32 x 16 wave tiles
-    TILE12(64, 64, 4, 2, 64, 2, 8),   // 82: 16 x 32
-    TILE12(64, 32, 4, 2, 64, 2, 8),   // 83: 16 x 16
-    TILE12(32, 64, 2, 4, 64, 2, 4),   // 84
-    TILE12(64, 64, 2, 4, 64, 3, 8),   // 85
-    TILE13(32, 64, 2, 2, 64, 2, 8),   // 86: v3 with the consumer's fragment reads hand-scheduled (PF = 3: asm reads two rounds ahead, counted waits)
-    TILE13(32, 64, 2, 2, 64, 3, 8),   // 87
-    TILE13(32, 32, 2, 2, 64, 2, 8),   // 88
-    TILE13(32, 32, 2, 2, 64, 3, 8),   // 89
-    TILE13(64, 64, 2, 2, 64, 2, 8),   // 90
+    XT(TILE12(32, 64, 2, 4, 64, 2, 8)),   // 79: v3 with EIGHT consumer waves (two per SIMD) on the same tile: 16 x 16 wave tiles
+    XT(TILE12(32, 64, 2, 4, 64, 3, 8)),   // 80
+    XT(TILE12(64, 64, 2, 4, 64, 2, 8)),   // 81: 32 x 16 wave tiles
+    XT(TILE12(64, 64, 4, 2, 64, 2, 8)),   // 82: 16 x 32
+    XT(TILE12(64, 32, 4, 2, 64, 2, 8)),   // 83: 16 x 16
+    XT(TILE12(32, 64, 2, 4, 64, 2, 4)),   // 84
+    XT(TILE12(64, 64, 2, 4, 64, 3, 8)),   // 85
+    XT(TILE13(32, 64, 2, 2, 64, 2, 8)),   // 86: v3 with the consumer's fragment reads hand-scheduled (PF = 3: asm reads two rounds ahead, counted waits)
+    XT(TILE13(32, 64, 2, 2, 64, 3, 8)),   // 87
+    XT(TILE13(32, 32, 2, 2, 64, 2, 8)),   // 88
+    XT(TILE13(32, 32, 2, 2, 64, 3, 8)),   // 89
+    XT(TILE13(64, 64, 2, 2, 64, 2, 8)),   // 90
     TILEH(32, 64, 2, 2, 2, 8),        // 91: v3 on SPLIT-fp16 arithmetic (PF = 4: filters pre-split, usot_conv_desc.w_frag = 2 + w_scale)
     TILEH(32, 64, 2, 2, 3, 8),        // 92
-    TILEH(32, 64, 2, 2, 4, 8),        // 93
+    XT(TILEH(32, 64, 2, 2, 4, 8)),        // 93
     TILEH(32, 32, 2, 2, 2, 8),        // 94
     TILEH(32, 32, 2, 2, 3, 8),        // 95
-    TILEH(32, 32, 2, 2, 4, 8),        // 96
+    XT(TILEH(32, 32, 2, 2, 4, 8)),        // 96
     TILEH(64, 64, 2, 2, 2, 8),        // 97
-    TILEH(64, 64, 2, 2, 3, 8),        // 98
+    XT(TILEH(64, 64, 2, 2, 3, 8)),        // 98
     TILEH(32, 64, 2, 2, 2, 4),        // 99
-    TILEH(32, 64, 2, 2, 4, 4),        // 100
-    TILEH(64, 64, 2, 2, 4, 8),        // 101
-    TILEH(32, 128, 2, 2, 2, 8),       // 102
-    TILEH(64, 128, 2, 2, 2, 8),       // 103
+    XT(TILEH(32, 64, 2, 2, 4, 4)),        // 100
+    XT(TILEH(64, 64, 2, 2, 4, 8)),        // 101
+    XT(TILEH(32, 128, 2, 2, 2, 8)),       // 102
+    XT(TILEH(64, 128, 2, 2, 2, 8)),       // 103
     TILEH(32, 32, 2, 2, 2, 4),        // 104
-    TILEHD(32, 64, 2, 2, 2, 4),       // 105: split-fp16 with the filter tile moved by four LDS-DMA wavefronts into five stages (PF = 5)
+    XT(TILEHD(32, 64, 2, 2, 2, 4)),       // 105: split-fp16 with the filter tile moved by four LDS-DMA wavefronts into five stages (PF = 5)
     TILEHD(32, 64, 2, 2, 3, 4),       // 106
     TILEHD(32, 64, 2, 2, 2, 8),       // 107
-    TILEHD(32, 32, 2, 2, 2, 4),       // 108
-    TILEHD(64, 64, 2, 2, 2, 4),       // 109
-    TILEHD(64, 64, 2, 2, 2, 8),       // 110
+    XT(TILEHD(32, 32, 2, 2, 2, 4)),       // 108
+    XT(TILEHD(64, 64, 2, 2, 2, 4)),       // 109
+    XT(TILEHD(64, 64, 2, 2, 2, 8)),       // 110
     TILEHD(32, 32, 2, 2, 3, 4),       // 111
-    TILEHD(64, 64, 2, 2, 3, 4),       // 112
-    TILEHD(32, 64, 2, 2, 4, 4),       // 113: D = 4 and SIX filter stages (the DMA five k-tiles ahead)
-    TILEHD(32, 32, 2, 2, 4, 4),       // 114
-    TILEHD(32, 64, 2, 2, 4, 8),       // 115
-    TILEHX(32, 64, 2, 2),             // 116: split-fp16, BOTH operands by LDS-DMA (PF = 6): the input map arrives split (usot_conv_desc.x_split), no producer waves
-    TILEHX(32, 32, 2, 2),             // 117
+    XT(TILEHD(64, 64, 2, 2, 3, 4)),       // 112
+    XT(TILEHD(32, 64, 2, 2, 4, 4)),       // 113: D = 4 and SIX filter stages (the DMA five k-tiles ahead)
+    XT(TILEHD(32, 32, 2, 2, 4, 4)),       // 114
+    XT(TILEHD(32, 64, 2, 2, 4, 8)),       // 115
+    XT(TILEHX(32, 64, 2, 2)),             // 116: split-fp16, BOTH operands by LDS-DMA (PF = 6): the input map arrives split (usot_conv_desc.x_split), no producer waves
+    XT(TILEHX(32, 32, 2, 2)),             // 117
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -2549,6 +2574,21 @@ int pick_tile(const usot_conv_desc *d, int M)
 
 extern "C" int usot_conv_tile_count(void) { return kNumTiles; }
 
+extern "C" int usot_conv_tile_built(int tile)
+{
+    if (tile < 1 || tile > kNumTiles) return 0;
+    return (kTiles[tile - 1].fn || kTiles[tile - 1].skfn) ? 1 : 0;
+}
+
+extern "C" int usot_experiments_built(void)
+{
+#ifdef USOT_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int usot_conv_tile_info(int tile, int *bm, int *bn)
 {
     if (tile < 1 || tile > kNumTiles) return USOT_EINVAL;
@@ -2563,6 +2603,7 @@ extern "C" int usot_conv_tile_name(int tile, char *buf, int len)
 {
     if (tile < 1 || tile > kNumTiles || !buf || len < 8) return USOT_EINVAL;
     const TileCfg &t = kTiles[tile - 1];
+    if (!t.fn && !t.skfn) { snprintf(buf, len, "(tile %d: experiments build only)", tile); return USOT_OK; }
     if (t.nst) { snprintf(buf, len, "conv_wstat_f32<NST=%d,RPS=%d>", t.nst, t.rps); return USOT_OK; }
     if (t.skfn) { snprintf(buf, len, "conv_igemm_f32_v3p<%d,%d,BK=%d,D=%d,NPW=%d>", t.bm, t.bn, t.bk, t.depth, (t.threads - 256) / 64); return USOT_OK; }
     if (t.wfrag == 2 && t.dw == 6) { snprintf(buf, len, "conv_igemm_f32_v3<%d,%d,BK=%d,PF=6>", t.bm, t.bn, t.bk); return USOT_OK; }
@@ -2682,7 +2723,7 @@ int fill_params(const usot_conv_desc *d, ConvK &p)
     p.K = d->KH * d->KW * d->Cin;
     p.cchunks = d->Cin / 32;
     p.KT = d->KH * d->KW * p.cchunks;
-    p.wscale = nullptr; p.zero = nullptr; p.x_split = p.y_split = 0;
+    p.wscale = nullptr; p.zero = nullptr; p.x_split = p.y_split = 0; p.ovf = nullptr;
     p.vec_store = !d->y_nchw && (p.y_cstride % 4 == 0) && (p.y_coff % 4 == 0) &&
                   (!d->res || (p.res_cstride % 4 == 0 && p.res_coff % 4 == 0)) &&
                   ((uintptr_t)d->y % 16 == 0) && (!d->res || (uintptr_t)d->res % 16 == 0) &&
@@ -2778,6 +2819,7 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
     }
     if (tile < 1 || tile > kNumTiles) return USOT_EINVAL;
     const TileCfg &tc = kTiles[tile - 1];
+    if (!tc.fn && !tc.skfn) return USOT_ENOTBUILT;
     long blocks = 0;
     if (tc.skfn) {                         // persistent stream-K: a resident set of workgroups shares the (tile, k-tile) units
         SkInfo sk;
@@ -2838,6 +2880,8 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
         if (d[i].w_frag != tc.wfrag) return USOT_EINVAL;
         if (tc.wfrag == 2 && (!d[i].w_scale || ((uintptr_t)d[i].w_scale & 3))) return USOT_EINVAL;
         p.wscale = d[i].w_scale;
+        if ((uintptr_t)d[i].ovf & 3) return USOT_EINVAL;
+        p.ovf = tc.wfrag == 2 ? d[i].ovf : nullptr;
         // split maps: only the split-fp16 tiles write them (vectorised NHWC epilogue, whole 64-channel blocks, no split-K), only the
         // all-DMA tiles read them - and those read nothing else
         p.x_split = d[i].x_split ? 1 : 0;

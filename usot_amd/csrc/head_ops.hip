@@ -673,6 +673,14 @@ __global__ __launch_bounds__(256) void decode_kernel(
             }
         }
         if (tsz_dev) {
+            // tsz_dev[3] (as a 64-bit integer): 0, or the address of the frame's sticky split-fp16 "a sum was not finite" word
+            // (usot_conv_desc.ovf).  Its value travels with the results (out[9]) and the word is cleared for the next frame.
+            const unsigned long long oa = ((const unsigned long long *)tsz_dev)[3];
+            if (oa) {                                 // (then `out` has 10 doubles)
+                int *f = (int *)(uintptr_t)oa;
+                out[9] = (double)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             // completion tag for a host that polls the (pinned, coherent) result block instead of
             // waiting for the whole stream: results first, system-scope fence, then the tag
             __threadfence_system();
@@ -979,7 +987,7 @@ extern "C" int usot_device_guard(void)
     return expect == dev ? USOT_OK : USOT_ESTATE;
 }
 
-extern "C" int usot_abi_version(void) { return 4; }   // 2: usot_conv_desc.w_frag; 3: w_scale; 4: x_split / y_split
+extern "C" int usot_abi_version(void) { return 5; }   // 2: usot_conv_desc.w_frag; 3: w_scale; 4: x_split / y_split; 5: ovf (conv + pw_pair descriptors), decode's out[9]
 
 extern "C" const char *usot_strerror(int code)
 {
@@ -989,6 +997,7 @@ extern "C" const char *usot_strerror(int code)
     case USOT_ELAUNCH: return "kernel launch failed";
     case USOT_ENOMEM: return "out of memory";
     case USOT_ESTATE: return "object used in the wrong state";
+    case USOT_ENOTBUILT: return "conv tile not compiled into this library (experimental tile: build with USOT_EXPERIMENTS=1)";
     default: return "unknown error";
     }
 }

@@ -59,6 +59,7 @@ struct PwF {
     const float *tbias = nullptr;  //      ... staged as relu(sum in part order + tbias)
     int rparts = 0;                // > 1: res = `rparts` partial sums [rparts][M][CO] of the shortcut conv; residual = sum + rbias
     const float *rbias = nullptr;
+    int *ovf = nullptr;            // split-fp16 form: sticky "a sum was not finite" word (usot_pw_pair_desc.ovf)
 };
 
 // acc[u] (u < CBW) = sum over rounds [r0, r0 + RS) of W fragment (cb0 + u, r) x the B operand rows in LDS.
@@ -157,6 +158,17 @@ __device__ __forceinline__ void store_split4(char *row, int k, int plane, f32x4 
     *(u32x2_t *)(row + plane + k * 2) = u32x2_t{lo0, lo1};
 }
 
+// split-fp16 range contract (conv_igemm.hip, usot_conv_desc.ovf): a value beyond the fp16 window was staged as hi = inf, lo = -inf and
+// every sum it entered is NaN; report it in the caller's sticky word before an activation makes it finite again
+__device__ __forceinline__ void note_not_finite(int *ovf, const f32x4 &a)
+{
+    if (!ovf) return;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bad |= !(__builtin_fabsf(a[e]) <= 3.4028234664e38f);
+    if (bad) __hip_atomic_store(ovf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Everything after "the pixel tile is in LDS": GEMM1 + residual + ReLU -> Y (global + LDS), GEMM2 (+ wave-group / workgroup
 // meeting) -> T.  Xs: the [16][CM + 4] tile (published by a barrier before the call); Ys / Ps: scratch.
 // H16: split-fp16 operands (GemmRing, BLO > 0): both banks pre-split with their per-row factors 1 / (row scale x 8) appended
@@ -199,7 +211,10 @@ __device__ __forceinline__ void pair_tail(const PwF &p, const float *Xs, float *
 #pragma unroll
         for (int u = 0; u < CBW1; ++u) {
             const int co = (wave * CBW1 + u) * 16 + quad * 4;              // within the slice
-            if constexpr (H16) acc[u] *= sc[u];
+            if constexpr (H16) {
+                acc[u] *= sc[u];
+                note_not_finite(p.ovf, acc[u]);       // before the ReLU below turns an overflow's NaN into a finite 0
+            }
             f32x4 v = acc[u] + bb[u] + rr[u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -217,7 +232,10 @@ __device__ __forceinline__ void pair_tail(const PwF &p, const float *Xs, float *
     gemm_blocks<CBW2, RS2, R2T, H16 ? CO / 2 : 0>((const f32x4 *)p.w1p + lane + (long)sl * R2 * 64, Ys + l15 * YP + quad * 4, cb0, ksl * RS2, acc);
     if constexpr (H16) {                                  // unscaled partial sums from here on (exact: powers of two)
 #pragma unroll
-        for (int u = 0; u < CBW2; ++u) acc[u] *= *(const f32x4 *)(p.w1p + (long)CN * COT + (cb0 + u) * 16 + quad * 4);
+        for (int u = 0; u < CBW2; ++u) {
+            acc[u] *= *(const f32x4 *)(p.w1p + (long)CN * COT + (cb0 + u) * 16 + quad * 4);
+            note_not_finite(p.ovf, acc[u]);
+        }
     }
     if constexpr (KS > 1) {                               // wave groups meet in LDS
         const int cn = cb0 * 16 + quad * 4;
@@ -643,6 +661,8 @@ static int pw_pair_f32_launch(void *stream, const usot_pw_pair_desc *d, bool spl
     if (d->res_parts > 1 && (!d->res_bias || ((uintptr_t)d->res_bias & 15) || d->res_parts > 16)) return USOT_EINVAL;
     p.rparts = d->res_parts > 1 ? d->res_parts : 0;
     p.rbias = d->res_bias;
+    if ((uintptr_t)d->ovf & 3) return USOT_EINVAL;
+    p.ovf = split16 ? d->ovf : nullptr;
     hipStream_t s = (hipStream_t)stream;
     const bool sliced = slices(d->M, d->CM, d->CN) > 1 && d->ws;          /* no workspace: the unsliced form */
     if (split16) {

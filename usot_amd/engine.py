@@ -14,6 +14,7 @@ lib/models/connect.py:221-281, lib/models/modules.py:137-151.
 """
 import ctypes as C
 import os
+import warnings
 import time
 
 import numpy as np
@@ -270,6 +271,11 @@ class Builder:
         self.lp_readback = []   # bytes a fused launch reads back of its OWN output (phase 5 of csrc/conv_pw_lp.hip): not algorithmic
         self.f32_bytes = []     # the same for every fp32 entry of `log` (parallel list): bench.py's roofline.algorithmic_bytes_per_launch
         self.geoms = []         # full geometry per conv, for the tuner
+        # split-fp16 launches of this plan report a not-finite sum (an activation beyond the fp16 window) in ONE sticky device word
+        # (usot_conv_desc.ovf / usot_pw_pair_desc.ovf); None until the plan has such a launch.  Readers: Session (through the decode
+        # kernel's out[9]) and Engine.track / features (after the replay), which re-plan on the exact-fp32 tiles and run again.
+        self.ovf = None
+        self.last_ws = None     # the split-K workspace of the descriptor conv_desc() built last (conv_deferred / conv_batch take their slabs from it)
 
     def buf(self, *shape, dtype=torch.float32):
         ch = getattr(self, '_chain', None)
@@ -300,6 +306,12 @@ class Builder:
     def join(self, lane, level=3):
         if self.lanes >= level:
             self.plan.join(lane)
+
+    def ovf_word(self):
+        if self.ovf is None:
+            self.ovf = torch.zeros(1, device=self.dev, dtype=torch.int32)
+            self.plan.keep.append(self.ovf)
+        return self.ovf
 
     def conv_desc(self, name, pc, x, n, h, w, *, cout=None, act=ACT_NONE, res=None, y=None, y_cstride=0, y_coff=0,
                   act2=ACT_NONE, act_split=0, y_nchw=False, groups=1, x_gs=0, y_gs=0, w_rows=None, row0=0, tile=None,
@@ -348,7 +360,9 @@ class Builder:
                           groups=groups, x_gs=x_gs, w_gs=(w_rows or cout) * k, b_gs=(w_rows or cout),
                           y_gs=y_gs if y_gs else n * oh * ow * cout, r_gs=0,
                           ksplit=ksplit, tile=ttile, ws=ws.data_ptr() if ws is not None else None, w_frag=frag,
-                          w_scale=wsc.data_ptr() + row0 * 4 if wsc is not None else None)
+                          w_scale=wsc.data_ptr() + row0 * 4 if wsc is not None else None,
+                          ovf=self.ovf_word().data_ptr() if frag == 2 else None)
+        self.last_ws = ws
         self.plan.keep += [x, wbank, pc.b, wsc]
         log = (name, m, cout, k, groups, m * cout * k * groups)
         geom = dict(name=name, N=n, H=h, W=w, Cin=pc.cin, Cout=cout, KH=pc.kh, KW=pc.kw, stride=pc.stride,
@@ -370,18 +384,28 @@ class Builder:
         """A convolution whose split-K reduction is DEFERRED to its consumer (usot_conv_desc.defer): one launch writes the `ks`
         partial tiles, no bias, no activation, no combine.  Returns (slabs [ks, m, cout], oh, ow); the consumer sums them, adds
         pc.b and activates while it stages its input (pw_pair_f32(t2_parts=ks, t2_bias=pc.b))."""
-        d, _, oh, ow, log, geom = self.conv_desc(name, pc, x, n, h, w, tile=tile, force_ks=ks, y=x)    # y is not written
-        if d.ksplit != ks or d.w_frag == 1:
+        if ks < 2:
+            raise hip.HipError('conv_deferred %s: a deferred reduction needs ksplit >= 2 (got %d)' % (name, ks))
+        d, _, oh, ow, log, geom = self.conv_desc(name, pc, x, n, h, w, tile=tile, force_ks=ks, y=self._unwritten_y())
+        slabs = self.last_ws
+        if d.ksplit != ks or d.w_frag == 1 or slabs is None:
             raise hip.HipError('conv_deferred %s: tile %d cannot split k %d ways' % (name, tile, ks))
         m = n * oh * ow
         d.defer, d.act, d.bias, d.res = 1, ACT_NONE, None, None
-        # the workspace conv_desc allocated is the last buffer it kept before x / w / b: find it by pointer
-        slabs = next(t for t in reversed(self.plan.keep) if isinstance(t, torch.Tensor) and t.data_ptr() == d.ws)
         hip.check(hip.lib().usot_plan_add_conv(self.plan.h, C.byref(d)), 'plan_add_conv(deferred) ' + name)
         self.log.append(log)
         self.f32_bytes.append(4 * (n * h * w * pc.cin + pc.cout * pc.kh * pc.kw * pc.cin + ks * m * pc.cout))
         self.geoms.append(geom)
         return slabs[:ks * m * pc.cout].view(ks, m, pc.cout), oh, ow
+
+    def _unwritten_y(self):
+        """The `y` of a deferred launch: the descriptor wants a valid pointer, the launch never writes it (its partial tiles go to
+        `ws`).  A 16-byte scratch of the plan rather than an alias of the input map: a tile that ignored `defer` would then
+        clobber scratch, not the activations."""
+        if getattr(self, '_y_scratch', None) is None:
+            self._y_scratch = torch.zeros(4, device=self.dev)
+            self.plan.keep.append(self._y_scratch)
+        return self._y_scratch
 
     @staticmethod
     def _conv_bytes(d):
@@ -404,17 +428,19 @@ class Builder:
             kw = dict(kw)
             dks = kw.pop('defer_ks', None)          # this problem's split-K reduction is deferred to its consumer (conv_deferred)
             if dks:
-                kw.update(force_ks=dks, y=x)
+                if dks < 2:
+                    raise hip.HipError('conv_batch %s: a deferred reduction needs ksplit >= 2 (got %d)' % (nm, dks))
+                kw.update(force_ks=dks, y=self._unwritten_y())
                 kw.pop('act', None)
             d, y, oh, ow, log, geom = self.conv_desc(nm, pc, x, n, h, w, tile=lead_tile, **kw)
             if lead_tile is None:
                 lead_tile = d.tile if d.tile else self.default_batch_tile
                 d.tile = lead_tile
             if dks:
-                if d.ksplit != dks or d.w_frag == 1:
+                slabs = self.last_ws
+                if d.ksplit != dks or d.w_frag == 1 or slabs is None:
                     raise hip.HipError('conv_batch %s: tile %d cannot split k %d ways' % (nm, d.tile, dks))
                 d.defer, d.act, d.bias, d.res = 1, ACT_NONE, None, None
-                slabs = next(t for t in reversed(self.plan.keep) if isinstance(t, torch.Tensor) and t.data_ptr() == d.ws)
                 y = slabs[:dks * n * oh * ow * pc.cout].view(dks, n * oh * ow, pc.cout)
             descs.append(d)
             outs.append((y, oh, ow))
@@ -771,7 +797,8 @@ class Builder:
                              nxt.b.data_ptr(), t.data_ptr(), m, c3.cin, c3.cout, nxt.cout, act2,
                              ws.data_ptr() if ws is not None else None,
                              t2_parts=t2_parts, t2_bias=t2_bias.data_ptr() if t2_bias is not None else None,
-                             res_parts=res_parts, res_bias=res_bias.data_ptr() if res_bias is not None else None)
+                             res_parts=res_parts, res_bias=res_bias.data_ptr() if res_bias is not None else None,
+                             ovf=self.ovf_word().data_ptr() if s16 else None)
         hip.check(hip.lib().usot_plan_add_pw_pair(self.plan.h, C.byref(d), 3 if s16 else 2), 'plan_add_pw_pair(f32) ' + name)
         self.plan.keep += [t2, res, w3p, w1p, c3.b, nxt.b, ws, t2_bias, res_bias]
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c3.cout * c3.cin + nxt.cout * c3.cout)))
@@ -1188,7 +1215,7 @@ def _as_dev_f32(t, device):
 
 
 # fp32 producer / consumer tile id -> its split-fp16 twin (same tile shape, producer depth and producer waves)
-SPLIT16_TILES = {55: 91, 56: 92, 53: 94, 54: 95, 57: 97, 39: 99, 47: 99, 31: 99, 41: 104, 49: 104, 33: 104, 38: 97, 46: 98, 30: 97, 59: 102}
+SPLIT16_TILES = {55: 91, 56: 92, 53: 94, 54: 95, 57: 97, 39: 99, 31: 99, 41: 104, 49: 104, 33: 104}      # (routed fp32 tiles only: the library holds no others)
 
 
 def load_tuning(path=None):
@@ -1251,9 +1278,13 @@ DEFAULT_OPTIONS = {
     # conv3 89 -> 66 us, layer1's 1x1 shortcut 50 -> 38 at batch 64
     'panel_1x1_lp': {(256, 1024), (128, 512), (64, 256)},
     'panel_min_panels': 192,
-    # fp32 convolutions with K >= split16_min_k on the producer / consumer tiles run on the split-fp16 form of the tile (every
-    # operand as hi + lo fp16, three fp16 MFMAs per product block, fp32 accumulation: csrc/conv_igemm.hip PF = 4)
-    'split16_f32': True,
+    # OPT-IN fast mode of the fp32 frame (default: exact fp32 products on v_mfma_f32_16x16x4_f32, the reference's arithmetic).  True:
+    # fp32 convolutions with K >= split16_min_k on the producer / consumer tiles run on the split-fp16 form of the tile (every operand
+    # as hi + lo fp16 - 22 significant bits - three fp16 MFMAs per product block, fp32 accumulation: csrc/conv_igemm.hip PF = 4 | 5):
+    # the frame 0.84 -> 0.68 ms at the same 1e-4 parity.  Operands must stay below 8 188 in magnitude; a launch that sees one beyond it
+    # says so in a sticky device word (usot_conv_desc.ovf) and the engine re-plans on the exact tiles and runs the call / frame again
+    # (Engine._to_exact, Session._rerun_exact) - the mode never returns a wrong finite number and never fails mid-video
+    'split16_f32': False,
     'split16_min_k': 1152,
     # (CM, CO, CN) of the fused fp32 pointwise pairs that run on split-fp16 operands too (layer3's six conv3 + conv1 pairs)
     'split16_pairs': {(256, 1024, 256)},
@@ -1261,8 +1292,6 @@ DEFAULT_OPTIONS = {
     # Session: frame t's bank append (encode + scatter) runs at the start of frame t + 1's graph on a side branch, not behind
     # frame t's result tag (Session._build)
     'defer_append': False,
-    # layer3 (from block lp_chains_from on) as lp_chains independent batch slices on parallel graph branches, chain i released
-    # i * lp_chain_skew launches of chain 0 late (backbone_bf16); 0 = one chain
     # layer3's conv2 -> conv3 (+ residual + ReLU) of the batched low-precision backbone in ONE launch (csrc/conv_pw_lp.hip: a 256-pixel
     # panel of conv2's output stays in LDS).  Bit-identical to the two launches; measured in the batch-64 bf16 step.
     # Value: the conv2 widths it is used for ((256,) = layer3; 128 = layer2's last block, whose next conv1 has no pair form)
@@ -1278,6 +1307,8 @@ DEFAULT_OPTIONS = {
     'conv_pw_rs': True,
     # panel size of those kernels: 0 = the launcher's rule (usot_conv_pw_pixels), 1 = 256 pixels / 16 wavefronts, 2 = 128 / 8 (A/B switch)
     'conv_pw_panel': 0,
+    # layer3 (from block lp_chains_from on) as lp_chains independent batch slices on parallel graph branches, chain i released
+    # i * lp_chain_skew launches of chain 0 late (backbone_bf16); 0 = one chain
     'lp_chains': 0,
     'lp_chains_from': 7,
     'lp_chain_skew': 2,
@@ -1390,6 +1421,7 @@ ENV_SWITCHES = {      # environment variable -> (option, parser)
     'USOT_STREAM_3X3_SHAPES': ('stream_3x3_shapes', _shapes),
     'USOT_FUSED_F32_SLICED': ('fused_f32_sliced', lambda v: v == '1'),
     'USOT_SPIN_SECONDS': ('spin_seconds', float),
+    'USOT_SPLIT16_F32': ('split16_f32', lambda v: v == '1'),
     'USOT_CONV_PW_LP': ('conv_pw_lp', lambda v: tuple(int(t) for t in v.split(',') if t)),      # '' = off, '256', '256,128'
     'USOT_CONV_PW_PAIR_LP': ('conv_pw_pair_lp', lambda v: v == '1'),
     'USOT_CONV_PW_RS': ('conv_pw_rs', lambda v: v == '1'),
@@ -1450,8 +1482,33 @@ class Engine:
             x = bld.buf(n, 3, size, size)
             xf, h = bld.backbone(x, n, size)
             self._finish(bld.plan)
-            self._feat[key] = dict(x=x, xf=xf, h=h, plan=bld.plan, log=bld.log, stages=bld.stages)
+            self._feat[key] = dict(x=x, xf=xf, h=h, plan=bld.plan, log=bld.log, stages=bld.stages, ovf=bld.ovf)
         return self._feat[key]
+
+    # ------------------------------------------------------------------ split-fp16 range contract
+    def _overflowed(self, p):
+        """True when the plan that just replayed saw a not-finite sum on a split-fp16 launch (usot_conv_desc.ovf): an activation
+        left the fp16 window (|x| >= 8 188).  Reads ONE device word (a stream synchronisation - only plans that contain split-fp16
+        launches have the word, i.e. only engines with 'split16_f32' on pay it) and clears it."""
+        w = p.get('ovf')
+        if w is None or int(w.item()) == 0:
+            return False
+        w.zero_()
+        return True
+
+    def _to_exact(self, where):
+        """The automatic fallback of the opt-in split-fp16 mode: from now on EVERY plan of this engine is built on the exact-fp32
+        tiles (the reference's arithmetic: models.py:179-198 returns finite maps for any finite fp32 input).  Sticky: a checkpoint
+        that drove one activation out of the fp16 window will do it again."""
+        if self.opt['split16_f32']:
+            warnings.warn('usot_amd: %s: an activation left the range of the split-fp16 products (|x| >= 8 188); this engine '
+                          'continues on the exact-fp32 tiles (engine option split16_f32 -> False)' % (where,), RuntimeWarning, stacklevel=3)
+        self.opt['split16_f32'] = False
+        self.range_fallbacks = getattr(self, 'range_fallbacks', 0) + 1
+        self._feat.clear()
+        self._track.clear()
+        self._zenc.clear()
+        self._zk_key = None
 
     def _finish(self, plan):
         if self.graphs:
@@ -1468,6 +1525,9 @@ class Engine:
         p = self._feat_plan(n, s)
         p['x'].copy_(x)
         p['plan'].run()
+        if self._overflowed(p):
+            self._to_exact('features()')
+            return self.features(x)
         return p['xf'].permute(0, 3, 1, 2)
 
     def _raw_pixels(self, x, shape_key, raw_pixels):
@@ -1513,12 +1573,16 @@ class Engine:
             zf = bld.buf(n, 7, 7, 256)
             zk = bld.encode_kernel(zf, n, 512, 'z')
             self._finish(bld.plan)
-            self._zenc[n] = dict(zf=zf, zk=zk, plan=bld.plan)
+            self._zenc[n] = dict(zf=zf, zk=zk, plan=bld.plan, ovf=bld.ovf)
         e = self._zenc[n]
         src = hip.to_nhwc(zf_nchw)
         if src.data_ptr() != e['zf'].data_ptr():
             e['zf'].copy_(src)
         e['plan'].run()
+        if self._overflowed(e):
+            src = src.clone()                    # (may alias the plan's own input buffer, which _to_exact drops)
+            self._to_exact('encode_template()')
+            return self.encode_template(src.permute(0, 3, 1, 2))
         return e
 
     def template(self, z, bbox=None, pr_pool=True):
@@ -1562,7 +1626,7 @@ class Engine:
             bbox, cls2, S = bld.heads(xf, b, hf, zk, mem, m, mk=mk, mem_lane=2 if m else None)
             self._finish(bld.plan)
             self._track[key] = dict(x=x, xf=xf, hf=hf, mem=mem, bbox=bbox, cls2=cls2, S=S, plan=bld.plan,
-                                    log=bld.log)
+                                    log=bld.log, ovf=bld.ovf)
         return self._track[key]
 
     def track(self, x, zf, template_mem=None, score_mem=None, clone=True):
@@ -1586,6 +1650,10 @@ class Engine:
             if src.data_ptr() != p['mem'].data_ptr():
                 p['mem'].copy_(src)
         p['plan'].run()
+        if self._overflowed(p):
+            # models.py:179-198 returns finite maps for any finite fp32 input: run the call again on the exact-fp32 tiles
+            self._to_exact('track()')
+            return self.track(x, zf, template_mem, score_mem, clone)
         cls = p['cls2'][0]
         bbox = p['bbox']
         if clone:
@@ -1696,6 +1764,7 @@ class Session:
         self._ctl_f64 = tsz_dev.numpy()
         self._ctl_i32 = idx_dev.numpy()
         self._ctl_u32 = self._ctl_i32.view(np.uint32)
+        self._ctl_u64 = self.ctl[0:56].view(torch.int64).numpy().view(np.uint64)
         self._rows = np.zeros(nq, np.int32)
         self._rows[1] = 1
         self._out_np = self.out8.numpy()
@@ -1754,6 +1823,11 @@ class Session:
         pl.keep += [self.bank, self.ctl, self.window, self.out8, tsz_dev, idx_dev] + self.zk
         self.xf, self.cls2, self.bbox, self.plan, self.log = xf, cls2, bbox, pl, bld.log
         self.f32_bytes = bld.f32_bytes
+        # split-fp16 range word of this frame graph (Builder.ovf): its address travels in the control block, the decode kernel
+        # publishes its value as out[9] with the results and clears it (csrc/head_ops.hip); 0 = no split-fp16 launch in the graph
+        self._ovf = bld.ovf
+        self._ctl_u64[3] = bld.ovf.data_ptr() if bld.ovf is not None else 0
+        self._out_np[9] = 0.0
         # warm-up must not leave a stray row in the bank: point the scatter at a scratch row
         self._set_ctl([0, 1] + [2] * (nq - 2), self.cap - 1, (64.0, 64.0))
         self._ctl_f64[6] = -1.0
@@ -1790,6 +1864,9 @@ class Session:
         enc = bld.encode_kernel(src, hi - lo, 256, 'mem')
         bld.plan.run()
         torch.cuda.current_stream().synchronize()
+        if bld.ovf is not None and int(bld.ovf.item()):
+            self.e._to_exact('Session: memory-feature encoders')
+            return self._encode_rows(lo, hi)
         for g in range(3):
             self.bank_enc[g][lo:hi].copy_(enc[g])
         torch.cuda.current_stream().synchronize()
@@ -1854,6 +1931,7 @@ class Session:
         rows[2:] = picks
         rows[2:] += 2                               # bank rows 0 / 1 = init feature and its flip, 2 + i = memory i
         self._set_ctl(rows, 2 + self.n, tsz_scaled, xaddr)
+        self._last_ctl = (rows.copy(), 2 + self.n, (float(tsz_scaled[0]), float(tsz_scaled[1])), xaddr)
         self._tag = float(self.n)
         self._ctl_f64[6] = self._tag
         self._stream = torch.cuda.current_stream()
@@ -1876,6 +1954,29 @@ class Session:
             raise
         self._x_ref = None                          # the tag was observed: the crop may be reused from here on
         return out
+
+    def _rerun_exact(self):
+        """The frame just collected saw an activation beyond the split-fp16 window (out[9]): rebuild this session's frame graph on
+        the exact-fp32 tiles (the engine's option flips for every later plan too) and run the SAME frame again - same crop, same
+        picks, same bank row, which the second run overwrites - instead of failing mid-video (the reference returns finite maps for
+        any finite fp32 input, models.py:179-198)."""
+        rows, slot, tsz, xaddr = self._last_ctl
+        self._stream.synchronize()                  # the failed frame's PrRoIPool + bank append behind the tag
+        x_keep = self.x.clone() if xaddr == 0 else None
+        self.e._to_exact('Session frame %r' % (self._tag,))
+        with torch.cuda.stream(self._stream):
+            self._build()                           # (leaves out[8] = -1: the warm-up replay's tag)
+            if x_keep is not None:
+                self.x.copy_(x_keep)
+            # 'defer_append': the previous frame's row was appended at the start of the failed run; the rebuilt graph's pooled-feature
+            # buffer is empty, so its start-of-graph append goes to the scratch row
+            self._prev_slot = self.cap - 1
+            self._set_ctl(rows, slot, tsz, xaddr)
+            self._ctl_f64[6] = self._tag
+            self.plan.run()
+        self._stream.synchronize()
+        if self._out_np[8] != self._tag:
+            raise hip.HipError('frame %r: the exact-fp32 re-run never published its result block' % (self._tag,))
 
     def _collect(self):
         out, tag = self._out_np, self._tag
@@ -1900,12 +2001,11 @@ class Session:
                 if out[8] != tag:
                     raise hip.HipError('frame %r never published its result block (tag reads %r): '
                                        'the frame graph did not run to the decode kernel' % (tag, float(out[8])))
+        if self._ovf is not None and out[9] != 0.0:
+            self._rerun_exact()                     # split-fp16 range contract broken by this frame: the same frame on the exact-fp32 tiles
+            out = self._out_np
         self._prev_slot, self._pending = 2 + self.n, True      # ('defer_append': this frame's row, written by the next graph)
         self.n += 1
-        if self.e.opt['split16_f32'] and not (out[1] == out[1] and out[7] == out[7]):
-            # the split-fp16 convolutions overflow visibly (inf -> nan) when an activation exceeds 8 188: say so instead of tracking on
-            raise hip.HipError('frame %r: the response maps are not finite; if this checkpoint drives an activation beyond 8 188, run it '
-                               "with engine_options['options'] = {'split16_f32': False} (exact-fp32 products)" % (tag,))
         return out[:8].copy()
 
     def append_feature(self, feat):

@@ -15,7 +15,7 @@ ACT_NONE, ACT_RELU, ACT_EXP, ACT_CONF = 0, 1, 2, 3
 
 EXPORTS = (
     'usot_abi_version', 'usot_device_guard', 'usot_strerror', 'usot_conv2d_f32', 'usot_conv_tile_count',
-    'usot_conv_tile_info', 'usot_conv_tile_name', 'usot_conv_tile_wfrag', 'usot_conv_tile_xsplit', 'usot_conv_tile_kreq', 'usot_conv_tile_streamk', 'usot_conv_streamk_ws_floats', 'usot_conv_pack_wfrag_f32', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
+    'usot_conv_tile_info', 'usot_conv_tile_built', 'usot_experiments_built', 'usot_conv_bf16_tile_built', 'usot_conv_tile_name', 'usot_conv_tile_wfrag', 'usot_conv_tile_xsplit', 'usot_conv_tile_kreq', 'usot_conv_tile_streamk', 'usot_conv_streamk_ws_floats', 'usot_conv_pack_wfrag_f32', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
     'usot_xcorr_depthwise_f32', 'usot_groupdw_f32', 'usot_conf_fusion_reduce_f32',
     'usot_prroi_pool_forward_f32', 'usot_prroi_pool_backward_f32', 'usot_prroi_pool_coor_backward_f32', 'usot_permute4_f32', 'usot_decode_f32',
     'usot_plan_create', 'usot_plan_destroy', 'usot_plan_add_conv', 'usot_plan_add_stem',
@@ -51,7 +51,7 @@ class ConvDesc(C.Structure):
                 ('x_gs', C.c_int64), ('w_gs', C.c_int64), ('b_gs', C.c_int64), ('y_gs', C.c_int64),
                 ('r_gs', C.c_int64),
                 ('ksplit', C.c_int32), ('tile', C.c_int32), ('w_frag', C.c_int32), ('defer', C.c_int32),
-                ('w_scale', C.c_void_p), ('x_split', C.c_int32), ('y_split', C.c_int32)]
+                ('w_scale', C.c_void_p), ('x_split', C.c_int32), ('y_split', C.c_int32), ('ovf', C.c_void_p)]
 
 
 class GroupDWDesc(C.Structure):
@@ -68,7 +68,8 @@ class PwPairDesc(C.Structure):
     _fields_ = [('t2', C.c_void_p), ('w3p', C.c_void_p), ('res', C.c_void_p), ('w1', C.c_void_p),
                 ('b3', C.c_void_p), ('b1', C.c_void_p), ('y', C.c_void_p), ('t', C.c_void_p),
                 ('M', C.c_int32), ('CM', C.c_int32), ('CO', C.c_int32), ('CN', C.c_int32), ('act2', C.c_int32),
-                ('ws', C.c_void_p), ('t2_parts', C.c_int32), ('res_parts', C.c_int32), ('t2_bias', C.c_void_p), ('res_bias', C.c_void_p)]
+                ('ws', C.c_void_p), ('t2_parts', C.c_int32), ('res_parts', C.c_int32), ('t2_bias', C.c_void_p), ('res_bias', C.c_void_p),
+                ('ovf', C.c_void_p)]
 
 
 class BneckDesc(C.Structure):
@@ -252,6 +253,20 @@ def tile_name(tile):
     return buf.value.decode()
 
 
+def tile_built(tile):
+    """Whether conv tile id `tile` is compiled into the library: the ROUTED tiles always, the experimental ids (lab notebook:
+    parity-green, measured slower, never selected by the engine) only when it was built with USOT_EXPERIMENTS=1."""
+    return bool(lib().usot_conv_tile_built(int(tile)))
+
+
+def lp_tile_built(tile):
+    return bool(lib().usot_conv_bf16_tile_built(int(tile)))
+
+
+def experiments_built():
+    return bool(lib().usot_experiments_built())
+
+
 def tile_wfrag(tile):
     """1 when conv tile id `tile` streams its filters in fragment order (descriptor field w_frag, pack_wfrag)."""
     return int(lib().usot_conv_tile_wfrag(int(tile))) if tile else 0
@@ -328,6 +343,8 @@ def tile_table():
     L = lib()
     out = {}
     for i in range(1, L.usot_conv_tile_count() + 1):
+        if not L.usot_conv_tile_built(i):
+            continue
         bm, bn = C.c_int(), C.c_int()
         L.usot_conv_tile_info(i, C.byref(bm), C.byref(bn))
         out[i] = (bm.value, bn.value)
@@ -360,7 +377,7 @@ def split16_pack(w):
 def conv_desc(x, w, bias, y, *, N, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, pad=(0, 0), dil=(1, 1),
               res=None, act=ACT_NONE, act2=ACT_NONE, act_split=0, y_cstride=0, y_coff=0,
               res_cstride=0, res_coff=0, y_nchw=0, groups=1, x_gs=0, w_gs=0, b_gs=0, y_gs=0, r_gs=0,
-              ksplit=1, tile=0, ws=None, w_frag=0, defer=0, w_scale=None, x_split=0, y_split=0):
+              ksplit=1, tile=0, ws=None, w_frag=0, defer=0, w_scale=None, x_split=0, y_split=0, ovf=None):
     d = ConvDesc()
     d.x, d.w, d.bias, d.res, d.y, d.ws = (x, w, bias or None, res or None, y, ws or None)
     d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout = N, H, W, Cin, OH, OW, Cout
@@ -373,12 +390,14 @@ def conv_desc(x, w, bias, y, *, N, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, pa
     d.ksplit, d.tile, d.w_frag, d.defer = ksplit, tile, w_frag, defer
     d.w_scale = w_scale or None
     d.x_split, d.y_split = int(x_split), int(y_split)
+    d.ovf = ovf or None          # split-fp16 tiles: the sticky "a finished sum was not finite" word (usot_conv_desc.ovf)
     return d
 
 
 def conv2d(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, act=ACT_NONE,
-           tile=0, ksplit=1, y_nchw=False, y_split=False):
-    """x NHWC [N,H,W,Cin] dense, w packed [Cout, KH*KW*Cin] -> y NHWC [N,OH,OW,Cout]."""
+           tile=0, ksplit=1, y_nchw=False, y_split=False, ovf=None):
+    """x NHWC [N,H,W,Cin] dense, w packed [Cout, KH*KW*Cin] -> y NHWC [N,OH,OW,Cout].
+    ovf: int32 device tensor, the sticky range word of the split-fp16 tiles (usot_conv_desc.ovf)."""
     _dev(x), _dev(w)
     N, H, W_, Cin = x.shape
     Cout = w.shape[0]
@@ -403,7 +422,8 @@ def conv2d(x, w, bias, *, KH, KW, stride=1, pad=(0, 0), dil=(1, 1), res=None, ac
                   N=N, H=H, W=W_, Cin=Cin, OH=OH, OW=OW, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad,
                   dil=dil, res=res.data_ptr() if res is not None else None, act=act, tile=tile,
                   ksplit=ksplit, ws=ws.data_ptr() if ws is not None else None, y_nchw=int(y_nchw), w_frag=frag,
-                  w_scale=wsc.data_ptr() if wsc is not None else None, x_split=xs, y_split=int(y_split))
+                  w_scale=wsc.data_ptr() if wsc is not None else None, x_split=xs, y_split=int(y_split),
+                  ovf=ovf.data_ptr() if ovf is not None else None)
     if tile_streamk(tile):
         keep = streamk_ws([d], tile, x.device)
     check(lib().usot_conv2d_f32(stream(), C.byref(d)), 'usot_conv2d_f32')
@@ -666,7 +686,7 @@ def pw_pair_f32_supported(cm, co, cn):
     return bool(lib().usot_pw_pair_f32_supported(int(cm), int(co), int(cn)))
 
 
-def pw_pair_f32(t2, w3, b3, res, w1, b1, act2=ACT_RELU, sliced=True, split16=False):
+def pw_pair_f32(t2, w3, b3, res, w1, b1, act2=ACT_RELU, sliced=True, split16=False, ovf=None):
     """fp32 NHWC: Y = relu(t2 . w3^T + b3 + res), T = act2(Y . w1^T + b1); w3 [CO,CM], w1 [CN,CO] in natural order
     (packed here).  Returns (Y, T)."""
     for t in (t2, w3, b3, res, w1, b1):
@@ -678,7 +698,8 @@ def pw_pair_f32(t2, w3, b3, res, w1, b1, act2=ACT_RELU, sliced=True, split16=Fal
     w3p, w1p = (pw_pair_s16_pack(w3), pw_pair_s16_pack(w1)) if split16 else (pw_pair_f32_pack(w3), pw_pair_f32_pack(w1))
     ws = pw_pair_f32_ws(M, CM, CO, CN, t2.device) if sliced else None
     d = pw_pair_desc(t2.data_ptr(), w3p.data_ptr(), b3.data_ptr(), res.data_ptr(), y.data_ptr(), w1p.data_ptr(), b1.data_ptr(),
-                     t.data_ptr(), M, CM, CO, CN, act2, ws.data_ptr() if ws is not None else None)
+                     t.data_ptr(), M, CM, CO, CN, act2, ws.data_ptr() if ws is not None else None,
+                     ovf=ovf.data_ptr() if ovf is not None else None)
     fn = lib().usot_pw_pair_f32s if split16 else lib().usot_pw_pair_f32
     check(fn(stream(), C.byref(d)), 'usot_pw_pair_f32')
     if ws is not None:
@@ -733,13 +754,15 @@ def pw_pair_supported(cm, co, cn):
     return bool(lib().usot_pw_pair_supported(int(cm), int(co), int(cn)))
 
 
-def pw_pair_desc(t2, w3p, b3, res, y, w1, b1, t, M, CM, CO, CN, act2, ws=None, t2_parts=0, t2_bias=None, res_parts=0, res_bias=None):
+def pw_pair_desc(t2, w3p, b3, res, y, w1, b1, t, M, CM, CO, CN, act2, ws=None, t2_parts=0, t2_bias=None, res_parts=0, res_bias=None,
+                 ovf=None):
     d = PwPairDesc()
     d.t2, d.w3p, d.res, d.w1, d.b3, d.b1, d.y, d.t = t2, w3p, res, w1, b3, b1, y, t
     d.M, d.CM, d.CO, d.CN, d.act2 = M, CM, CO, CN, act2
     d.ws = ws
     d.t2_parts, d.t2_bias = t2_parts, t2_bias
     d.res_parts, d.res_bias = res_parts, res_bias
+    d.ovf = ovf or None
     return d
 
 
