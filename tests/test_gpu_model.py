@@ -388,12 +388,14 @@ def test_split16_out_of_range_activation_falls_back_to_exact_fp32():
     big = x * 2000.0
     with pytest.warns(RuntimeWarning, match='split-fp16'):
         a = ms.track(big, template_mem=mem, score_mem=sm)
-    b = me.track(big, template_mem=mem, score_mem=sm)
+    # (the exact engine is given the SAME template feature: ms.zf was computed on split products before the fallback and differs
+    # from me.zf in the last bits)
+    b = me.engine.track(big, ms.zf, mem, sm)
     assert ms.engine.range_fallbacks == 1 and ms.engine.opt['split16_f32'] is False
     for u, v in zip(a, b):
         _finite_or_same(u, v)
     a = ms.track(x, template_mem=mem, score_mem=sm)           # and it stays on the exact tiles
-    b = me.track(x, template_mem=mem, score_mem=sm)
+    b = me.engine.track(x, ms.zf, mem, sm)
     for u, v in zip(a, b):
         _finite_or_same(u, v)
     # the feature API likewise

@@ -1481,7 +1481,7 @@ class Engine:
             bld = Builder(self.W, self.tuning, self.lanes, self.opt)
             x = bld.buf(n, 3, size, size)
             xf, h = bld.backbone(x, n, size)
-            self._finish(bld.plan)
+            self._finish(bld.plan, bld.ovf)
             self._feat[key] = dict(x=x, xf=xf, h=h, plan=bld.plan, log=bld.log, stages=bld.stages, ovf=bld.ovf)
         return self._feat[key]
 
@@ -1507,14 +1507,25 @@ class Engine:
         self.range_fallbacks = getattr(self, 'range_fallbacks', 0) + 1
         self._feat.clear()
         self._track.clear()
+        # the template encodes (what sessions snapshot and track() reads) are REBUILT on the exact tiles from the features they were
+        # made of, not dropped: the caller's template() is still in force
+        made_of = {n: e['zf'].clone() for n, e in self._zenc.items()}
+        key = self._zk_key
         self._zenc.clear()
-        self._zk_key = None
+        for n, zf in made_of.items():
+            self.encode_template(zf.permute(0, 3, 1, 2))
+        self._zk_key = key
 
-    def _finish(self, plan):
+    def _finish(self, plan, ovf=None):
         if self.graphs:
             plan.run()                       # warm: module load, first-touch
             torch.cuda.current_stream().synchronize()
             plan.capture()
+        if ovf is not None:
+            # the warm-up replay ran on UNINITIALISED input buffers (torch.empty: any bit pattern, NaN and inf included), which the
+            # split-fp16 launches duly reported: that is not a verdict on the caller's data
+            torch.cuda.current_stream().synchronize()
+            ovf.zero_()
 
     def features(self, x):
         """x NCHW [n,3,s,s] -> xf as an NCHW-shaped view of the NHWC result [n,256,hf,hf].
@@ -1572,7 +1583,7 @@ class Engine:
             bld = Builder(self.W, self.tuning, self.lanes, self.opt)
             zf = bld.buf(n, 7, 7, 256)
             zk = bld.encode_kernel(zf, n, 512, 'z')
-            self._finish(bld.plan)
+            self._finish(bld.plan, bld.ovf)
             self._zenc[n] = dict(zf=zf, zk=zk, plan=bld.plan, ovf=bld.ovf)
         e = self._zenc[n]
         src = hip.to_nhwc(zf_nchw)
@@ -1624,7 +1635,7 @@ class Engine:
             xf, hf = bld.backbone(x, b, size, need_stem=False)
             zk = self._zenc[b]['zk']
             bbox, cls2, S = bld.heads(xf, b, hf, zk, mem, m, mk=mk, mem_lane=2 if m else None)
-            self._finish(bld.plan)
+            self._finish(bld.plan, bld.ovf)
             self._track[key] = dict(x=x, xf=xf, hf=hf, mem=mem, bbox=bbox, cls2=cls2, S=S, plan=bld.plan,
                                     log=bld.log, ovf=bld.ovf)
         return self._track[key]
@@ -1831,7 +1842,7 @@ class Session:
         # warm-up must not leave a stray row in the bank: point the scatter at a scratch row
         self._set_ctl([0, 1] + [2] * (nq - 2), self.cap - 1, (64.0, 64.0))
         self._ctl_f64[6] = -1.0
-        e._finish(pl)
+        e._finish(pl, bld.ovf)
         torch.cuda.current_stream().synchronize()
         self.feat.zero_()                   # the warm-up replay pooled a feature of the zero crop: not a pending append
         torch.cuda.current_stream().synchronize()
