@@ -460,7 +460,7 @@ def measure_backbone_bf16(model, device, batch=64, size=255, steps=0, warmup=2, 
     rows = []
     for kind, tile, ks, groups, ms in prof:
         ms_all += ms
-        if kind in (11, 18, 22, 23, 24, 25, 26, 27, 28, 29, 30):                             # K_CONVB, K_PWPAIR, K_PANEL
+        if kind in (11, 18, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31):                             # K_CONVB, K_PWPAIR, K_PANEL
             name, M, N, K, g, macs = next(convs)
             ms_conv += ms
             fl_conv += 2.0 * macs
@@ -581,7 +581,7 @@ def mixed_roofline(pm, batch, size, n, dt, top=5):
     rows, ms_all, ms_conv, fl_conv = [], 0.0, 0.0, 0.0
     for kind, tile, ks, groups, ms in prof:
         ms_all += ms
-        if kind in (0, 11, 18, 22, 23, 24, 25, 26, 27, 28, 29, 30):
+        if kind in (0, 11, 18, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31):
             try:
                 name, M, N, K, g, macs = next(convs)
             except StopIteration:

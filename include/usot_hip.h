@@ -228,6 +228,19 @@ int usot_conv_pw_pair_lp(void *stream, const usot_conv_desc *c2, const usot_pw_p
 int usot_conv_pw_pair_supported(int CM, int CO, int CN);
 int usot_plan_add_conv_pw_pair(void *plan, const usot_conv_desc *c2, const usot_pw_pair_desc *d, int dtype);
 int usot_plan_add_conv_pw(void *plan, const usot_conv_desc *c2, const void *w3, const float *b3, const void *res, void *y, int dtype);
+/* usot_conv_pw_pair_lp for layer3's blocks (CM = 256, CO = 1024, CN = 256; conv2 3 x 3 / stride 1 / pad = dil in 1..4) with the matrix-pipe
+ * work and the HBM work OVERLAPPED on every CU (csrc/conv_pw_ov.hip; modules.py:43-56,40-42): two kinds of 8-wave workgroup share a CU -
+ * one runs conv2 on 128-pixel panels and, later, the next conv1 on the panel's Y rows; the other takes the conv2 panels (through L2), runs
+ * conv3 + residual + ReLU and streams Y out - paired through write-through stores and flags in `ws`.  Same arithmetic as the pair form with
+ * the row-shared k-loop (k order (kh, 32-channel chunk, kw)); T bit-identical to usot_conv2d_lp on this launch's Y.
+ * ws: usot_conv_pw_ov_ws_bytes(M) bytes (M = conv2's output pixels), 16-byte aligned, ZERO before the first launch; every launch leaves the
+ * hand-off flags zero again (graph-replay safe).  The word after the 2 ceil(M / 128) flags is a sticky error flag: non-zero = a bounded
+ * hand-off wait ran out (the launch finished on garbage instead of hanging). */
+int usot_conv_pw_ov_lp(void *stream, const usot_conv_desc *c2, const usot_pw_pair_desc *d, int dtype, void *ws);
+int usot_conv_pw_ov_supported(int CM, int CO, int CN);
+int64_t usot_conv_pw_ov_ws_bytes(int64_t M);
+int usot_plan_add_conv_pw_ov(void *plan, const usot_conv_desc *c2, const usot_pw_pair_desc *d, int dtype, void *ws);
+int usot_conv_pw_ov_trace(void *buf);      /* measurement: placement + phase time stamps of later launches into buf (32 int64 per workgroup); NULL = off */
 
 /* 3x3 / stride 1 / pad 1 convolution of the batched low-precision backbone as a direct convolution from an LDS halo tile
  * (csrc/conv3x3_halo.hip; layer1's conv2 + BN + ReLU, modules.py:43-46): x, y NHWC dense [N][H][W][C] and w [Cout][9 Cin]

@@ -1453,6 +1453,54 @@ def test_conv_pw_at_the_timed_size_is_deterministic_and_equal_to_the_unfused_cha
         assert torch.equal(runs[0][0], y2) and torch.equal(runs[0][1], tt)
 
 
+@pytest.mark.experiments
+@pytest.mark.parametrize('n,h,dil,act2', [(2, 31, 2, 1), (1, 12, 1, 0), (3, 33, 2, 1), (16, 31, 2, 1)])
+def test_conv_pw_overlapped_form_matches_float64_and_its_own_conv1(n, h, dil, act2):
+    """csrc/conv_pw_ov.hip (EXPERIMENT: measured slower, not routed): a layer3 block as matrix-pipe and HBM workgroups side by side,
+    paired through write-through stores and flags.  Y against float64 on the rounded operands (T2 rounded to the storage type as the
+    kernel does: <= 4 ulp, a T2 value on a rounding boundary may round the other way), T bit-identical to the tiled conv1 on this
+    launch's own Y, nothing written past the last pixel, the hand-off flags back at zero (graph-replay safe), error word clear; twice."""
+    import ctypes as C
+    L = hip.lib()
+    dtype, dt = torch.bfloat16, 0
+    cm, co, cn = 256, 1024, 256
+    M = n * h * h
+    g = torch.Generator().manual_seed(n * 100 + h)
+    t1 = torch.randn(n, h, h, cm, generator=g).relu().to(dtype)
+    w2 = (torch.randn(cm, 9 * cm, generator=g) / (9 * cm) ** 0.5).to(dtype)
+    w3 = (torch.randn(co, cm, generator=g) / cm ** 0.5).to(dtype)
+    w1 = (torch.randn(cn, co, generator=g) / co ** 0.5).to(dtype)
+    b2, b3, b1 = (torch.randn(c, generator=g) * 0.1 for c in (cm, co, cn))
+    res = torch.randn(M, co, generator=g).to(dtype)
+    t1d, w2d, w3d, w1d, b2d, b3d, b1d, resd = (a.to(DEV) for a in (t1, w2, w3, w1, b2, b3, b1, res))
+    assert L.usot_conv_pw_ov_supported(cm, co, cn) == 1
+    ws = torch.zeros(int(L.usot_conv_pw_ov_ws_bytes(M)) // 4, dtype=torch.int32, device=DEV)
+    d2 = hip.conv_desc(t1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), None, N=n, H=h, W=h, Cin=cm, OH=h, OW=h, Cout=cm, KH=3, KW=3,
+                       pad=(dil, dil), dil=(dil, dil), act=1)
+    x64 = t1.double().permute(0, 3, 1, 2)
+    w64 = w2.double().view(cm, 3, 3, cm).permute(0, 3, 1, 2)
+    t2r = torch.nn.functional.conv2d(x64, w64, b2.double(), padding=dil, dilation=dil).relu().permute(0, 2, 3, 1).reshape(M, cm).to(dtype).double()
+    ref = (t2r @ w3.double().t() + b3.double() + res.double()).relu()
+    ulp = 2.0 ** -8
+    for _ in range(2):
+        y = torch.full((M + 2, co), 5.0, dtype=dtype, device=DEV)
+        t = torch.full((M + 2, cn), 5.0, dtype=dtype, device=DEV)
+        pd = hip.pw_pair_desc(None, w3d.data_ptr(), b3d.data_ptr(), resd.data_ptr(), y.data_ptr(), w1d.data_ptr(), b1d.data_ptr(),
+                              t.data_ptr(), M, cm, co, cn, act2)
+        hip.check(L.usot_conv_pw_ov_lp(hip.stream(), C.byref(d2), C.byref(pd), dt, hip.ptr(ws)), 'usot_conv_pw_ov_lp')
+        torch.cuda.synchronize()
+        assert torch.all(y[M:] == 5.0) and torch.all(t[M:] == 5.0)
+        assert int(ws[:2 * ((M + 127) // 128) + 1].abs().sum()) == 0
+        assert float(((y[:M].float().cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 4 * ulp
+        tt = torch.empty(M, cn, dtype=dtype, device=DEV)
+        yc = y[:M].contiguous()
+        d1 = hip.conv_desc(yc.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), tt.data_ptr(), N=1, H=M, W=1, Cin=co, OH=M, OW=1, Cout=cn, KH=1, KW=1,
+                           act=act2, tile=32)
+        hip.check(L.usot_conv2d_lp(hip.stream(), C.byref(d1), dt, 0), 'conv1')
+        torch.cuda.synchronize()
+        assert torch.equal(t[:M], tt)
+
+
 def test_backbone_bf16_conv_pw_option_is_bit_identical():
     """Engine options 'conv_pw_lp' / 'conv_pw_pair_lp' (layer3's conv2 -> conv3 and layer2's conv2 -> conv3 -> next conv1 fused per
     pixel panel): the batched bf16 backbone's output is bit-identical to the unfused lowering's with the per-tap k-loop, and within

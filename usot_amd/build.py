@@ -60,7 +60,7 @@ def build_info():
 def _write_info(compiled, linked, seconds):
     import json, socket, time
     with open(INFO, 'w') as f:
-        json.dump({'csrc_tree': csrc_tree(), 'compiled_units': compiled, 'linked': linked, 'seconds': round(seconds, 1),
+        json.dump({'csrc_tree': csrc_tree(), 'experiments': EXPERIMENTS, 'compiled_units': compiled, 'linked': linked, 'seconds': round(seconds, 1),
                    'when': int(time.time()), 'host': socket.gethostname(), 'hipcc': _hipcc()}, f, indent=1, sort_keys=True)
 
 
@@ -87,8 +87,14 @@ def is_stale():
 def build(force=False, verbose=False):
     """Compile every .hip translation unit and link the shared library.  Leaves csrc/build_info.json: which units THIS call
     compiled (an empty list = the library was up to date and nothing ran), so a driver's record can show a real build."""
-    import time
+    import json, time
     t0 = time.time()
+    try:
+        with open(INFO) as f:
+            if bool(json.load(f).get('experiments', False)) != EXPERIMENTS and os.path.exists(LIB):
+                force = True                       # the objects on disk were compiled with the other -DUSOT_EXPERIMENTS setting
+    except Exception:
+        pass
     if not force and not is_stale():
         if not os.path.exists(INFO):
             _write_info([], False, 0.0)

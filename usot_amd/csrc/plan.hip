@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3, K_PW3, K_PANEL, K_PANELP, K_HALO, K_KSTREAM, K_CKSTREAM, K_BNECK1, K_BNECKT, K_CONVPW, K_CONVPWP };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3, K_PW3, K_PANEL, K_PANELP, K_HALO, K_KSTREAM, K_CKSTREAM, K_BNECK1, K_BNECKT, K_CONVPW, K_CONVPWP, K_CONVPWO };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -113,6 +113,7 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
             break;
         case K_PANELP: rc = usot_pw_panel_pair_lp(s, &op.pw, op.i[6]); break;
         case K_CONVPWP: rc = usot_conv_pw_pair_lp(s, &op.conv, &op.pw, op.i[6]); break;
+        case K_CONVPWO: rc = usot_conv_pw_ov_lp(s, &op.conv, &op.pw, op.i[6], (void *)op.p[0]); break;
         case K_CONVPW: rc = usot_conv_pw_lp(s, &op.conv, op.p[0], (const float *)op.p[1], op.p[2], (void *)op.p[3], op.i[6]); break;
         case K_HALO:
             rc = usot_conv3x3_halo_lp(s, op.p[0], op.p[1], (const float *)op.p[2], (void *)op.p[3], op.i[0], op.i[1], op.i[2], op.i[3],
@@ -381,6 +382,18 @@ extern "C" int usot_plan_add_conv_pw_pair(void *plan, const usot_conv_desc *c2, 
     if (!op) return USOT_ESTATE;
     op->conv = *c2;
     op->pw = *d;
+    op->i[6] = dtype;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_conv_pw_ov(void *plan, const usot_conv_desc *c2, const usot_pw_pair_desc *d, int dtype, void *ws)
+{
+    if (!c2 || !d || !ws || !usot_conv_pw_ov_supported(d->CM, d->CO, d->CN) || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
+    Op *op = push(plan, K_CONVPWO);
+    if (!op) return USOT_ESTATE;
+    op->conv = *c2;
+    op->pw = *d;
+    op->p[0] = ws;
     op->i[6] = dtype;
     return USOT_OK;
 }

@@ -730,8 +730,21 @@ class Builder:
                            tile=(0 if self.opt['conv_pw_rs'] else 4) | int(self.opt['conv_pw_panel']))
         d = hip.pw_pair_desc(None, w3.data_ptr(), c3.b.data_ptr(), res.data_ptr(), y.data_ptr(), w1.data_ptr(), nxt.b.data_ptr(),
                              t.data_ptr(), m, c3.cin, c3.cout, nxt.cout, act2)
-        hip.check(hip.lib().usot_plan_add_conv_pw_pair(self.plan.h, C.byref(d2), C.byref(d), 1 if dtype == torch.float16 else 0),
-                  'plan_add_conv_pw_pair ' + name)
+        L = hip.lib()
+        # 'conv_pw_ov_lp': layer3's blocks on the OVERLAPPED form (csrc/conv_pw_ov.hip: matrix-pipe and HBM workgroups side by side on
+        # every CU) when the launch has at least conv_pw_ov_min_panels panels of 128 pixels and the geometry is the one it is built for
+        ov = (self.opt['conv_pw_ov_lp'] and self.opt['conv_pw_rs'] and L.usot_conv_pw_ov_supported(c3.cin, c3.cout, nxt.cout)
+              and c2.kh == 3 and c2.kw == 3 and c2.stride == 1 and tuple(c2.pad) == tuple(c2.dil) and 1 <= c2.dil[1] <= 4
+              and (oh, ow) == (h, h) and (m + 127) // 128 >= self.opt['conv_pw_ov_min_panels'] and m * c3.cout * 2 < 2 ** 31)
+        if ov:
+            ws = torch.zeros(int(L.usot_conv_pw_ov_ws_bytes(m)) // 4, dtype=torch.int32, device=self.dev)     # flags zero; T2 hand-off map
+            hip.check(L.usot_plan_add_conv_pw_ov(self.plan.h, C.byref(d2), C.byref(d), 1 if dtype == torch.float16 else 0, hip.ptr(ws)),
+                      'plan_add_conv_pw_ov ' + name)
+            self.plan.keep.append(ws)
+            self.ov_ws = getattr(self, 'ov_ws', []) + [ws]
+        else:
+            hip.check(L.usot_plan_add_conv_pw_pair(self.plan.h, C.byref(d2), C.byref(d), 1 if dtype == torch.float16 else 0),
+                      'plan_add_conv_pw_pair ' + name)
         self.plan.keep += [t1, res, w2, w3, w1, c2.b, c3.b, nxt.b]
         k2 = c2.kh * c2.kw * c2.cin
         self.log.append((name, m, c3.cout, c3.cin, 1, m * (c2.cout * k2 + c3.cout * c3.cin + nxt.cout * c3.cout)))
@@ -1301,6 +1314,11 @@ DEFAULT_OPTIONS = {
     # layer3's blocks likewise, the next block's conv1 (or the neck) as a FIFTH phase of the launch: the workgroup reads its own Y
     # panel back (csrc/conv_pw_lp.hip) - the standalone 1024 -> 256 launch disappears
     'conv_pw_p5_lp': True,
+    # EXPERIMENT (USOT_EXPERIMENTS=1 builds only; measured SLOWER, csrc/conv_pw_ov.hip: 234 vs 146 us per block): those launches on the
+    # OVERLAPPED form - two kinds of 8-wave workgroup per CU, conv2 (and the next conv1) on the matrix pipe beside conv3's residual / Y
+    # streams of another panel - from conv_pw_ov_min_panels 128-pixel panels up
+    'conv_pw_ov_lp': False,
+    'conv_pw_ov_min_panels': 384,
     # phase 1 of those kernels on the ROW-SHARED k-loop where the geometry allows it (3 x 3, stride 1, pad = dil: one staged activation
     # tile per (kh, channel chunk) serves the three kw taps - a third fewer LDS-DMA instructions per k-tile; k order (kh, chunk, kw), so
     # results differ from the per-tap loop's by fp32 summation order).  False: the per-tap loop, bit-identical to the unfused launches
@@ -1427,6 +1445,8 @@ ENV_SWITCHES = {      # environment variable -> (option, parser)
     'USOT_CONV_PW_RS': ('conv_pw_rs', lambda v: v == '1'),
     'USOT_CONV_PW_PANEL': ('conv_pw_panel', int),
     'USOT_CONV_PW_P5_LP': ('conv_pw_p5_lp', lambda v: v == '1'),
+    'USOT_CONV_PW_OV_LP': ('conv_pw_ov_lp', lambda v: v == '1'),
+    'USOT_CONV_PW_OV_MIN_PANELS': ('conv_pw_ov_min_panels', int),
 }
 
 
