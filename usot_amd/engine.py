@@ -1994,8 +1994,8 @@ class Session:
         rows, slot, tsz, xaddr = self._last_ctl
         self._stream.synchronize()                  # the failed frame's PrRoIPool + bank append behind the tag
         x_keep = self.x.clone() if xaddr == 0 else None
-        self.e._to_exact('Session frame %r' % (self._tag,))
         with torch.cuda.stream(self._stream):
+            self.e._to_exact('Session frame %r' % (self._tag,))
             self._build()                           # (leaves out[8] = -1: the warm-up replay's tag)
             if x_keep is not None:
                 self.x.copy_(x_keep)
