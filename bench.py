@@ -868,27 +868,36 @@ def main():
                        'result_streams': len({g[0].out8.data_ptr() for g in group}), 'hip_streams': len({g[4].cuda_stream for g in group})},
         }
         line['roofline'] = roofline(sess, frames=10)
-        if not a.no_xcorr:
-            line['xcorr_hbm'] = xcorr_bandwidth(device)
-        if world == 1:
-            line['video_loop_pcie_inclusive'] = video_loop(model, device)
-        if world == 1 and not a.no_extras:
-            # the two low-precision north-star configurations and the fp32 lock-step mode, measured by the
-            # same process (each a few seconds; their own full lines: --workload backbone_bf16 / track_mixed)
-            line['backbone_bf16_b64'] = measure_backbone_bf16(model, device, 64, a.size)
+
+        def extra(key, fn):
+            # a sub-measurement that fails must not take the headline line with it: the line then carries the error text under its key
+            try:
+                line[key] = fn()
+            except Exception as exc:      # noqa: BLE001
+                line[key] = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:300])}
+
+        def mixed_b32():
             pm = measure_track_mixed(model, device, 32, a.size)
             n, t = _timed(pm['plan'].run, 1.0)
-            line['track_mixed_b32'] = {
-                'workload': 'configs[4], one GPU: fp16 backbone + head convs, fp32 xcorr / reduce / predictions, 32 streams in '
-                            'lock step, N_q=7, one hipGraph', 'value': round(32 * n / t, 1), 'unit': 'frames/s',
-                'steps': n, 'ms_per_step': round(t / n * 1e3, 3), 'dtype': 'fp16+f32',
-                'roofline': mixed_roofline(pm, 32, a.size, n, t)}
-            line['track_split16'] = measure_track_split16(model, device, a.size)
-            line['lockstep_f32_b4'] = measure_lockstep_f32(model, device, 4, a.size)
+            return {'workload': 'configs[4], one GPU: fp16 backbone + head convs, fp32 xcorr / reduce / predictions, 32 streams in '
+                                'lock step, N_q=7, one hipGraph', 'value': round(32 * n / t, 1), 'unit': 'frames/s',
+                    'steps': n, 'ms_per_step': round(t / n * 1e3, 3), 'dtype': 'fp16+f32',
+                    'roofline': mixed_roofline(pm, 32, a.size, n, t)}
+        if not a.no_xcorr:
+            extra('xcorr_hbm', lambda: xcorr_bandwidth(device))
+        if world == 1:
+            extra('video_loop_pcie_inclusive', lambda: video_loop(model, device))
+        if world == 1 and not a.no_extras:
+            # the two low-precision north-star configurations, the opt-in split-fp16 frame and the fp32 lock-step mode, measured by
+            # the same process (each a few seconds; their own full lines: --workload backbone_bf16 / track_mixed)
+            extra('backbone_bf16_b64', lambda: measure_backbone_bf16(model, device, 64, a.size))
+            extra('track_mixed_b32', mixed_b32)
+            extra('track_split16', lambda: measure_track_split16(model, device, a.size))
+            extra('lockstep_f32_b4', lambda: measure_lockstep_f32(model, device, 4, a.size))
             if a.size != 271:
-                line['track_271'] = measure_track_271(model, device)
+                extra('track_271', lambda: measure_track_271(model, device))
         if world == 1 and not a.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+            extra('cpu_baseline', cpu_baseline)
         line['build_info'] = build_info_line()
         print(json.dumps(line))
     streams.barrier()

@@ -35,8 +35,11 @@ extern "C" {
 #define USOT_ACT_CONF      3   /* exp(min(max(x,0),4))    connect.py:128-131 (ReLU then clamp) */
 
 int usot_abi_version(void);
-/* One GPU per process: the library binds to the first device a launcher runs on (its launchers cache per-device state);
- * USOT_OK on that device, USOT_ESTATE on any other.  Every launcher with such state calls it first. */
+/* Launchers cache per-DEVICE state (zero pages, LDS-limit raises, CU counts) in tables indexed by the current HIP device:
+ * usot_device_slot() = that index (hipGetDevice; 0 .. 15) or -1; usot_device_guard() = USOT_OK when the current device has a slot,
+ * USOT_ESTATE otherwise.  One process may drive one GPU (the benchmarked form: one rank per GPU) or several (set the device, use its
+ * streams); until round 6 the library bound itself to the first device it saw. */
+int usot_device_slot(void);
 int usot_device_guard(void);
 /* HBM ceiling probe of the box (csrc/bw_probe.hip): mode 0 read `bytes`, 1 copy `bytes`, 2 read `bytes` + write bytes / 4
  * (GroupDW's byte mix, one interleaved read stream, non-temporal stores), 3 GroupDW's TRAFFIC without its compute - an address-level

@@ -13,7 +13,7 @@ db() { find "$1" -name '*.db' | head -1; }
 
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$out/smoke.log" 2>&1
 timeout 1500 python -m pytest tests -m gpu -q > "$out/pytest.log" 2>&1; tail -3 "$out/pytest.log"
-timeout 600 python bench.py > "$out/bench.json" 2> "$out/bench.err"
+timeout 600 python bench.py --no-cpu-baseline > "$out/bench_before_counters.json" 2> "$out/bench.err"
 timeout 300 python bench.py --streams-per-gpu 4 --no-extras --no-xcorr --no-cpu-baseline > "$out/streams4_bench.json" 2>> "$out/bench.err"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$out/prof" -- python "$root/bench.py" --steps 100 --warmup 10 $hl > "$out/profiled_bench.json" 2> "$out/prof.err")
 python scripts/rocpd_stats.py "$(db "$out/prof")" > "$out/kernel_stats.txt"
@@ -58,6 +58,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python scripts/pmc_xcorr_to_json.py "$(db "$out/pmc_xc_FETCH_SIZE")" "$(db "$out/pmc_xc_WRITE_SIZE")" 2048 "$out/pmc_xcorr.json" "$commit" > /dev/null
 rm -rf "$out/pmc_lp_busy" "$out/pmc_mx_busy" "$out/prof_mx" "$out/pmc_mx_FETCH_SIZE" "$out/pmc_mx_WRITE_SIZE" "$out/pmc_busy_f32" "$out/prof_xc" "$out/pmc_xc_FETCH_SIZE" "$out/pmc_xc_WRITE_SIZE"
+# the three bench lines LAST, with this pass's counters in place (profiles/pmc_*.json are keyed to the source tree: bench.py prints null
+# for traffic / mfma_busy / clock when they were measured on another one) - on the box only; copy them into profiles/ at home as well
+cp "$out"/pmc_traffic.json "$out"/pmc_busy.json "$out"/pmc_traffic_bf16.json "$out"/pmc_traffic_mixed.json "$out"/pmc_xcorr.json profiles/
+timeout 600 python bench.py > "$out/bench.json" 2>> "$out/bench.err"
 timeout 300 python bench.py --workload backbone_bf16 > "$out/config3_bf16_bench.json" 2>> "$out/bench.err"
 timeout 300 python bench.py --workload track_mixed --batch 32 > "$out/config5_fp16_mixed_b32_bench.json" 2>> "$out/bench.err"
 rm -rf "$out/prof" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/prof_lp" "$out/pmc_lp_FETCH_SIZE" "$out/pmc_lp_WRITE_SIZE"

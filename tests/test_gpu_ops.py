@@ -1526,6 +1526,13 @@ def test_backbone_bf16_conv_pw_option_is_bit_identical():
     assert float((a - b).abs().max()) <= 0.05 * float(b.abs().max()) and float((a - b).abs().mean()) <= 4e-3 * float(b.abs().mean() + 1e-6) + 1e-3
 
 
+def test_launcher_state_is_indexed_by_the_current_device():
+    """csrc/common.h: the launchers' cached state (zero pages, raised LDS limits, CU counts) lives in tables indexed by the current HIP
+    device, so one process may drive several GPUs; the index is hipGetDevice's."""
+    L = hip.lib()
+    assert L.usot_device_slot() == torch.cuda.current_device() and L.usot_device_guard() == 0
+
+
 def test_bw_probe_kernels_move_the_right_bytes():
     """The HBM ceiling probes bench.py quotes GroupDW against (csrc/bw_probe.hip): copy copies, the 4:1 mix sums the four
     adjacent 1 KiB rows of each 64-element group, bad arguments are refused."""

@@ -650,7 +650,8 @@ extern "C" int usot_bneck_first_supported(int Cin, int Cmid, int Cout, int Cnext
  * k, wn [64][256]; biases fp32 (b3c = conv3's + the downsample's); y [N][H][W][256], t [N][H][W][64]. */
 extern "C" int usot_bneck_first_lp(void *stream, const usot_bneck_desc *d, int dtype)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     if (!d || !d->x || !d->w1 || !d->w2 || !d->w3c || !d->wn || !d->b1 || !d->b2 || !d->b3c || !d->bn || !d->y || !d->t) return USOT_EINVAL;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
     if (((uintptr_t)d->x | (uintptr_t)d->w1 | (uintptr_t)d->w2 | (uintptr_t)d->w3c | (uintptr_t)d->wn | (uintptr_t)d->b1 |
@@ -665,8 +666,10 @@ extern "C" int usot_bneck_first_lp(void *stream, const usot_bneck_desc *d, int d
     const long nt = (long)p.tiles_x * p.tiles_y * d->N;
     if (nt > 0x7fffffffL || (long)d->H * d->W * 128 >= 0x7fffffffL) return USOT_EINVAL;      // 32-bit offsets inside an image
     p.ntiles = (int)nt;
-    static const uint16_t *zero_page = nullptr;
-    static int cus = 0;
+    static const uint16_t *zero_page_d[USOT_MAX_DEV] = {};
+    const uint16_t *&zero_page = zero_page_d[usot_dv];
+    static int cus_d[USOT_MAX_DEV] = {};
+    int &cus = cus_d[usot_dv];
     if (!zero_page) {
         void *zp = nullptr;
         if (hipGetSymbolAddress(&zp, HIP_SYMBOL(bk_zero16)) != hipSuccess || !zp) return USOT_ELAUNCH;
@@ -677,7 +680,8 @@ extern "C" int usot_bneck_first_lp(void *stream, const usot_bneck_desc *d, int d
                   ? prop.multiProcessorCount : 256;
     }
     p.zero = zero_page;
-    static bool raised[2] = {false, false};
+    static bool raised_d[USOT_MAX_DEV][2] = {};
+    bool (&raised)[2] = raised_d[usot_dv];
     const void *fn = dtype ? (const void *)bneck_first_kernel<true> : (const void *)bneck_first_kernel<false>;
     if (!raised[dtype]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess) return USOT_ELAUNCH;
@@ -705,7 +709,8 @@ extern "C" int usot_bneck_tail_supported(int Cmid, int Cout, int Cnext)
  * d->bn (d->b1 unused); y [N][H][W][256] = relu(conv3(relu(conv2 t1)) + residual), t [N][H][W][Cnext] = relu(conv1'(y)). */
 extern "C" int usot_bneck_tail_lp(void *stream, const usot_bneck_desc *d, int Cnext, int dtype)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     if (!d || !d->x || !d->w1 || !d->w2 || !d->w3c || !d->wn || !d->b2 || !d->b3c || !d->bn || !d->y || !d->t) return USOT_EINVAL;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || (dtype != 0 && dtype != 1) || !usot_bneck_tail_supported(64, 256, Cnext)) return USOT_EINVAL;
     if (((uintptr_t)d->x | (uintptr_t)d->w1 | (uintptr_t)d->w2 | (uintptr_t)d->w3c | (uintptr_t)d->wn |
@@ -720,8 +725,10 @@ extern "C" int usot_bneck_tail_lp(void *stream, const usot_bneck_desc *d, int Cn
     const long nt = (long)p.tiles_x * p.tiles_y * d->N;
     if (nt > 0x7fffffffL || (long)d->H * d->W * 512 >= 0x7fffffffL) return USOT_EINVAL;      // 32-bit offsets inside an image
     p.ntiles = (int)nt;
-    static const uint16_t *zero_page = nullptr;
-    static int cus = 0;
+    static const uint16_t *zero_page_d[USOT_MAX_DEV] = {};
+    const uint16_t *&zero_page = zero_page_d[usot_dv];
+    static int cus_d[USOT_MAX_DEV] = {};
+    int &cus = cus_d[usot_dv];
     if (!zero_page) {
         void *zp = nullptr;
         if (hipGetSymbolAddress(&zp, HIP_SYMBOL(bk_zero16)) != hipSuccess || !zp) return USOT_ELAUNCH;
@@ -735,7 +742,8 @@ extern "C" int usot_bneck_tail_lp(void *stream, const usot_bneck_desc *d, int Cn
     const int v = (dtype ? 2 : 0) + (Cnext == 128 ? 1 : 0);
     const void *fns[4] = {(const void *)bneck_tail_kernel<false, 64>, (const void *)bneck_tail_kernel<false, 128>,
                           (const void *)bneck_tail_kernel<true, 64>, (const void *)bneck_tail_kernel<true, 128>};
-    static bool raised[4] = {false, false, false, false};
+    static bool raised_d[USOT_MAX_DEV][4] = {};
+    bool (&raised)[4] = raised_d[usot_dv];
     if (!raised[v]) {
         if (hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS) != hipSuccess) return USOT_ELAUNCH;
         raised[v] = true;

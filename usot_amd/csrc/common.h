@@ -13,9 +13,14 @@ static inline int usot_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // The launchers keep per-DEVICE facts in function-local statics: raised dynamic-LDS limits (hipFuncSetAttribute), the address
 // of a __device__ zero page (hipGetSymbolAddress), the CU count.  All of these belong to ONE device; the execution model is
-// one process per GPU (streams.py), so the library binds itself to the first device a launcher runs on and every
-// launcher refuses (USOT_ESTATE) to run on another one - instead of handing device 0's zero page to a kernel on device 1 or
-// skipping the LDS-limit raise there.  Defined in head_ops.hip.
+// Per-device launcher state (round 6).  Launchers cache what they learn about a device - the address of a zero page in device memory,
+// whether a kernel's dynamic-LDS limit was raised, the CU count, resident-workgroup counts - in function-local statics.  Those are now
+// arrays indexed by the CURRENT HIP device (usot_device_slot(): hipGetDevice, 0 .. USOT_MAX_DEV - 1), so one process may drive several
+// GPUs (SURVEY 8e's "one process + per-device streams" form) as well as one; a device index beyond the table returns USOT_ESTATE.
+// Initialisation races between host threads are benign (idempotent values).  usot_device_guard() stays in the ABI: USOT_OK when the
+// current device has a slot.  Both are defined in head_ops.hip.
+constexpr int USOT_MAX_DEV = 16;
+extern "C" int usot_device_slot(void);
 extern "C" int usot_device_guard(void);
 
 // Running total of the finished k-blocks of an MFMA accumulator (4 floats per lane); see conv_igemm.hip: blocked_mma.

@@ -208,7 +208,8 @@ extern "C" int usot_conv3x3_halo_supported(int Cin, int Cout) { return Cin == 64
 extern "C" int usot_conv3x3_halo_lp(void *stream, const void *x, const void *w, const float *bias, void *y,
                                     int N, int H, int W, int Cin, int Cout, int act, int dtype)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || (dtype != 0 && dtype != 1) || !usot_conv3x3_halo_supported(Cin, Cout)) return USOT_EINVAL;
     if (act != USOT_ACT_NONE && act != USOT_ACT_RELU) return USOT_EINVAL;
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)y) & 15) return USOT_EINVAL;
@@ -219,7 +220,8 @@ extern "C" int usot_conv3x3_halo_lp(void *stream, const void *x, const void *w, 
     const long nt = (long)p.tiles_x * p.tiles_y * N;
     if (nt > 0x7fffffffL) return USOT_EINVAL;
     p.ntiles = (int)nt;
-    static int cus = 0;
+    static int cus_d[USOT_MAX_DEV] = {};
+    int &cus = cus_d[usot_dv];
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -227,7 +229,8 @@ extern "C" int usot_conv3x3_halo_lp(void *stream, const void *x, const void *w, 
                   ? prop.multiProcessorCount : 256;
     }
     constexpr int lds = HLDS;
-    static bool raised[2] = {false, false};
+    static bool raised_d[USOT_MAX_DEV][2] = {};
+    bool (&raised)[2] = raised_d[usot_dv];
     const void *fn = dtype ? (const void *)conv3x3_halo_kernel<true> : (const void *)conv3x3_halo_kernel<false>;
     if (!raised[dtype]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return USOT_ELAUNCH;

@@ -1052,7 +1052,8 @@ extern "C" int usot_conv_bf16_tile_built(int tile) { return (tile >= 1 && tile <
  * ksplit / nchw / channel-offset outputs are fp32-path features. */
 extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, int out_f32)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     if (dtype != 0 && dtype != 1) return USOT_EINVAL;
     if (!d || !d->x || !d->w || !d->y) return USOT_EINVAL;
     if (d->Cin <= 0 || (d->Cin % BKB) || d->Cout <= 0 || (d->Cout & 3) || d->N <= 0) return USOT_EINVAL;
@@ -1087,7 +1088,8 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     p.nfast = 1;
     const long blocks = (long)p.MT * p.NT * p.groups;
     if (blocks <= 0 || blocks > 0x7fffffffL) return USOT_EINVAL;
-    static const uint16_t *zero_page = nullptr;
+    static const uint16_t *zero_page_d[USOT_MAX_DEV] = {};
+    const uint16_t *&zero_page = zero_page_d[usot_dv];
     if (!zero_page) {
         void *zp = nullptr;
         if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess || !zp) return USOT_ELAUNCH;
@@ -1101,7 +1103,8 @@ extern "C" int usot_conv2d_lp(void *stream, const usot_conv_desc *d, int dtype, 
     if (lds_out > 144 * 1024) lds_out = (size_t)tc.bm * (tc.bn / 2 + 4) * 4;   // two channel slices
     if (lds_out > lds) lds = lds_out;
     if (lds > 64 * 1024) {
-        static bool raised[2][kNumTilesB + 1] = {{false}};
+        static bool raised_d[USOT_MAX_DEV][2][kNumTilesB + 1] = {};
+        bool (&raised)[2][kNumTilesB + 1] = raised_d[usot_dv];
         if (!raised[dtype][tile]) {
             if (hipFuncSetAttribute((const void *)(dtype ? tc.fn16 : tc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return USOT_ELAUNCH;

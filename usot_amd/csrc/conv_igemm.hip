@@ -2757,7 +2757,10 @@ int64_t sk_plan(const TileCfg &tc, const usot_conv_desc *d, int n, ConvBatch &bt
     }
     if (U <= 0 || U > 0x3fffffffL) return USOT_EINVAL;
     for (int i = n; i < 5; ++i) { sk.ubase[i] = (int)U; sk.tbase[i] = (int)T; }
-    static int slots[128] = {0};                       // resident workgroups of this tile on this device (usot_device_guard: one device)
+    const int usot_dv = usot_device_slot();
+    if (usot_dv < 0) return USOT_ESTATE;
+    static int slots_d[USOT_MAX_DEV][128] = {};
+    int (&slots)[128] = slots_d[usot_dv];                       // resident workgroups of this tile on the current device
     const int tile = (int)(&tc - kTiles);
     if (!slots[tile]) {
         const size_t lds = (size_t)tc.stages * (tc.bm + tc.bn) * (tc.bk + 4) * sizeof(float);
@@ -2786,7 +2789,8 @@ extern "C" int64_t usot_conv_streamk_ws_floats(const usot_conv_desc *d, int n, i
     if (!d || n < 1 || n > 4 || tile < 1 || tile > kNumTiles) return USOT_EINVAL;
     const TileCfg &tc = kTiles[tile - 1];
     if (!tc.skfn) return 0;
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     ConvBatch bt;
     SkInfo sk;
     bt.n = n;
@@ -2803,7 +2807,8 @@ extern "C" int usot_conv_tile_streamk(int tile) { return (tile >= 1 && tile <= k
 
 extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int n)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     if (!d || n < 1 || n > 4) return USOT_EINVAL;
     ConvBatch bt;
     bt.n = n;
@@ -2861,7 +2866,8 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
         }
         for (int i = n; i < 5; ++i) bt.start[i] = (int)blocks;
         const size_t lds = (size_t)4 * 32 * (128 * tc.rps + 4) * sizeof(float) + 8 * 4 * 64 * 16;
-        static bool raised[128] = {false};
+        static bool raised_d[USOT_MAX_DEV][128] = {};
+    bool (&raised)[128] = raised_d[usot_dv];
         if (!raised[tile]) {
             if (hipFuncSetAttribute((const void *)tc.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return USOT_ELAUNCH;
@@ -2889,7 +2895,8 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
         if (p.x_split != (tc.wfrag == 2 && tc.dw == 6 ? 1 : 0)) return USOT_EINVAL;
         if (p.y_split && (tc.wfrag != 2 || !p.vec_store || (d[i].Cout & 63) || (p.y_coff & 63) || (p.y_cstride & 63) || p.ksplit > 1 || d[i].res)) return USOT_EINVAL;
         if (p.x_split) {
-            static const float *zero_page = nullptr;
+            static const float *zero_page_d[USOT_MAX_DEV] = {};
+    const float *&zero_page = zero_page_d[usot_dv];
             if (!zero_page) {
                 void *zp = nullptr;
                 if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16_f32)) != hipSuccess || !zp) return USOT_ELAUNCH;
@@ -2918,7 +2925,8 @@ extern "C" int usot_conv2d_batch_f32(void *stream, const usot_conv_desc *d, int 
     if (tc.wfrag == 2 && tc.dw == 5) lds = (size_t)(3 * tc.bm + (tc.depth >= 4 ? 6 : 5) * tc.bn) * ld * sizeof(float);      // three activation + five (six) filter stages
     if (tc.wfrag == 2 && tc.dw == 6) lds = (size_t)(6 * tc.bm + 6 * tc.bn) * ld * sizeof(float);                           // six of each
     if (lds > 64 * 1024) {
-        static bool raised[128] = {false};
+        static bool raised_d[USOT_MAX_DEV][128] = {};
+    bool (&raised)[128] = raised_d[usot_dv];
         if (!raised[tile]) {
             if (hipFuncSetAttribute((const void *)tc.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return USOT_ELAUNCH;

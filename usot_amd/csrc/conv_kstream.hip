@@ -220,10 +220,12 @@ __global__ __launch_bounds__(512) void conv_kstream_kernel(const CKStreamK p)
 template <int CIN>
 int ck_launch(void *stream, const CKStreamK &p, int dtype)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     constexpr int CC = CIN / 64;
     constexpr int lds = (CK_S * CK_BN * 8 + (CK_BN / 4 > CC * 8 ? CK_BN / 4 : CC * 8)) * 16;
-    static bool raised[2] = {false, false};
+    static bool raised_d[USOT_MAX_DEV][2] = {};
+    bool (&raised)[2] = raised_d[usot_dv];
     const void *fn = dtype ? (const void *)conv_kstream_kernel<CIN, true> : (const void *)conv_kstream_kernel<CIN, false>;
     if (!raised[dtype]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return USOT_ELAUNCH;

@@ -658,7 +658,10 @@ template <int NW, int CM, int CN, bool RS>
 int cp_launch_rs(hipStream_t s, const CpK &p, int dtype)
 {
     using Cf = CpCfg<NW, CM, CN>;
-    static bool raised[2] = {false, false};
+    const int usot_dv = usot_device_slot();
+    if (usot_dv < 0) return USOT_ESTATE;
+    static bool raised_d[USOT_MAX_DEV][2] = {};
+    bool (&raised)[2] = raised_d[usot_dv];
     const void *fn = dtype ? (const void *)conv_pw_kernel<true, NW, CM, CN, RS> : (const void *)conv_pw_kernel<false, NW, CM, CN, RS>;
     if (!raised[dtype]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) != hipSuccess) return USOT_ELAUNCH;
@@ -688,7 +691,10 @@ int cp_fill(const usot_conv_desc *c2, int CM, CpK &p)
     if (((uintptr_t)c2->x % 16) || ((uintptr_t)c2->w % 16) || ((uintptr_t)c2->bias % 16)) return 0;
     const long M = (long)c2->N * oh * ow;
     if (M > 0x7fffffffL - 256) return 0;
-    static const uint16_t *zero_page = nullptr;
+    const int usot_dv = usot_device_slot();
+    if (usot_dv < 0) return 0;
+    static const uint16_t *zero_page_d[USOT_MAX_DEV] = {};
+    const uint16_t *&zero_page = zero_page_d[usot_dv];
     if (!zero_page) {
         void *zp = nullptr;
         if (hipGetSymbolAddress(&zp, HIP_SYMBOL(cp_zero16)) != hipSuccess || !zp) return 0;
@@ -727,7 +733,9 @@ extern "C" int usot_conv_pw_pair_supported(int CM, int CO, int CN)
  * 256-pixel panels would spill into a mostly empty second round (CUs < panels < 1.5 CUs: e.g. 273 at batch 64 of 271 x 271 crops). */
 extern "C" int usot_conv_pw_pixels(int64_t M)
 {
-    static int cus = 0;
+    const int usot_dv = usot_device_slot() < 0 ? 0 : usot_device_slot();      // (a host-side shape query: no device is not an error here)
+    static int cus_d[USOT_MAX_DEV] = {};
+    int &cus = cus_d[usot_dv];
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -742,7 +750,8 @@ extern "C" int usot_conv_pw_pixels(int64_t M)
 extern "C" int usot_conv_pw_lp(void *stream, const usot_conv_desc *c2, const void *w3, const float *b3, const void *res, void *y,
                                int dtype)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     if (!c2 || !w3 || !b3 || !res || !y || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
     if (!usot_conv_pw_supported(c2->Cin, c2->Cout, 4 * c2->Cout)) return USOT_EINVAL;
     const void *ptrs[] = {w3, b3, res, y};
@@ -761,7 +770,8 @@ extern "C" int usot_conv_pw_lp(void *stream, const usot_conv_desc *c2, const voi
  * w1 [CN][CO], b1, t, M (= conv2's output pixels), CM, CO, CN, act2; d->t2 is ignored */
 extern "C" int usot_conv_pw_pair_lp(void *stream, const usot_conv_desc *c2, const usot_pw_pair_desc *d, int dtype)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     if (!c2 || !d || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
     if (!d->w3p || !d->b3 || !d->res || !d->y || !d->w1 || !d->b1 || !d->t) return USOT_EINVAL;
     if (d->act2 != USOT_ACT_NONE && d->act2 != USOT_ACT_RELU) return USOT_EINVAL;

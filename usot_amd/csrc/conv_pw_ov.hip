@@ -558,7 +558,8 @@ extern "C" int usot_conv_pw_ov_lp(void *stream, const usot_conv_desc *c2, const 
     (void)stream; (void)c2; (void)d; (void)dtype; (void)ws; (void)g_ov_dbg;
     return USOT_ENOTBUILT;
 #else
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     if (!c2 || !d || !ws || (dtype != 0 && dtype != 1)) return USOT_EINVAL;
     if (!d->w3p || !d->b3 || !d->res || !d->y || !d->w1 || !d->b1 || !d->t) return USOT_EINVAL;
     if (d->act2 != USOT_ACT_NONE && d->act2 != USOT_ACT_RELU) return USOT_EINVAL;
@@ -571,8 +572,10 @@ extern "C" int usot_conv_pw_ov_lp(void *stream, const usot_conv_desc *c2, const 
         if ((uintptr_t)q % 16) return USOT_EINVAL;
     const long M = (long)c2->N * c2->OH * c2->OW;
     if (M != d->M || M * OV_CO * 2 >= 0x7fffffffL || (long)c2->N * c2->H * c2->W * OV_CM >= 0x7fffffffL) return USOT_EINVAL;   // 32-bit offsets
-    static const uint16_t *zero_page = nullptr;
-    static int cus = 0;
+    static const uint16_t *zero_page_d[USOT_MAX_DEV] = {};
+    const uint16_t *&zero_page = zero_page_d[usot_dv];
+    static int cus_d[USOT_MAX_DEV] = {};
+    int &cus = cus_d[usot_dv];
     if (!zero_page) {
         void *zp = nullptr;
         if (hipGetSymbolAddress(&zp, HIP_SYMBOL(ov_zero16)) != hipSuccess || !zp) return USOT_ELAUNCH;
@@ -596,7 +599,8 @@ extern "C" int usot_conv_pw_ov_lp(void *stream, const usot_conv_desc *c2, const 
     p.err = p.flags + 2 * p.NP;
     p.dbg = g_ov_dbg;
     p.t2s = (uint16_t *)((char *)ws + ((2 * (long)p.NP + 1) * 4 + 255) / 256 * 256);
-    static bool raised[2] = {false, false};
+    static bool raised_d[USOT_MAX_DEV][2] = {};
+    bool (&raised)[2] = raised_d[usot_dv];
     const void *fn = dtype ? (const void *)conv_pw_ov_kernel<true> : (const void *)conv_pw_ov_kernel<false>;
     if (!raised[dtype]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, OV_LDS) != hipSuccess) return USOT_ELAUNCH;

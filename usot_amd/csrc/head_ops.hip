@@ -977,15 +977,14 @@ extern "C" int usot_thin_conv3x3_f32(void *stream, const usot_conv_desc *d, int 
     return USOT_OK;
 }
 
-extern "C" int usot_device_guard(void)
+extern "C" int usot_device_slot(void)
 {
-    static std::atomic<int> bound{-1};
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return USOT_ELAUNCH;
-    int expect = -1;
-    if (bound.compare_exchange_strong(expect, dev)) return USOT_OK;
-    return expect == dev ? USOT_OK : USOT_ESTATE;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= USOT_MAX_DEV) return -1;
+    return dev;
 }
+
+extern "C" int usot_device_guard(void) { return usot_device_slot() >= 0 ? USOT_OK : USOT_ESTATE; }
 
 extern "C" int usot_abi_version(void) { return 5; }   // 2: usot_conv_desc.w_frag; 3: w_scale; 4: x_split / y_split; 5: ovf (conv + pw_pair descriptors), decode's out[9]
 

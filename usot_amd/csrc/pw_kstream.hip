@@ -185,15 +185,18 @@ __global__ __launch_bounds__(512) void pw_kstream_kernel(const KStreamK p)
 template <int K, int N>
 int ks_launch(void *stream, const KStreamK &p, int dtype)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     constexpr int lds = KS_S * N * 8 * 16 + ((N / 4 > (K / 64) * 8 ? N / 4 : (K / 64) * 8)) * 16;
-    static bool raised[2] = {false, false};
+    static bool raised_d[USOT_MAX_DEV][2] = {};
+    bool (&raised)[2] = raised_d[usot_dv];
     const void *fn = dtype ? (const void *)pw_kstream_kernel<K, N, true> : (const void *)pw_kstream_kernel<K, N, false>;
     if (!raised[dtype]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return USOT_ELAUNCH;
         raised[dtype] = true;
     }
-    static int cus = 0;
+    static int cus_d[USOT_MAX_DEV] = {};
+    int &cus = cus_d[usot_dv];
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;

@@ -295,10 +295,12 @@ __global__ __launch_bounds__(512) void pw_pair_kernel(const PwK p)
 template <int CM, int CO, int CN>
 int pw_launch(hipStream_t s, const PwK &p, int dtype)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     using G16 = PwCfg<CM, CO, CN, true>;
     constexpr int lds = G16::LDS_BYTES;
-    static bool raised[2] = {false, false};
+    static bool raised_d[USOT_MAX_DEV][2] = {};
+    bool (&raised)[2] = raised_d[usot_dv];
     const void *fn = dtype ? (const void *)pw_pair_kernel<CM, CO, CN, true> : (const void *)pw_pair_kernel<CM, CO, CN, false>;
     if (lds > 64 * 1024 && !raised[dtype]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return USOT_ELAUNCH;
@@ -306,7 +308,8 @@ int pw_launch(hipStream_t s, const PwK &p, int dtype)
     }
     int cus = 256;
     {
-        static int cached = 0;
+        static int cached_d[USOT_MAX_DEV] = {};
+    int &cached = cached_d[usot_dv];
         if (!cached) {
             int dev = 0;
             hipDeviceProp_t prop;

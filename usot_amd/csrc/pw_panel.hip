@@ -380,15 +380,18 @@ __global__ __launch_bounds__(512) void pw_panel_kernel(const PanelK p)
 template <int K, int N, int CN, int PB>
 int panel_launch(hipStream_t s, PanelK p, int dtype)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     using C = PanelCfg<K, N, CN, PB>;
-    static bool raised[2] = {false, false};
+    static bool raised_d[USOT_MAX_DEV][2] = {};
+    bool (&raised)[2] = raised_d[usot_dv];
     const void *fn = dtype ? (const void *)pw_panel_kernel<K, N, CN, PB, true> : (const void *)pw_panel_kernel<K, N, CN, PB, false>;
     if (C::LDS_BYTES > 64 * 1024 && !raised[dtype]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) return USOT_ELAUNCH;
         raised[dtype] = true;
     }
-    static int cus = 0;
+    static int cus_d[USOT_MAX_DEV] = {};
+    int &cus = cus_d[usot_dv];
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;

@@ -415,11 +415,13 @@ template <int CM, int CO, int CN, int S = 1, bool H16 = false> int launch(hipStr
 
 template <int CIN, int CM, int CO, int CN> int launch_triple(hipStream_t s, const PwT &q)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     constexpr int NB2 = CN / 16, KS2 = NB2 >= 8 ? 1 : 8 / NB2, KS0 = 8 / (CM / 16);
     constexpr int PSF = ps_floats<CM, KS0>() > ps_floats<CN, KS2>() ? ps_floats<CM, KS0>() : ps_floats<CN, KS2>();
     const size_t lds = (size_t)(16 * (9 * CIN + 4) + 16 * (CM + 4) + 16 * (CO + 4) + PSF) * sizeof(float);
-    static bool raised = false;
+    static bool raised_d[USOT_MAX_DEV] = {};
+    bool &raised = raised_d[usot_dv];
     if (lds > 64 * 1024 && !raised) {
         if (hipFuncSetAttribute((const void *)pw_triple_f32_kernel<CIN, CM, CO, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return USOT_ELAUNCH;
@@ -506,11 +508,13 @@ __global__ __launch_bounds__(512) void pw_single_f32_kernel(const Pw1 p)
 
 template <int K, int N, int S> int launch1(hipStream_t s, const Pw1 &p)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     constexpr int NB = N / 16 / S, KS = NB >= 8 ? 1 : 8 / NB;
     const size_t lds = (size_t)(16 * (K + 4) + (KS > 1 ? (KS - 1) * 16 * (NB * 16 + 4) : 0)) * sizeof(float);
     if (lds > 64 * 1024) {
-        static bool raised = false;
+        static bool raised_d[USOT_MAX_DEV] = {};
+    bool &raised = raised_d[usot_dv];
         if (!raised) {
             if (hipFuncSetAttribute((const void *)pw_single_f32_kernel<K, N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return USOT_ELAUNCH;
@@ -605,10 +609,12 @@ __global__ __launch_bounds__(512) void stream_conv3x3_f32_kernel(const PwC p)
 
 template <int CIN, int N, int S> int launch3(hipStream_t s, const PwC &p)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     constexpr int K = 9 * CIN, NB = N / 16 / S, KS = NB >= 8 ? 1 : 8 / NB;
     const size_t lds = (size_t)(16 * (K + 4) + (KS > 1 ? (KS - 1) * 16 * (NB * 16 + 4) : 0)) * sizeof(float);
-    static bool raised = false;
+    static bool raised_d[USOT_MAX_DEV] = {};
+    bool &raised = raised_d[usot_dv];
     if (lds > 64 * 1024 && !raised) {
         if (hipFuncSetAttribute((const void *)stream_conv3x3_f32_kernel<CIN, N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return USOT_ELAUNCH;

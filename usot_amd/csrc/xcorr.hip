@@ -1087,7 +1087,8 @@ extern "C" int usot_groupdw_auto_variant(int total_samples, int OW)
 
 static int groupdw_multi_impl(void *stream, const usot_groupdw_desc *d, int nseg, int out_dtype)
 {
-    if (usot_device_guard() != USOT_OK) return USOT_ESTATE;     // per-device statics below: one GPU per process (common.h)
+    const int usot_dv = usot_device_slot();        // per-device launcher state below (common.h)
+    if (usot_dv < 0) return USOT_ESTATE;
     if (!d || nseg < 1 || nseg > 3) return USOT_EINVAL;
     static const int hk[3] = {5, 3, 5}, wk[3] = {5, 5, 3};
     GdwK p;
@@ -1136,7 +1137,8 @@ static int groupdw_multi_impl(void *stream, const usot_groupdw_desc *d, int nseg
         p.nty = p.ntx = 1;
         const long nunits = p.C == 256 ? 8L * ((total + 1) / 2) : (long)(p.C / 64) * total;
         if (nunits > 0x7fffffffL) return USOT_EINVAL;
-        static int slots = 0;
+        static int slots_d[USOT_MAX_DEV] = {};
+    int &slots = slots_d[usot_dv];
         if (!slots) {
             (void)hipFuncSetAttribute((const void *)groupdw_dmap_kernel<25, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDmaP<25>::LDS_BYTES);
             (void)hipFuncSetAttribute((const void *)groupdw_dmap_kernel<25, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDmaP<25>::LDS_BYTES);
@@ -1167,7 +1169,8 @@ static int groupdw_multi_impl(void *stream, const usot_groupdw_desc *d, int nseg
         p.total = total;
         p.nty = p.ntx = 1;
         const long nb = p.C == 256 ? 8L * ((total + 1) / 2) : (long)(p.C / 64) * total;
-        static bool attr_set = false;
+        static bool attr_set_d[USOT_MAX_DEV] = {};
+    bool &attr_set = attr_set_d[usot_dv];
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<25, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<25>::LDS_BYTES);
             (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<27, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<27>::LDS_BYTES);
@@ -1176,7 +1179,8 @@ static int groupdw_multi_impl(void *stream, const usot_groupdw_desc *d, int nseg
             attr_set = true;
         }
         if (out_dtype) {
-            static bool attr_lp = false;
+            static bool attr_lp_d[USOT_MAX_DEV] = {};
+    bool &attr_lp = attr_lp_d[usot_dv];
             if (!attr_lp) {
                 (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<25, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<25>::LDS_BYTES);
                 (void)hipFuncSetAttribute((const void *)groupdw_dma_kernel<27, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GdwDma<27>::LDS_BYTES);

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libusot_hip.so')
 ACT_NONE, ACT_RELU, ACT_EXP, ACT_CONF = 0, 1, 2, 3
 
 EXPORTS = (
-    'usot_abi_version', 'usot_device_guard', 'usot_strerror', 'usot_conv2d_f32', 'usot_conv_tile_count',
+    'usot_abi_version', 'usot_device_guard', 'usot_device_slot', 'usot_strerror', 'usot_conv2d_f32', 'usot_conv_tile_count',
     'usot_conv_tile_info', 'usot_conv_tile_built', 'usot_experiments_built', 'usot_conv_bf16_tile_built', 'usot_conv_tile_name', 'usot_conv_tile_wfrag', 'usot_conv_tile_xsplit', 'usot_conv_tile_kreq', 'usot_conv_tile_streamk', 'usot_conv_streamk_ws_floats', 'usot_conv_pack_wfrag_f32', 'usot_conv_ws_floats', 'usot_stem_conv_f32', 'usot_maxpool3x3s2_f32',
     'usot_xcorr_depthwise_f32', 'usot_groupdw_f32', 'usot_conf_fusion_reduce_f32',
     'usot_prroi_pool_forward_f32', 'usot_prroi_pool_backward_f32', 'usot_prroi_pool_coor_backward_f32', 'usot_permute4_f32', 'usot_decode_f32',
