@@ -289,3 +289,61 @@ def test_split16_pack_reconstructs_the_bank_to_22_bits():
     fr = pp[:rows * k].view(torch.float16).view(rows // 16, k // 32, 2, 4, 16, 8).float()
     rec2 = (fr[:, :, 0] + fr[:, :, 1]).permute(0, 3, 1, 2, 4).reshape(rows, k) * (pp[rows * k:] * hip.SPLIT16_X_SCALE)[:, None]
     assert ((rec2 - w).abs() <= amax * 2.0 ** -21).all()
+
+
+def _bilinear_f64(img, dw, dh):
+    """Exact (float64) bilinear resampling on half-pixel centres with edge clamping, by torch - an implementation that shares
+    nothing with hostutils.resize_bilinear_u8."""
+    import torch.nn.functional as F
+    t = torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None]
+    return F.interpolate(t, size=(dh, dw), mode='bilinear', align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+
+
+def test_resize_against_two_independent_bilinear_implementations():
+    """`cv2` is not in this image, so hostutils.resize_bilinear_u8 (the restatement of cv2.resize's fixed-point INTER_LINEAR,
+    track_utils.py:77-78) cannot be pinned bit for bit.  What CAN be pinned is its sampling geometry and weights:
+    against torch's float64 bilinear interpolation the uint8 result must be the rounded exact value up to the fixed-point
+    scheme's own error (0.5 of rounding + 11-bit weights and the >> 4 / >> 16 truncations: < 0.9 LSB, mean 0.25-0.3), and against
+    Pillow's affine bilinear sampler (another fixed-point implementation) within 1 LSB - at the window sizes the tracker
+    produces (s_x of 127 ... 612 pixels resized to 255 / 127), on noise images (worst case for interpolation error)."""
+    from PIL import Image
+    g = np.random.default_rng(3)
+    for h, w, dh, dw in ((301, 301, 255, 255), (188, 188, 255, 255), (612, 612, 255, 255), (127, 127, 255, 255),
+                         (97, 131, 127, 127), (509, 509, 255, 255), (260, 260, 271, 271)):
+        img = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = hostutils.resize_bilinear_u8(img, dw, dh).astype(np.float64)
+        exact = _bilinear_f64(img, dw, dh)
+        d = np.abs(got - exact)
+        assert d.max() < 0.9 and d.mean() < 0.3, (h, w, d.max(), d.mean())
+        assert -0.2 < (got - exact).mean() < 0.02                        # the >> 4 / >> 16 truncations of the scheme bias it by -1/8 LSB, nothing more
+        pil = np.asarray(Image.fromarray(img).transform((dw, dh), Image.AFFINE, (w / dw, 0, 0, 0, h / dh, 0),
+                                                        resample=Image.BILINEAR)).astype(np.float64)
+        assert np.abs(got - pil).max() <= 1.0, (h, w)
+    # a shifted or align_corners=True geometry is NOT within that bound (the check has teeth)
+    img = g.integers(0, 256, (301, 301, 3), dtype=np.uint8)
+    import torch.nn.functional as F
+    t = torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None]
+    wrong = F.interpolate(t, size=(255, 255), mode='bilinear', align_corners=True)[0].permute(1, 2, 0).numpy()
+    assert np.abs(hostutils.resize_bilinear_u8(img, 255, 255) - wrong).max() > 20
+
+
+def test_crop_against_an_independent_restatement_of_the_reference_crop():
+    """track_utils.py:30-119 restated with numpy padding + the float64 bilinear above (no hostutils code): mean-colour canvas,
+    integer window, resize to the model size.  hostutils.get_subwindow_tracking must agree within the fixed-point bound; the
+    device crop kernel is bit-compared with hostutils on the GPU (tests/test_gpu_ops.py::test_device_crop_matches_host_crop)."""
+    g = np.random.default_rng(5)
+    im = g.integers(0, 256, (240, 320, 3), dtype=np.uint8)
+    avg = np.mean(im, axis=(0, 1))
+    for pos, win, size in (((160.0, 120.0), 301, 255), ((5.0, 7.0), 188, 255), ((318.0, 236.0), 401, 255), ((100.5, 60.5), 127, 127),
+                           ((30.0, 200.0), 90, 127)):
+        c = (win + 1) / 2
+        x0, y0 = round(pos[0] - c), round(pos[1] - c)                          # Python 3 round (half to even), track_utils.py:44-46
+        canvas = np.empty((240 + 2 * 640, 320 + 2 * 640, 3), np.uint8)
+        canvas[:] = avg.astype(np.uint8)                                     # the reference assigns float means into a uint8 array
+        canvas[640:640 + 240, 640:640 + 320] = im
+        patch = canvas[640 + y0:640 + y0 + win, 640 + x0:640 + x0 + win]
+        want = patch.astype(np.float64) if win == size else _bilinear_f64(patch, size, size)
+        got, _ = hostutils.get_subwindow_tracking(im, np.array(pos), size, win, avg, out_mode='raw')
+        assert got.shape == (size, size, 3)
+        d = np.abs(got.astype(np.float64) - want)
+        assert d.max() < (0.9 if win != size else 1e-12), (pos, win, d.max())
