@@ -573,6 +573,16 @@ int usot_rows_copy_multi_f32(void *stream, int nseg, const float *const *src, co
 int usot_plan_add_rows_copy_multi(void *plan, int nseg, const float *const *src, const int32_t *idx_dev,
                                   float *const *dst, int n_rows, const int32_t *row_len, int scatter,
                              int32_t *stash_next);
+/* append + gather in one launch (the session's 'defer_append' = 2 frame): fresh[0..3] = the memory feature the previous frame
+ * pooled and its three kernel-side encodings (one row each), bank[0..3] their banks, picked[0..2] the frame's picked-kernel
+ * buffers of banks 1-3 (n_pick <= 32 rows each).  Row idx_dev[slot_pos] of every bank receives the fresh row, rows
+ * idx_dev[0 .. n_pick) of banks 1-3 are gathered - one that IS the appended row is taken from `fresh`.  idx_dev may be pinned
+ * host memory (the control block).  Replaces usot_rows_copy_multi_f32 (scatter) + usot_rows_copy_multi_f32 (gather);
+ * the reference keeps the queue in Python lists (usot_tracker.py:222-264). */
+int usot_rows_append_gather_f32(void *stream, const float *const *fresh, float *const *bank, float *const *picked,
+                                const int32_t *row_len, const int32_t *idx_dev, int n_pick, int slot_pos);
+int usot_plan_add_rows_append_gather(void *plan, const float *const *fresh, float *const *bank, float *const *picked,
+                                     const int32_t *row_len, const int32_t *idx_dev, int n_pick, int slot_pos);
 int usot_plan_add_rows_copy(void *plan, const float *src, const int32_t *idx_dev, float *dst,
                             int n_rows, int row_len, int scatter);
 int usot_plan_fork(void *plan, int lane);

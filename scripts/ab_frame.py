@@ -15,7 +15,7 @@ for c in cfgs:
         k, v = kv.split('=')
         k = k.lower()                         # engine.OPTIONS keys: stream_1x1=0, fused_f32_sliced=1, ...
         cur = engine.OPTIONS[k]
-        engine.OPTIONS[k] = set() if isinstance(cur, set) else type(cur)(int(v))
+        engine.OPTIONS[k] = set() if isinstance(cur, set) else (int(v) if isinstance(cur, bool) and int(v) > 1 else type(cur)(int(v)))
     model, _ = bench.build_model(0, 1, dev)
     sess, crops, p = bench.open_stream(model, dev, seed=0)
     conf = bench.Confidences()

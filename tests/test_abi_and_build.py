@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(libpath):
     # the reference's own native symbols (prroi_pooling_gpu_impl.cuh:20-54)
     assert {'PrRoIPoolingForwardGpu', 'PrRoIPoolingBackwardGpu', 'PrRoIPoolingCoorBackwardGpu'} <= set(syms)
     L.usot_abi_version.restype = ctypes.c_int
-    assert L.usot_abi_version() == 5
+    assert L.usot_abi_version() == 6
     L.usot_strerror.restype = ctypes.c_char_p
     assert b'invalid' in L.usot_strerror(-1)
 

@@ -1136,6 +1136,43 @@ def test_rows_copy_multi_gather_scatter_and_stash():
     assert hip.lib().usot_rows_copy_multi_f32(hip.stream(), 1, pp(outs), hip.ptr(idx), pp(dsts), 4, rl, 1, hip.ptr(stash)) != 0
 
 
+@pytest.mark.parametrize('pinned', [False, True], ids=['idx_dev', 'idx_pinned'])
+def test_rows_append_gather(pinned):
+    """usot_rows_append_gather_f32 (the session's default frame since round 6): ONE launch appends a fresh row to four banks
+    and gathers n_pick rows of banks 1-3 - a picked row that IS the appended one must come from the fresh row (the bank row is
+    being written by other workgroups of the same launch), every other bank row stays untouched, and the index block may be
+    pinned host memory (the session's control block).  Against plain indexing; the reference keeps the queue in Python lists
+    (usot_tracker.py:222-264)."""
+    import ctypes as C
+    lens = [7 * 7 * 256, 5 * 5 * 256, 3 * 5 * 256, 64]
+    g = torch.Generator().manual_seed(11)
+    for picks, slot in (([0, 1, 4, 9, 9, 3, 9], 9), ([0, 1, 2, 2, 2, 2, 2], 11), ([5], 5), (list(range(12)) + [3] * 20, 7)):
+        banks = [torch.randn(12, n, generator=g).to(DEV) for n in lens]
+        before = [b.clone() for b in banks]
+        fresh = [torch.randn(1, n, generator=g).to(DEV) for n in lens]
+        nq = len(picks)
+        idx_h = torch.tensor(picks + [-5, 123, 456, slot], dtype=torch.int32)          # slot_pos = nq + 3, as in the control block
+        idx = idx_h.pin_memory() if pinned else idx_h.to(DEV)
+        picked = [torch.full((nq, n), -1.0, device=DEV) for n in lens[1:]]
+        p4 = lambda ts: (C.c_void_p * 4)(*[t.data_ptr() for t in ts])
+        p3 = (C.c_void_p * 3)(*[t.data_ptr() for t in picked])
+        hip.check(hip.lib().usot_rows_append_gather_f32(hip.stream(), p4(fresh), p4(banks), p3, (C.c_int32 * 4)(*lens),
+                                                        C.c_void_p(idx.data_ptr()), nq, nq + 3), 'rows_append_gather')
+        torch.cuda.synchronize()
+        for k in range(4):
+            want = before[k].clone()
+            want[slot] = fresh[k][0]
+            assert torch.equal(banks[k], want), (k, picks, slot)
+            if k:
+                assert torch.equal(picked[k - 1], want[torch.tensor(picks).long()]), (k, picks, slot)
+    # argument checks: more than 32 picked rows, a row length that is not a multiple of four floats, a missing pointer
+    bad = (C.c_void_p * 3)(picked[0].data_ptr(), None, picked[2].data_ptr())
+    L = hip.lib()
+    assert L.usot_rows_append_gather_f32(hip.stream(), p4(fresh), p4(banks), p3, (C.c_int32 * 4)(*lens), C.c_void_p(idx.data_ptr()), 33, 36) != 0
+    assert L.usot_rows_append_gather_f32(hip.stream(), p4(fresh), p4(banks), p3, (C.c_int32 * 4)(lens[0], 6, lens[2], lens[3]), C.c_void_p(idx.data_ptr()), 4, 7) != 0
+    assert L.usot_rows_append_gather_f32(hip.stream(), p4(fresh), p4(banks), bad, (C.c_int32 * 4)(*lens), C.c_void_p(idx.data_ptr()), 4, 7) != 0
+
+
 @pytest.mark.parametrize('size,n', [(255, 2), (127, 1), (271, 1), (63, 3)])
 def test_stem_pool_f32(size, n):
     """Fused fp32 MFMA stem + max-pool vs conv2d + relu + max_pool2d (fp32: accumulation order only)."""

@@ -511,6 +511,46 @@ __global__ __launch_bounds__(256) void rows_copy_multi_kernel(const RowsK k, con
     }
 }
 
+// Append + gather in ONE launch (round 6, the session's 'defer_append' = 2 frame): the row the PREVIOUS frame pooled (bank 0)
+// and its three encodings (banks 1-3) go to row idx[slot_pos] of their banks, and the n_pick rows idx[0 .. n_pick) of banks
+// 1-3 are gathered into the frame's picked-kernel buffers - a picked row that IS the appended row is read from the new
+// row itself, so the two halves need no ordering between them.  blockIdx.y: 0-3 = append bank y, 4-6 = gather bank y - 3.
+// idx lives in pinned HOST memory (the control block): a workgroup fetches its words once.
+struct RowsAG {
+    const float *fresh[4];
+    float *bank[4];
+    float *picked[3];
+    int row_len4[4];
+    int n_pick, slot_pos;
+};
+__global__ __launch_bounds__(256) void rows_append_gather_kernel(const RowsAG k, const int *__restrict__ idx)
+{
+    __shared__ int rows[33];
+    if (threadIdx.x < k.n_pick) rows[threadIdx.x] = idx[threadIdx.x];
+    if (threadIdx.x == 32) rows[32] = idx[k.slot_pos];
+    __syncthreads();
+    const int slot = rows[32];
+    const int job = blockIdx.y;
+    if (job < 4) {
+        const int rl = k.row_len4[job];
+        const f32x4 *__restrict__ src = (const f32x4 *)k.fresh[job];
+        f32x4 *__restrict__ dst = (f32x4 *)k.bank[job] + (long)slot * rl;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < rl; i += gridDim.x * 256) dst[i] = src[i];
+        return;
+    }
+    const int b = job - 3;
+    const int rl = k.row_len4[b];
+    const f32x4 *__restrict__ fresh = (const f32x4 *)k.fresh[b];
+    const f32x4 *__restrict__ bank = (const f32x4 *)k.bank[b];
+    f32x4 *__restrict__ dst = (f32x4 *)k.picked[b - 1];
+    const int total = k.n_pick * rl;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / rl, e = i - r * rl;
+        const int row = rows[r];
+        dst[i] = row == slot ? fresh[e] : bank[(long)row * rl + e];
+    }
+}
+
 // ---- SiamFC crop on the device (lib/utils/track_utils.py:30-119): window extraction with
 // mean-colour padding, OpenCV-style fixed-point bilinear resize (the arithmetic restated in
 // usot_amd/hostutils.py::resize_bilinear_u8) and HWC uint8 -> CHW float32, one thread per
@@ -579,23 +619,53 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const CropK p)
 }
 
 // ---- decode (usot_tracker.py:138-163): one workgroup, double precision like the numpy
-// reference (its grids are float64, so everything after the float32 sigmoid promotes) -------
-__global__ __launch_bounds__(256) void decode_kernel(
+// reference (its grids are float64, so everything after the float32 sigmoid promotes).
+// One response cell per thread at S <= 32 (a single pass: the loads of all six maps in flight
+// together), the argmax as a wavefront butterfly + one LDS round over the waves, and the WINNING
+// thread — which still holds its cell's box, score and penalty in registers — publishes the
+// results (round 6; before: 256 threads x 3 cells, an 8-step LDS tree, thread 0 recomputing the
+// winner's cell: 10.8 us per frame in the graph).  Same expressions, same order: bit-identical.
+struct DecCell {
+    double ps, x1, y1, x2, y2, pen;
+    float sc;
+    int i;
+};
+
+// np.argmax semantics (usot_tracker.py:163): first maximum, and a NaN counts as the maximum (the first NaN wins);
+// index 0x7fffffff = "no cell" loses to everything
+__device__ __forceinline__ bool dec_better(double ov, int oi, double mv, int mi)
+{
+    const bool on = ov != ov, mn = mv != mv;
+    return oi != 0x7fffffff &&
+        (mi == 0x7fffffff || (on && !mn) || (on == mn && (on ? oi < mi : (ov > mv || (ov == mv && oi < mi)))));
+}
+
+__global__ __launch_bounds__(1024) void decode_kernel(
     const float *__restrict__ cls, const float *__restrict__ cls_mem, const float *__restrict__ bbox,
     const double *__restrict__ window, double *__restrict__ out, int S, int instance_size, int stride,
     float ratio, double penalty_k, double window_influence, double tw, double th,
     const double *__restrict__ tsz_dev, float *__restrict__ roi_out)
 {
-    if (tsz_dev) { tw = tsz_dev[0]; th = tsz_dev[1]; }
-    __shared__ double best_v[256];
-    __shared__ int best_i[256];
+    // the control block lives in pinned HOST memory: every word the kernel needs from it is fetched here, in one round trip over
+    // the link (the ovf address and the frame tag used to be read at the end, one dependent round trip each)
+    unsigned long long oa = 0;
+    double tag = 0.0;
+    if (tsz_dev) {
+        tw = tsz_dev[0]; th = tsz_dev[1];
+        oa = ((const unsigned long long *)tsz_dev)[3];
+        tag = tsz_dev[6];
+    }
+    __shared__ double wave_v[16];
+    __shared__ int wave_i[16];
+    __shared__ int win_i;
     const int n = S * S;
     const double tpad = (tw + th) * 0.5;
     const double tsz = sqrt((tw + tpad) * (th + tpad));
     const double tratio = tw / th;
-    double bv = -1e300;
-    int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    DecCell best;
+    best.ps = -1e300; best.i = 0x7fffffff;
+    best.x1 = best.y1 = best.x2 = best.y2 = best.pen = 0.0; best.sc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int r = i / S, c = i - r * S;
         const double gx = (double)((c - S / 2) * stride + instance_size / 2);
         const double gy = (double)((r - S / 2) * stride + instance_size / 2);
@@ -612,50 +682,41 @@ __global__ __launch_bounds__(256) void decode_kernel(
         rr = fmax(rr, 1.0 / rr);
         const double pen = exp(-(rr * sr - 1.0) * penalty_k);
         const double ps = pen * (double)sc * (1.0 - window_influence) + window[i] * window_influence;
-        // np.argmax semantics (usot_tracker.py:163): first maximum, and a NaN counts as the maximum
-        // (the first NaN wins).  `bi` stays a valid index whatever the maps hold.
-        if (bi == 0x7fffffff || ps > bv || (ps != ps && bv == bv)) { bv = ps; bi = i; }
-    }
-    best_v[threadIdx.x] = bv;
-    best_i[threadIdx.x] = bi;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-            const double ov = best_v[threadIdx.x + off];
-            const int oi = best_i[threadIdx.x + off];
-            const double mv = best_v[threadIdx.x];
-            const int mi = best_i[threadIdx.x];
-            const bool on = ov != ov, mn = mv != mv;
-            const bool take = oi != 0x7fffffff &&
-                (mi == 0x7fffffff || (on && !mn) || (on == mn && (on ? oi < mi : (ov > mv || (ov == mv && oi < mi)))));
-            if (take) {
-                best_v[threadIdx.x] = ov;
-                best_i[threadIdx.x] = oi;
-            }
+        if (dec_better(ps, i, best.ps, best.i)) {
+            best.ps = ps; best.i = i; best.sc = sc; best.pen = pen;
+            best.x1 = x1; best.y1 = y1; best.x2 = x2; best.y2 = y2;
         }
-        __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const int i = min(max(best_i[0], 0), n - 1);
-        const int r = i / S, c = i - r * S;
-        const double gx = (double)((c - S / 2) * stride + instance_size / 2);
-        const double gy = (double)((r - S / 2) * stride + instance_size / 2);
-        const float s0 = 1.0f / (1.0f + expf(-cls[i]));
-        const float s1 = 1.0f / (1.0f + expf(-cls_mem[i]));
-        const float sc = ratio * s0 + (1.0f - ratio) * s1;
-        const double x1 = gx - (double)bbox[i], y1 = gy - (double)bbox[n + i];
-        const double x2 = gx + (double)bbox[2 * n + i], y2 = gy + (double)bbox[3 * n + i];
-        const double w = x2 - x1, h = y2 - y1;
-        const double pad = (w + h) * 0.5;
-        double sr = sqrt((w + pad) * (h + pad)) / tsz;
-        sr = fmax(sr, 1.0 / sr);
-        double rr = tratio / (w / h);
-        rr = fmax(rr, 1.0 / rr);
-        out[0] = (double)i;
-        out[1] = (double)sc;
-        out[2] = exp(-(rr * sr - 1.0) * penalty_k);
-        out[3] = x1; out[4] = y1; out[5] = x2; out[6] = y2;
-        out[7] = best_v[0];
+    double rv = best.ps;
+    int ri = best.i;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(rv, off, 64);
+        const int oi = __shfl_xor(ri, off, 64);
+        if (dec_better(ov, oi, rv, ri)) { rv = ov; ri = oi; }
+    }
+    const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { wave_v[wv] = rv; wave_i[wv] = ri; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        rv = threadIdx.x < nw ? wave_v[threadIdx.x] : -1e300;
+        ri = threadIdx.x < nw ? wave_i[threadIdx.x] : 0x7fffffff;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(rv, off, 64);
+            const int oi = __shfl_xor(ri, off, 64);
+            if (dec_better(ov, oi, rv, ri)) { rv = ov; ri = oi; }
+        }
+        if (threadIdx.x == 0) win_i = ri;
+    }
+    __syncthreads();
+    // `win_i` is a valid cell whatever the maps hold (every cell beats "no cell"); its owner publishes
+    if (best.i == win_i) {
+        out[0] = (double)best.i;
+        out[1] = (double)best.sc;
+        out[2] = best.pen;
+        out[3] = best.x1; out[4] = best.y1; out[5] = best.x2; out[6] = best.y2;
+        out[7] = best.ps;
         if (roi_out) {
             // usot_tracker.py:329-350 (pool_label_search): the S-point axis of the response
             // map applied to the search feature; box rounded to float32 first (np.array(...,
@@ -664,7 +725,7 @@ __global__ __launch_bounds__(256) void decode_kernel(
             const double hi = (double)((S - 1 - S / 2) * stride + instance_size / 2);
             const double slope = (double)(2 * (S / 2)) / (hi - lo);
             const double gap = 1.0 / slope;
-            const double bx[4] = {x1, y1, x2, y2};
+            const double bx[4] = {best.x1, best.y1, best.x2, best.y2};
             roi_out[0] = 0.f;
             for (int e = 0; e < 4; ++e) {
                 double v = (double)(float)bx[e];
@@ -675,7 +736,6 @@ __global__ __launch_bounds__(256) void decode_kernel(
         if (tsz_dev) {
             // tsz_dev[3] (as a 64-bit integer): 0, or the address of the frame's sticky split-fp16 "a sum was not finite" word
             // (usot_conv_desc.ovf).  Its value travels with the results (out[9]) and the word is cleared for the next frame.
-            const unsigned long long oa = ((const unsigned long long *)tsz_dev)[3];
             if (oa) {                                 // (then `out` has 10 doubles)
                 int *f = (int *)(uintptr_t)oa;
                 out[9] = (double)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -684,12 +744,19 @@ __global__ __launch_bounds__(256) void decode_kernel(
             // completion tag for a host that polls the (pinned, coherent) result block instead of
             // waiting for the whole stream: results first, system-scope fence, then the tag
             __threadfence_system();
-            out[8] = tsz_dev[6];
+            out[8] = tag;
         }
     }
 }
 
 }  // namespace
+
+// one thread per response cell up to 1024 cells (S <= 32), whole wavefronts
+static inline unsigned decode_threads(int S)
+{
+    const int n = S * S;
+    return (unsigned)(n >= 1024 ? 1024 : (n + 63) / 64 * 64);
+}
 
 extern "C" int usot_conf_fusion_reduce_f32(void *stream, const float *cv, float *out,
                                            int B, int M, int P, int C)
@@ -852,7 +919,7 @@ extern "C" int usot_decode_f32(void *stream, const float *cls, const float *cls_
                                double tw, double th)
 {
     if (!cls || !cls_mem || !bbox || !window || !out || S <= 0 || S > 64) return USOT_EINVAL;
-    hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cls, cls_mem, bbox,
+    hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(decode_threads(S)), 0, (hipStream_t)stream, cls, cls_mem, bbox,
                        window, out, S, instance_size, stride, ratio, penalty_k, window_influence, tw, th,
                        (const double *)nullptr, (float *)nullptr);
     USOT_CHECK_LAUNCH();
@@ -867,7 +934,7 @@ extern "C" int usot_decode_dev_f32(void *stream, const float *cls, const float *
                                    double window_influence, const double *tsz_dev, float *roi_out)
 {
     if (!cls || !cls_mem || !bbox || !window || !out || !tsz_dev || S <= 0 || S > 64) return USOT_EINVAL;
-    hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cls, cls_mem, bbox,
+    hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(decode_threads(S)), 0, (hipStream_t)stream, cls, cls_mem, bbox,
                        window, out, S, instance_size, stride, ratio, penalty_k, window_influence, 1.0, 1.0,
                        tsz_dev, roi_out);
     USOT_CHECK_LAUNCH();
@@ -916,6 +983,29 @@ extern "C" int usot_rows_copy_multi_f32(void *stream, int nseg, const float *con
     k.nseg = nseg; k.n_rows = n_rows; k.scatter = scatter; k.stash = stash_next;
     const int blocks = (int)((most + 255) / 256 > 1024 ? 1024 : (most + 255) / 256);
     hipLaunchKernelGGL(rows_copy_multi_kernel, dim3(blocks, nseg), dim3(256), 0, (hipStream_t)stream, k, (const int *)idx_dev);
+    USOT_CHECK_LAUNCH();
+    return USOT_OK;
+}
+
+extern "C" int usot_rows_append_gather_f32(void *stream, const float *const *fresh, float *const *bank, float *const *picked,
+                                           const int32_t *row_len, const int32_t *idx_dev, int n_pick, int slot_pos)
+{
+    if (!fresh || !bank || !picked || !row_len || !idx_dev || n_pick < 1 || n_pick > 32 || slot_pos < 0) return USOT_EINVAL;
+    RowsAG k;
+    long most = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (!fresh[i] || !bank[i] || row_len[i] <= 0 || (row_len[i] & 3)) return USOT_EINVAL;
+        if (((uintptr_t)fresh[i] % 16) || ((uintptr_t)bank[i] % 16)) return USOT_EINVAL;
+        if (i && (!picked[i - 1] || ((uintptr_t)picked[i - 1] % 16))) return USOT_EINVAL;
+        k.fresh[i] = fresh[i]; k.bank[i] = bank[i]; k.row_len4[i] = row_len[i] / 4;
+        if (i) k.picked[i - 1] = picked[i - 1];
+        const long t = (long)(i ? n_pick : 1) * k.row_len4[i];
+        if (t > most) most = t;
+    }
+    if (most > 0x3fffffffL) return USOT_EINVAL;
+    k.n_pick = n_pick; k.slot_pos = slot_pos;
+    const int blocks = (int)((most + 255) / 256 > 64 ? 64 : (most + 255) / 256);
+    hipLaunchKernelGGL(rows_append_gather_kernel, dim3(blocks, 7), dim3(256), 0, (hipStream_t)stream, k, (const int *)idx_dev);
     USOT_CHECK_LAUNCH();
     return USOT_OK;
 }
@@ -986,7 +1076,7 @@ extern "C" int usot_device_slot(void)
 
 extern "C" int usot_device_guard(void) { return usot_device_slot() >= 0 ? USOT_OK : USOT_ESTATE; }
 
-extern "C" int usot_abi_version(void) { return 5; }   // 2: usot_conv_desc.w_frag; 3: w_scale; 4: x_split / y_split; 5: ovf (conv + pw_pair descriptors), decode's out[9]
+extern "C" int usot_abi_version(void) { return 6; }   // 2: usot_conv_desc.w_frag; 3: w_scale; 4: x_split / y_split; 5: ovf (conv + pw_pair descriptors), decode's out[9]; 6: usot_rows_append_gather_f32
 
 extern "C" const char *usot_strerror(int code)
 {

@@ -24,7 +24,7 @@ extern "C" int usot_conv_resolve_tile(const usot_conv_desc *d);
 
 namespace {
 
-enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3, K_PW3, K_PANEL, K_PANELP, K_HALO, K_KSTREAM, K_CKSTREAM, K_BNECK1, K_BNECKT, K_CONVPW, K_CONVPWP, K_CONVPWO };
+enum Kind { K_CONV, K_STEM, K_POOL, K_GDW, K_CONF, K_PRROI, K_PERM, K_DECODE, K_FORK, K_JOIN, K_ROWS, K_CONVB, K_CVTB, K_POOLB, K_STEMB, K_ROWSM, K_THIN, K_STEMP, K_PWPAIR, K_PW1, K_SC3, K_PW3, K_PANEL, K_PANELP, K_HALO, K_KSTREAM, K_CKSTREAM, K_BNECK1, K_BNECKT, K_CONVPW, K_CONVPWP, K_CONVPWO, K_ROWSAG };
 
 constexpr int kLanes = 4;     // lane 0 is the caller's stream
 
@@ -163,6 +163,13 @@ int issue(Plan *pl, hipStream_t main_stream, bool lanes, hipEvent_t *marks = nul
             float *dsts[4] = {(float *)op.l[0], (float *)op.l[1], (float *)op.l[2], (float *)op.l[3]};
             rc = usot_rows_copy_multi_f32(s, op.i[0], srcs, (const int32_t *)op.p[4], dsts, op.i[1], &op.i[3], op.i[2],
                                           (int32_t *)op.p[5]);
+            break;
+        }
+        case K_ROWSAG: {
+            const float *fresh[4] = {(const float *)op.p[0], (const float *)op.p[1], (const float *)op.p[2], (const float *)op.p[3]};
+            float *bank[4] = {(float *)op.l[0], (float *)op.l[1], (float *)op.l[2], (float *)op.l[3]};
+            float *picked[3] = {(float *)op.l[4], (float *)op.l[5], (float *)op.l[6]};
+            rc = usot_rows_append_gather_f32(s, fresh, bank, picked, &op.i[2], (const int32_t *)op.p[4], op.i[0], op.i[1]);
             break;
         }
         case K_STEMB:
@@ -488,6 +495,19 @@ extern "C" int usot_plan_add_rows_copy_multi(void *plan, int nseg, const float *
     for (int i = 0; i < nseg; ++i) { op->p[i] = src[i]; op->l[i] = (int64_t)(uintptr_t)dst[i]; op->i[3 + i] = row_len[i]; }
     op->p[4] = idx_dev; op->p[5] = stash_next;
     op->i[0] = nseg; op->i[1] = n_rows; op->i[2] = scatter;
+    return USOT_OK;
+}
+
+extern "C" int usot_plan_add_rows_append_gather(void *plan, const float *const *fresh, float *const *bank, float *const *picked,
+                                                const int32_t *row_len, const int32_t *idx_dev, int n_pick, int slot_pos)
+{
+    if (!fresh || !bank || !picked || !row_len || !idx_dev || n_pick < 1 || n_pick > 32 || slot_pos < 0) return USOT_EINVAL;
+    Op *op = push(plan, K_ROWSAG);
+    if (!op) return USOT_ESTATE;
+    for (int i = 0; i < 4; ++i) { op->p[i] = fresh[i]; op->l[i] = (int64_t)(uintptr_t)bank[i]; op->i[2 + i] = row_len[i]; }
+    for (int i = 0; i < 3; ++i) op->l[4 + i] = (int64_t)(uintptr_t)picked[i];
+    op->p[4] = idx_dev;
+    op->i[0] = n_pick; op->i[1] = slot_pos;
     return USOT_OK;
 }
 

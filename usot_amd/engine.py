@@ -544,6 +544,13 @@ class Builder:
                             # the shortcut conv's reduction rides in the pair's residual read (consumed ONLY there: the deferred-conv2 path below)
                             sc, _, _ = self.conv_deferred('b%d.ds' % bi, ds, cur, n, h, h, tile=rd[0], ks=rd[1])
                             sc_parts, sc_bias = rd[1], ds.b
+                        elif getattr(self, 'piggyback', None) and self.batch and len(self.piggyback) <= 3:
+                            # Session 'defer_append' = 2: the previous frame's memory-feature encoders ride in this launch (independent
+                            # problems on the same tile; the shortcut conv's 248 workgroups leave CUs free)
+                            pg, self.piggyback = self.piggyback, None
+                            res = self.conv_batch([('b%d.ds' % bi, ds, cur, n, h, h, {})] + pg)
+                            sc = res[0][0]
+                            self.piggy_out = [r[0] for r in res[1:]]
                         else:
                             sc, _, _ = self.conv('b%d.ds' % bi, ds, cur, n, h, h)
             elif ds is not None and self.lanes < 3:   # shortcut conv shares conv1's launch
@@ -1302,9 +1309,13 @@ DEFAULT_OPTIONS = {
     # (CM, CO, CN) of the fused fp32 pointwise pairs that run on split-fp16 operands too (layer3's six conv3 + conv1 pairs)
     'split16_pairs': {(256, 1024, 256)},
     'split16_min_m': 64,
-    # Session: frame t's bank append (encode + scatter) runs at the start of frame t + 1's graph on a side branch, not behind
-    # frame t's result tag (Session._build)
-    'defer_append': False,
+    # Session: frame t's bank append (encode + scatter) is DEFERRED into frame t + 1's graph instead of sitting behind frame t's result
+    # tag (Session._build; Session.flush() for readers of the bank between frames).  1 / True: on a side branch at the start of the
+    # graph (measured + 29 us: a fork + join cost more than the kernels they hide)
+    # 2 (round 6): the same deferral with NO side branch - the previous frame's encoder convolutions ride in layer2's shortcut-conv
+    # launch and one kernel in front of the heads appends + gathers (usot_rows_append_gather_f32); 0 / False = in-frame append
+    'defer_append': 2,
+    'defer_append_enc_ks': 4,       # split-K of the riding encoder problems (36 k-tiles: 9 each, a quarter of the shortcut conv's loop)
     # layer3's conv2 -> conv3 (+ residual + ReLU) of the batched low-precision backbone in ONE launch (csrc/conv_pw_lp.hip: a 256-pixel
     # panel of conv2's output stays in LDS).  Bit-identical to the two launches; measured in the batch-64 bf16 step.
     # Value: the conv2 widths it is used for ((256,) = layer3; 128 = layer2's last block, whose next conv1 has no pair form)
@@ -1440,6 +1451,8 @@ ENV_SWITCHES = {      # environment variable -> (option, parser)
     'USOT_FUSED_F32_SLICED': ('fused_f32_sliced', lambda v: v == '1'),
     'USOT_SPIN_SECONDS': ('spin_seconds', float),
     'USOT_SPLIT16_F32': ('split16_f32', lambda v: v == '1'),
+    'USOT_DEFER_APPEND': ('defer_append', int),
+    'USOT_DEFER_APPEND_ENC_KS': ('defer_append_enc_ks', int),
     'USOT_CONV_PW_LP': ('conv_pw_lp', lambda v: tuple(int(t) for t in v.split(',') if t)),      # '' = off, '256', '256,128'
     'USOT_CONV_PW_PAIR_LP': ('conv_pw_pair_lp', lambda v: v == '1'),
     'USOT_CONV_PW_RS': ('conv_pw_rs', lambda v: v == '1'),
@@ -1811,9 +1824,28 @@ class Session:
         # the branch joins in front of the heads.  Every control-block read (gather rows, the previous scatter row, the crop's
         # address in the stem, the target size in the decode) happens before the tag, so the host may rewrite the block as soon
         # as collect() returns; flush() appends the pending feature for anybody who reads the bank between frames.
-        self.defer = bool(e.opt['defer_append']) and e.lanes == 0
+        self.defer = int(e.opt['defer_append']) if e.lanes == 0 else 0
         self._pending, self._prev_slot = False, self.cap - 1
-        if self.defer:
+        if self.defer == 2:
+            # 'defer_append' = 2 (round 6): the same deferral WITHOUT a side branch.  The previous frame's three encoder
+            # convolutions ride in the launch of layer2's shortcut conv (Builder.piggyback), and ONE kernel in front of the heads
+            # appends feature + encodings to their banks and gathers this frame's picked rows (usot_rows_append_gather_f32: a
+            # picked row that is the appended one is read from the fresh encodings) - two launches fewer than the in-frame
+            # append (encode, scatter, gather -> one), nothing forked.  The stem reads the crop's address from the control block.
+            bld.piggyback = [('enc_k%d.mem' % g, e.W.enc_k[g], self.feat, 1, 7, 7,
+                              dict(cout=256, act=ACT_RELU, force_ks=e.opt['defer_append_enc_ks'])) for g in range(3)]
+            xf, hf = bld.backbone(self.x, 1, self.size, need_stem=False, xptr_dev=idx_dev[nq + 1:nq + 3])
+            new_enc = getattr(bld, 'piggy_out', None)
+            if new_enc is None:                      # no stand-alone shortcut conv took them (other lowering options): own launch
+                bld.piggyback = None
+                new_enc = bld.encode_kernel(self.feat, 1, 256, 'mem')
+            fresh, banks = [self.feat] + new_enc, [self.bank] + self.bank_enc
+            rl = [int(b[0].numel()) for b in banks]
+            hip.check(L.usot_plan_add_rows_append_gather(
+                pl.h, (C.c_void_p * 4)(*[t.data_ptr() for t in fresh]), (C.c_void_p * 4)(*[t.data_ptr() for t in banks]),
+                (C.c_void_p * 3)(*[t.data_ptr() for t in mk]), (C.c_int32 * 4)(*rl), hip.ptr(idx_dev), nq, nq + 3),
+                'plan_add_rows_append_gather')
+        elif self.defer:
             pl.fork(3)
             new_enc = bld.encode_kernel(self.feat, 1, 256, 'mem')       # the PREVIOUS frame's pooled feature
             self._rows_multi(pl, [self.feat] + new_enc, idx_dev[nq + 3:], [self.bank] + self.bank_enc, 1, scatter=1)

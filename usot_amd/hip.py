@@ -26,7 +26,7 @@ EXPORTS = (
     'usot_plan_add_conv_bf16', 'usot_plan_add_cvt_bf16', 'usot_plan_add_maxpool_bf16',
     'usot_conv2d_lp', 'usot_cvt_f32_to_lp', 'usot_maxpool3x3s2_lp', 'usot_plan_add_conv_lp', 'usot_plan_add_cvt_lp',
     'usot_plan_add_maxpool_lp', 'usot_stem_pool_lp', 'usot_plan_add_stem_pool_lp',
-    'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
+    'usot_rows_copy_multi_f32', 'usot_plan_add_rows_copy_multi', 'usot_rows_append_gather_f32', 'usot_plan_add_rows_append_gather', 'usot_thin_conv3x3_f32', 'usot_plan_add_thin_conv', 'usot_stem_pool_f32', 'usot_plan_add_stem_pool',
     'usot_plan_profile', 'usot_plan_op_info', 'usot_rows_copy_f32', 'usot_plan_add_rows_copy', 'usot_crop_resize_u8_f32', 'usot_conv_resolve_tile', 'usot_decode_dev_f32',
     'PrRoIPoolingForwardGpu', 'usot_groupdw_auto_variant',
     'usot_stem_pool_ind_f32', 'usot_plan_add_stem_pool_ind', 'usot_bw_probe', 'usot_conv_kstream_lp', 'usot_conv_kstream_supported', 'usot_plan_add_conv_kstream', 'usot_pw_kstream_lp', 'usot_pw_kstream_supported', 'usot_plan_add_pw_kstream', 'usot_conv3x3_halo_lp', 'usot_conv3x3_halo_supported', 'usot_plan_add_conv3x3_halo', 'usot_bneck_first_lp', 'usot_bneck_first_supported', 'usot_plan_add_bneck_first', 'usot_bneck_tail_lp', 'usot_bneck_tail_supported', 'usot_plan_add_bneck_tail', 'usot_pw_panel_lp', 'usot_pw_panel_supported', 'usot_pw_panel_pixels', 'usot_pw_panel_min_pixels', 'usot_plan_add_pw_panel', 'usot_pw_panel_pair_lp', 'usot_pw_panel_pair_supported', 'usot_plan_add_pw_panel_pair', 'usot_conv_pw_lp', 'usot_conv_pw_supported', 'usot_conv_pw_pixels', 'usot_plan_add_conv_pw', 'usot_conv_pw_pair_lp', 'usot_conv_pw_pair_supported', 'usot_plan_add_conv_pw_pair', 'usot_conv_pw_ov_lp', 'usot_conv_pw_ov_supported', 'usot_conv_pw_ov_ws_bytes', 'usot_plan_add_conv_pw_ov', 'usot_conv_pw_ov_trace', 'usot_stem_conv_mu_f32', 'usot_stem_pool_mu_f32', 'usot_plan_add_stem_pool_mu', 'usot_plan_add_stem_mu', 'usot_pw_pair_lp', 'usot_pw_pair_layout', 'usot_pw_pair_supported', 'usot_plan_add_pw_pair', 'usot_pw_pair_f32', 'usot_pw_pair_f32s', 'usot_pw_pair_f32s_supported', 'usot_pw_pair_f32_supported', 'usot_pw_pair_f32_ws_floats', 'usot_pw_single_f32', 'usot_pw_single_f32_supported', 'usot_plan_add_pw_single', 'usot_stream_conv3x3_f32', 'usot_stream_conv3x3_f32_supported', 'usot_plan_add_stream_conv3x3', 'usot_pw_triple_f32', 'usot_pw_triple_f32_supported', 'usot_plan_add_pw_triple',
@@ -156,6 +156,8 @@ def lib():
         L.usot_plan_add_thin_conv.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.usot_rows_copy_multi_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.usot_plan_add_rows_copy_multi.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.usot_rows_append_gather_f32.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int]
+        L.usot_plan_add_rows_append_gather.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int]
         L.usot_crop_resize_u8_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 9
         L.usot_plan_add_conv_bf16.argtypes = [C.c_void_p, C.c_void_p]
         L.usot_plan_add_conv_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
