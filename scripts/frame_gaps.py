@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""From a rocprofv3 --kernel-trace rocpd database of the default bench: per frame (a frame starts at each
-rows_copy_multi gather that follows a scatter), the GPU-busy time inside the frame, the gaps between its kernels, and the
+"""From a rocprofv3 --kernel-trace rocpd database of the default bench: per frame (a frame starts at its stem kernel;
+before round 6 at the rows_copy_multi gather in front of it), the GPU-busy time inside the frame, the gaps between its kernels, and the
 gap between the frame's last kernel and the next frame's first one."""
 import sqlite3, sys
 import numpy as np
@@ -8,11 +8,12 @@ db = sqlite3.connect(sys.argv[1])
 rows = db.execute('select s.display_name, k.start, k.end from rocpd_kernel_dispatch k '
                   'join rocpd_info_kernel_symbol s on k.kernel_id = s.id order by k.start').fetchall()
 starts = [i for i, r in enumerate(rows) if 'stem_pool_f32' in r[0]]
-starts = [i - 1 for i in starts if i > 0 and 'rows_copy_multi' in rows[i - 1][0]]
+if not any('rows_append_gather' in r[0] for r in rows):        # before round 6's 'defer_append' = 2 a frame began with the gather
+    starts = [i - 1 for i in starts if i > 0 and 'rows_copy_multi' in rows[i - 1][0]]
 frames = []
 for a, b in zip(starts[:-1], starts[1:]):
     ks = rows[a:b]
-    if not 40 <= len(ks) <= 70:
+    if not 36 <= len(ks) <= 70:
         continue
     busy = sum(e - s for _, s, e in ks)
     inner = sum(max(0, ks[i + 1][1] - ks[i][2]) for i in range(len(ks) - 1))
@@ -32,7 +33,7 @@ pos = collections.defaultdict(list)
 names = {}
 for a, b in zip(starts[:-1], starts[1:]):
     ks = rows[a:b]
-    if not 40 <= len(ks) <= 70 or (rows[b][1] - ks[0][1]) / 1e3 < 900:
+    if not 36 <= len(ks) <= 70 or (rows[b][1] - ks[0][1]) / 1e3 < 900:
         continue
     for i in range(1, len(ks)):
         pos[i].append(max(0, ks[i][1] - ks[i - 1][2]) / 1e3)

@@ -1315,7 +1315,9 @@ DEFAULT_OPTIONS = {
     # 2 (round 6): the same deferral with NO side branch - the previous frame's encoder convolutions ride in layer2's shortcut-conv
     # launch and one kernel in front of the heads appends + gathers (usot_rows_append_gather_f32); 0 / False = in-frame append
     'defer_append': 2,
-    'defer_append_enc_ks': 4,       # split-K of the riding encoder problems (36 k-tiles: 9 each, a quarter of the shortcut conv's loop)
+    # split-K of the riding encoder problems (36 k-tiles): short workgroups that leave the shortcut conv's CUs early.  Frame graph on one
+    # box (scripts/ab_frame.py): ks 1: 839.5 us, 2: 830.5, 4: 826.5, 12: 822; on another 3: 837, 9: 842, 12 / 18 / 36: 829-832
+    'defer_append_enc_ks': 12,
     # layer3's conv2 -> conv3 (+ residual + ReLU) of the batched low-precision backbone in ONE launch (csrc/conv_pw_lp.hip: a 256-pixel
     # panel of conv2's output stays in LDS).  Bit-identical to the two launches; measured in the batch-64 bf16 step.
     # Value: the conv2 widths it is used for ((256,) = layer3; 128 = layer2's last block, whose next conv1 has no pair form)
