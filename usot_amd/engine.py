@@ -1827,6 +1827,8 @@ class Session:
         # address in the stem, the target size in the decode) happens before the tag, so the host may rewrite the block as soon
         # as collect() returns; flush() appends the pending feature for anybody who reads the bank between frames.
         self.defer = int(e.opt['defer_append']) if e.lanes == 0 else 0
+        if self.defer == 2 and nq > 32:             # usot_rows_append_gather_f32 takes up to 32 picked rows: longer queues append in-frame
+            self.defer = 0
         self._pending, self._prev_slot = False, self.cap - 1
         if self.defer == 2:
             # 'defer_append' = 2 (round 6): the same deferral WITHOUT a side branch.  The previous frame's three encoder
@@ -1902,8 +1904,9 @@ class Session:
         torch.cuda.current_stream().synchronize()
 
     def flush(self):
-        """'defer_append': append the last frame's pooled feature to the bank NOW (it otherwise happens at the start of the next
-        frame's graph).  For readers of the bank between frames; the next frame rewrites the same row with the same values."""
+        """'defer_append': append the last frame's pooled feature to the bank NOW (it otherwise happens inside the next frame's
+        graph).  For readers of the bank between frames; the next frame rewrites the same row with the same values (mode 2: the
+        same sums in the riding launch's split-K order, i.e. equal to fp32 rounding)."""
         if not getattr(self, 'defer', False) or not self._pending:
             return
         st = getattr(self, '_stream', None) or torch.cuda.current_stream()
