@@ -1760,10 +1760,13 @@ class Session:
     frame, usot_tracker.py:222-258,264).  The three kernel-side encodings of a memory feature
     (connect.py:55-74 `_k` branches, a pure function of the feature) are computed ONCE, when the
     feature is appended, and kept in `bank_enc` beside it; the reference re-encodes the seven
-    picked features every frame (connect.py:251-255).  One frame =
-        gather the 7 picked rows' encodings by device indices -> backbone -> neck -> heads
-        -> decode -> PrRoIPool of the winning box -> encode it -> scatter feature + encodings,
-    with one 64-byte control upload before and one 64-byte result download after.
+    picked features every frame (connect.py:251-255).  One frame (engine option 'defer_append' = 2, the default) =
+        backbone (the PREVIOUS frame's pooled feature is encoded by three problems riding in layer2's shortcut-conv launch)
+        -> neck -> append that feature + its encodings to the banks and gather the 7 picked rows' encodings by the control
+        block's indices (one kernel) -> heads -> decode -> PrRoIPool of the winning box (appended by the NEXT frame, or by
+        flush()),
+    with one ~100-byte control block written before and one 64-byte result block polled after (both pinned host memory the
+    kernels address directly).  'defer_append' = 0 is the in-frame form: gather -> backbone -> ... -> PrRoIPool -> encode -> scatter.
     """
 
     ROW = 7 * 7 * 256
