@@ -276,6 +276,10 @@ class Builder:
         # kernel's out[9]) and Engine.track / features (after the replay), which re-plan on the exact-fp32 tiles and run again.
         self.ovf = None
         self.last_ws = None     # the split-K workspace of the descriptor conv_desc() built last (conv_deferred / conv_batch take their slabs from it)
+        # riders (Session 'defer_append' = 2): up to three independent conv_batch items that the backbone's first stand-alone shortcut
+        # conv takes into ITS launch; their outputs land in `piggy_out` (None = nobody took them: the caller launches them itself)
+        self.piggyback = None
+        self.piggy_out = None
 
     def buf(self, *shape, dtype=torch.float32):
         ch = getattr(self, '_chain', None)
@@ -544,7 +548,7 @@ class Builder:
                             # the shortcut conv's reduction rides in the pair's residual read (consumed ONLY there: the deferred-conv2 path below)
                             sc, _, _ = self.conv_deferred('b%d.ds' % bi, ds, cur, n, h, h, tile=rd[0], ks=rd[1])
                             sc_parts, sc_bias = rd[1], ds.b
-                        elif getattr(self, 'piggyback', None) and self.batch and len(self.piggyback) <= 3:
+                        elif self.piggyback and self.batch and len(self.piggyback) <= 3:
                             # Session 'defer_append' = 2: the previous frame's memory-feature encoders ride in this launch (independent
                             # problems on the same tile; the shortcut conv's 248 workgroups leave CUs free)
                             pg, self.piggyback = self.piggyback, None
@@ -1842,7 +1846,7 @@ class Session:
             bld.piggyback = [('enc_k%d.mem' % g, e.W.enc_k[g], self.feat, 1, 7, 7,
                               dict(cout=256, act=ACT_RELU, force_ks=e.opt['defer_append_enc_ks'])) for g in range(3)]
             xf, hf = bld.backbone(self.x, 1, self.size, need_stem=False, xptr_dev=idx_dev[nq + 1:nq + 3])
-            new_enc = getattr(bld, 'piggy_out', None)
+            new_enc = bld.piggy_out
             if new_enc is None:                      # no stand-alone shortcut conv took them (other lowering options): own launch
                 bld.piggyback = None
                 new_enc = bld.encode_kernel(self.feat, 1, 256, 'mem')
