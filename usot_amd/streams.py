@@ -78,8 +78,12 @@ def broadcast_summary():
 
 
 def _collective_device(device):
-    """gloo moves host memory; RCCL moves device memory."""
-    return torch.device('cpu') if dist.get_backend() == 'gloo' else device
+    """gloo moves host memory; RCCL moves device memory (a caller that names no device, or the CPU, gets this rank's GPU)."""
+    if dist.get_backend() == 'gloo':
+        return torch.device('cpu')
+    if device is None or torch.device(device).type != 'cuda':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device(device)
 
 
 def broadcast_weights(model, src=0, device=None):
