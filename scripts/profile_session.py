@@ -10,7 +10,7 @@ model, _ = bench.build_model(0, 1, dev)
 sess, crops, p = bench.open_stream(model, dev, seed=0)
 conf = bench.Confidences()
 bench.run_frames(sess, crops, p, conf, 20)
-KINDS = {18: 'pw_pair (fused conv3 + next conv1)', 0: 'conv', 1: 'stem', 2: 'maxpool', 3: 'groupdw', 4: 'conf_reduce', 5: 'prroi', 6: 'permute', 7: 'decode', 10: 'rows', 15: 'rows_multi', 16: 'thin_conv (bbox_pred + cls_preds)', 17: 'stem_pool (fused)'}
+KINDS = {18: 'pw_pair (fused conv3 + next conv1)', 0: 'conv', 1: 'stem', 2: 'maxpool', 3: 'groupdw', 4: 'conf_reduce', 5: 'prroi', 6: 'permute', 7: 'decode', 10: 'rows', 15: 'rows_multi', 16: 'thin_conv (bbox_pred + cls_preds)', 17: 'stem_pool (fused)', 32: 'rows_append_gather (append previous feature + gather picks)'}
 prof = sess.plan.profile(20)
 convs = iter(sess.log)
 tot = 0.0
